@@ -26,16 +26,33 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BN_HD __host__ __device__ __forceinline__
+#if defined(BN_INLINE_ALL)
+#define BN_HD_NOINLINE __host__ __device__ __forceinline__
+#else
 #define BN_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#endif
+#else
+#if defined(BN_TRACK_BOUNDS)
+#define BN_HD inline
 #else
 #define BN_HD inline __attribute__((always_inline))
+#endif
 #define BN_HD_NOINLINE __attribute__((noinline))
+#endif
+
+// scheduling fence: stops the machine scheduler from interleaving independent field multiplications (which
+// multiplies live ranges and forces spills); device only, no instruction emitted
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BN_NO_SCHED_FENCE)
+#define BN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BN_SCHED_FENCE() do { } while (0)
 #endif
 
 #if defined(BN_TRACK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <execinfo.h>
 #define BN_TRACKING 1
 #else
 #define BN_TRACKING 0
@@ -60,6 +77,7 @@ inline long double fp_dbg_value(const Fp& a) {
 }
 inline void fp_dbg_fail(const char* what, double x) {
   fprintf(stderr, "bn254 bound violation: %s (%g)\n", what, x);
+  void* bt[32]; int n = backtrace(bt, 32); backtrace_symbols_fd(bt, n, 2);
   abort();
 }
 inline void fp_dbg_check(const Fp& a, const char* where) {
@@ -189,6 +207,7 @@ BN_HD Fp fp_lincomb_reduce(int32_t k1, const Fp& a, int32_t k2, const Fp& b) {
 // ---- Montgomery product (finely-integrated product scanning): one 64-bit accumulator, no carries ---------------
 // requires lb_a * lb_b <= 2.5 (9 * 2^58 * lb_a lb_b + 9 * 2^58 + carry < 2^63)
 BN_HD Fp fp_mul(const Fp& a, const Fp& b) {
+  BN_SCHED_FENCE();
   int64_t acc = 0;
   int32_t m[BN_NL];
   Fp r;
@@ -212,6 +231,7 @@ BN_HD Fp fp_mul(const Fp& a, const Fp& b) {
     acc >>= BN_LB;
   }
   r.v[BN_NL - 1] = (int32_t)acc;
+  BN_SCHED_FENCE();
 #if BN_TRACKING
   if (a.lb * b.lb > 2.5) fp_dbg_fail("fp_mul: accumulator may overflow", a.lb * b.lb);
   BN_SETB(r, 1.0 + a.vb * b.vb / 169.0 + 1e-6, 1.0);
@@ -220,6 +240,7 @@ BN_HD Fp fp_mul(const Fp& a, const Fp& b) {
 }
 // squaring: the 36 cross products are taken once against a doubled operand (45 + 81 mads instead of 162)
 BN_HD Fp fp_sqr(const Fp& a) {
+  BN_SCHED_FENCE();
   int64_t acc = 0;
   int32_t m[BN_NL];
   int32_t a2[BN_NL];
@@ -248,6 +269,7 @@ BN_HD Fp fp_sqr(const Fp& a) {
     acc >>= BN_LB;
   }
   r.v[BN_NL - 1] = (int32_t)acc;
+  BN_SCHED_FENCE();
 #if BN_TRACKING
   if (a.lb * a.lb > 1.25) fp_dbg_fail("fp_sqr: accumulator may overflow", a.lb);  // doubled operand: 2 lb^2 <= 2.5
   BN_SETB(r, 1.0 + a.vb * a.vb / 169.0 + 1e-6, 1.0);

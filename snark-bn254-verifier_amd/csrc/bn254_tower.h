@@ -94,8 +94,8 @@ BN_HD Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
   Fp2 t02 = fp2_sub2(fp2_mul_nl(fp2_add(a.c0, a.c2), fp2_add(b.c0, b.c2)), v0, v2);
   Fp6 r;
   r.c0 = fp2_add(v0, fp2_mul_xi(t12));
-  r.c1 = fp2_add(t01, fp2_mul_xi(v2));
-  r.c2 = fp2_add(t02, v1);
+  r.c1 = fp2_reduce(fp2_add(t01, fp2_mul_xi(v2)));
+  r.c2 = fp2_reduce(fp2_add(t02, v1));
   return r;
 }
 // Chung-Hasan SQR2: 2 products + 3 squarings in Fp2
@@ -108,7 +108,7 @@ BN_HD Fp6 fp6_sqr(const Fp6& a) {
   Fp6 r;
   r.c0 = fp2_add(s0, fp2_mul_xi(s3));
   r.c1 = fp2_add(s1, fp2_mul_xi(s4));
-  r.c2 = fp2_sub2(fp2_add(fp2_add(s1, s2), s3), s0, s4);
+  r.c2 = fp2_reduce(fp2_sub2(fp2_add(fp2_add(s1, s2), s3), s0, s4));
   return r;
 }
 BN_HD Fp6 fp6_mul_fp2(const Fp6& a, const Fp2& b) { Fp6 r; r.c0 = fp2_mul_nl(a.c0, b); r.c1 = fp2_mul_nl(a.c1, b); r.c2 = fp2_mul_nl(a.c2, b); return r; }
@@ -121,8 +121,8 @@ BN_HD Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
   Fp2 t02 = fp2_sub(fp2_mul_nl(fp2_add(a.c0, a.c2), b0), v0);                       // a2 b0
   Fp6 r;
   r.c0 = fp2_add(v0, fp2_mul_xi(t12));
-  r.c1 = t01;
-  r.c2 = fp2_add(t02, v1);
+  r.c1 = fp2_reduce(t01);
+  r.c2 = fp2_reduce(fp2_add(t02, v1));
   return r;
 }
 BN_HD Fp6 fp6_inv(const Fp6& a) {
