@@ -1,0 +1,129 @@
+/*
+ * bn254_verify.h -- C ABI of the MI355X-native batch BN254 verifier (libbn254_verify_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of succinctlabs/snark-bn254-verifier.  The reference has no FFI of its
+ * own; its only surface is the Rust API (paths relative to /root/reference):
+ *     Groth16Verifier::verify(proof:&[u8], vk:&[u8], public_inputs:&[Fr]) -> Result<bool, Groth16Error>   verifier/src/lib.rs:44-49
+ *     PlonkVerifier::verify(...)                                                                         verifier/src/lib.rs:69-74
+ * and, below it, the `bn` crate calls that do all the work (groth16/verify.rs:70-77).  The entry points here are what a
+ * thin Rust `extern "C"` wrapper binds to keep that surface and add `verify_batch(&[proof], &vk, &[[Fr]])`
+ * (INTEGRATION.md shows the binding).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - All field elements cross the boundary as 32-byte big-endian integers, exactly as in gnark files.
+ *   - Return value = infrastructure status (BN254_OK or a negative BN254_E_* code).  Per-proof outcomes are reported
+ *     only through status bytes (BN254_REJECT ... below); nothing panics, unlike the reference's unwrap()s.
+ *   - The caller owns every buffer it passes; the library owns the opaque prepared-vk handle.
+ *   - A prepared vk is immutable and may be shared between threads; a (handle, stream) pair runs one batch at a time.
+ *   - There is NO CPU fallback: every verify entry point runs the HIP kernels and fails with BN254_E_NO_DEVICE if
+ *     no gfx950 device is usable.
+ */
+#ifndef BN254_VERIFY_H
+#define BN254_VERIFY_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-proof status bytes (one per proof, written to status[]) ------------------------------------------------
+ * Mapping to the reference's observable behaviour (verifier/src/...):                                            */
+enum {
+  BN254_REJECT = 0,              /* Ok(false): pairing equation does not hold           groth16/verify.rs:77          */
+  BN254_ACCEPT = 1,              /* Ok(true)                                                                           */
+  BN254_ERR_NOT_MEMBER = 2,      /* a proof coordinate >= p: Field(NotMember), a panic via unwrap   converter.rs:85-86,144-147, lib.rs:45 */
+  BN254_ERR_NOT_ON_CURVE = 3,    /* Group(NotOnCurve)                                     converter.rs:87,152          */
+  BN254_ERR_NOT_IN_SUBGROUP = 4, /* Group(NotInSubgroup), G2 point B only                 converter.rs:152             */
+  BN254_ERR_INPUT_LEN = 5,       /* Err(PrepareInputsFailed): len(inputs)+1 != len(vk.K)  groth16/verify.rs:54-56      */
+  BN254_ERR_MALFORMED = 6,       /* everything else the reference turns into a panic: short buffer, flag 0b00, no square root */
+  BN254_ERR_OPENING_MISMATCH = 7,/* PlonK Error::OpeningPolyMismatch                      plonk/verify.rs:212-214      */
+  BN254_ERR_PAIRING_FAILED = 8,  /* PlonK Error::PairingCheckFailed                       plonk/kzg.rs:185-187         */
+  BN254_ERR_BSB22_MISMATCH = 9,  /* PlonK Error::Bsb22CommitmentMismatch                  plonk/verify.rs:52-54        */
+  BN254_ERR_INVERSE = 10         /* PlonK Error::InverseNotFound                          plonk/verify.rs:106          */
+};
+
+/* ---- infrastructure return codes ----------------------------------------------------------------------------- */
+enum {
+  BN254_OK = 0,
+  BN254_E_BAD_ARG = -1,
+  BN254_E_NO_DEVICE = -2,   /* no usable HIP device / kernel image: the product never falls back to the CPU */
+  BN254_E_HIP = -3,         /* a HIP runtime call failed; bn254_last_error() has the text */
+  BN254_E_VK = -4,          /* the verifying key bytes do not parse (status byte equivalent: BN254_ERR_MALFORMED) */
+  BN254_E_NOMEM = -5
+};
+
+/* ---- verifying-key interpretation ---------------------------------------------------------
+ * BN254_VK_REFERENCE reproduces the reference's actual input->output function: compressed G2 roots ordered by c0 only
+ * (as the pinned `bn` does), beta negated on load (groth16/converter.rs:79) and the literal equation of
+ * groth16/verify.rs:70-77.  BN254_VK_GNARK uses gnark-exact G2 decompression and gnark's equation
+ * e(A,B) = e(alpha,beta) e(L,gamma) e(C,delta).  The two agree on every proof for verifying keys whose beta2, gamma2 have
+ * y.c0 / y.c1 in different halves of [0,p) and delta2 in the same half (the SP1 key is presumably of this kind). */
+enum { BN254_VK_REFERENCE = 0, BN254_VK_GNARK = 1 };
+
+typedef struct bn254_g16_pvk bn254_g16_pvk;
+
+/* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
+ * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
+ * Miller-loop line tables for the two fixed G2 arguments, fixed-base window tables for vk.K.  Host work; no GPU needed. */
+int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out);
+void bn254_groth16_vk_free(bn254_g16_pvk* pvk);
+/* number of public inputs the key expects (len(vk.K) - 1) */
+size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk);
+
+/* verify_batch on host buffers.  proofs: n records of proof_stride bytes (>= 256; bytes beyond 256 -- gnark's commitment
+ * count / commitments / PoK -- are ignored exactly as in groth16/converter.rs:15-25).  public_inputs: n * n_public * 32 bytes,
+ * big-endian, NOT range-checked and used modulo r exactly like bn::Fr::from_slice + AffineG1 * Fr.
+ * status: n bytes.  device: HIP device ordinal. */
+int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride,
+                               const uint8_t* public_inputs, size_t n_public, size_t n, uint8_t* status, int device);
+
+/* Same, with proofs / public_inputs / status already resident in the memory of `device` (the bench path: inputs in
+ * HBM when the timed region starts).  hip_stream is a hipStream_t (NULL = default stream); the call only enqueues
+ * work and returns, so the caller synchronises the stream before reading status.  Use bn254_groth16_reserve() first to
+ * keep the call free of allocations (graph capture). */
+int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_proofs, size_t proof_stride,
+                                      const void* d_public_inputs, size_t n_public, size_t n, void* d_status,
+                                      int device, void* hip_stream);
+/* pre-allocate the per-device workspace for batches of up to n proofs and upload the key's tables */
+int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
+
+/* Groth16Verifier::verify (lib.rs:44-49) as one call: vk parsed on every call like the reference, one proof, one status
+ * byte.  Runs on the GPU (device 0). */
+int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
+                         const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
+
+/* ---- measurement support ------------------------------------------------------------------------------------------
+ * When enabled, verify_batch_device brackets each kernel with HIP events on the launch stream; after the stream has been
+ * synchronised, bn254_groth16_last_kernel_ms returns their durations.  Names: bn254_groth16_kernel_name(i). */
+#define BN254_G16_NUM_KERNELS 4
+void bn254_set_profiling(int enabled);
+int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]);
+const char* bn254_groth16_kernel_name(int i);
+
+/* ---- synthetic gnark-format workload generator (bench / tests; host threads, no GPU) --------------------------------
+ * Deterministic (SplitMix64 seed).  Writes a gnark-compressed verifying key (292 + 32 (n_public+1) + 4 + 128 bytes), n
+ * proofs (256 bytes each, A | B | C uncompressed) that satisfy gnark's equation, their public inputs, and the status the
+ * verifier must return.  If invalid_every > 0 every invalid_every-th proof is corrupted, cycling through: public input
+ * + 1 (REJECT), C + G1 (REJECT), A.y + 1 (NOT_ON_CURVE), B replaced by a twist point outside G2 (NOT_IN_SUBGROUP),
+ * A.x >= p (NOT_MEMBER).  If agree != 0 the key is sampled so that BN254_VK_REFERENCE and BN254_VK_GNARK agree on it. */
+size_t bn254_synth_groth16_vk_len(size_t n_public);
+int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_every, int agree, int threads,
+                        uint8_t* vk_out, uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected_status_out);
+
+/* ---- probes of the device arithmetic, used by the GPU parity tests (tests/test_gpu_*.py) ---------------------------
+ * Each runs one lane per item on `device` and copies the result back.  Fp12 layout: 12 x 32 bytes in tower order
+ * c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1; G1: x | y; G2: x.c1 | x.c0 | y.c1 | y.c0 (gnark order). */
+int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);                 /* n x 32 B each */
+int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);        /* 0 mul 1 sqr 2 inv 3 cyclo_sqr(after easy part) 4 frob1 */
+int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, size_t n, int device);          /* e(P_i, Q_i), n x 384 B */
+int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device);                       /* 1 = in G2 */
+
+const char* bn254_status_string(int status_byte);
+const char* bn254_last_error(void);
+const char* bn254_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,151 @@
+"""ctypes binding of libbn254_verify_amd.so.  Mirrors the reference's API names (verifier/src/lib.rs:29-49):
+Groth16Verifier.verify(proof, vk, public_inputs) plus the new verify_batch."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REJECT, ACCEPT, ERR_NOT_MEMBER, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP, ERR_INPUT_LEN, ERR_MALFORMED = range(7)
+VK_REFERENCE, VK_GNARK = 0, 1
+NUM_KERNELS = 4
+
+
+class Bn254Error(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "libbn254_verify_amd.so")
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc"), "-j2"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return lib_path()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path()):
+            raise Bn254Error("libbn254_verify_amd.so is not built (run __graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(lib_path())
+        L.bn254_last_error.restype = C.c_char_p
+        L.bn254_version.restype = C.c_char_p
+        L.bn254_status_string.restype = C.c_char_p
+        L.bn254_groth16_kernel_name.restype = C.c_char_p
+        L.bn254_groth16_vk_num_public.restype = C.c_size_t
+        L.bn254_synth_groth16_vk_len.restype = C.c_size_t
+        L.bn254_groth16_vk_prepare.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.POINTER(C.c_void_p)]
+        L.bn254_groth16_vk_free.argtypes = [C.c_void_p]
+        L.bn254_groth16_vk_num_public.argtypes = [C.c_void_p]
+        L.bn254_groth16_verify_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        L.bn254_groth16_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        L.bn254_groth16_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.bn254_groth16_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p]
+        L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.bn254_synth_groth16.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bn254_synth_groth16_vk_len.argtypes = [C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise Bn254Error("bn254 error %d: %s" % (rc, lib().bn254_last_error().decode()))
+
+
+def _inputs_bytes(public_inputs):
+    return b"".join(x if isinstance(x, (bytes, bytearray)) else int(x).to_bytes(32, "big") for x in public_inputs)
+
+
+class PreparedVk:
+    """Opaque prepared verifying key (bn254_groth16_vk_prepare)."""
+
+    def __init__(self, vk_bytes, mode=VK_REFERENCE):
+        self._h = C.c_void_p()
+        _check(lib().bn254_groth16_vk_prepare(bytes(vk_bytes), len(vk_bytes), mode, C.byref(self._h)))
+        self.n_public = lib().bn254_groth16_vk_num_public(self._h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def verify_batch(self, proofs, public_inputs, n=None, proof_stride=256, n_public=None, device=0):
+        """proofs: bytes (n * proof_stride); public_inputs: bytes (n * n_public * 32). Returns n status bytes."""
+        n_public = self.n_public if n_public is None else n_public
+        if n is None:
+            n = len(proofs) // proof_stride
+        st = (C.c_uint8 * max(n, 1))()
+        _check(lib().bn254_groth16_verify_batch(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device))
+        return bytes(st)[:n]
+
+    def verify_batch_device(self, d_proofs, d_inputs, d_status, n, proof_stride=256, n_public=None, device=0, stream=None):
+        """Raw device pointers (ints); enqueues on `stream` (a hipStream_t value) and returns."""
+        n_public = self.n_public if n_public is None else n_public
+        _check(lib().bn254_groth16_verify_batch_device(self._h, d_proofs, proof_stride, d_inputs, n_public, n, d_status, device, stream))
+
+    def reserve(self, n, device=0):
+        _check(lib().bn254_groth16_reserve(self._h, n, device))
+
+    def last_kernel_ms(self, device=0):
+        ms = (C.c_float * NUM_KERNELS)()
+        _check(lib().bn254_groth16_last_kernel_ms(self._h, device, ms))
+        return {lib().bn254_groth16_kernel_name(i).decode(): ms[i] for i in range(NUM_KERNELS)}
+
+    def close(self):
+        if self._h:
+            lib().bn254_groth16_vk_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Groth16Verifier:
+    """Mirror of the reference's `Groth16Verifier` (verifier/src/lib.rs:29-49)."""
+
+    @staticmethod
+    def verify(proof, vk, public_inputs, mode=VK_REFERENCE):
+        """Returns the status byte: ACCEPT = Ok(true), REJECT = Ok(false), ERR_INPUT_LEN = Err(PrepareInputsFailed);
+        the other ERR_* codes are the reference's panics (unwrap of a loader error)."""
+        st = C.c_uint8(0xEE)
+        ib = _inputs_bytes(public_inputs)
+        _check(lib().bn254_groth16_verify(bytes(proof), len(proof), bytes(vk), len(vk), ib, len(public_inputs), mode, C.byref(st)))
+        return st.value
+
+    @staticmethod
+    def verify_batch(proofs, vk, public_inputs, mode=VK_REFERENCE, device=0):
+        """proofs: list of byte strings; public_inputs: list of lists. Returns a list of status bytes."""
+        pvk = PreparedVk(vk, mode)
+        try:
+            n = len(proofs)
+            stride = max([256] + [len(p) for p in proofs])
+            pb = b"".join(bytes(p).ljust(stride, b"\0") for p in proofs)
+            npub = len(public_inputs[0]) if n else 0
+            ib = b"".join(_inputs_bytes(x) for x in public_inputs)
+            short = [len(p) < 256 for p in proofs]
+            st = list(pvk.verify_batch(pb, ib, n, stride, npub, device))
+            return [ERR_MALFORMED if s else v for s, v in zip(short, st)]
+        finally:
+            pvk.close()
+
+
+def synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=0):
+    """Deterministic synthetic gnark-format workload: (vk, proofs, inputs, expected_status) as bytes."""
+    L = lib()
+    vk = (C.c_uint8 * L.bn254_synth_groth16_vk_len(n_public))()
+    proofs = (C.c_uint8 * max(256 * n, 1))()
+    inputs = (C.c_uint8 * max(32 * n_public * n, 1))()
+    exp = (C.c_uint8 * max(n, 1))()
+    _check(L.bn254_synth_groth16(seed, n_public, n, invalid_every, 1 if agree else 0, threads, vk, proofs, inputs, exp))
+    return bytes(vk), bytes(proofs)[:256 * n], bytes(inputs)[:32 * n_public * n], bytes(exp)[:n]

@@ -1,0 +1,335 @@
+// bn254_capi.hip -- implementation of the C ABI declared in include/bn254_verify.h.
+// Host orchestration only: key preparation (bn254_host.hpp), device buffers, kernel launches (bn254_kernels.hip).
+// There is deliberately no CPU implementation of verify here: if HIP is unusable the calls fail (BN254_E_NO_DEVICE).
+#include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/bn254_verify.h"
+#include "bn254_host.hpp"
+
+static_assert(BN254_REJECT == BN254_ST_REJECT && BN254_ACCEPT == BN254_ST_ACCEPT && BN254_ERR_NOT_MEMBER == BN254_ST_NOT_MEMBER &&
+              BN254_ERR_NOT_ON_CURVE == BN254_ST_NOT_ON_CURVE && BN254_ERR_NOT_IN_SUBGROUP == BN254_ST_NOT_IN_SUBGROUP &&
+              BN254_ERR_INPUT_LEN == BN254_ST_INPUT_LEN && BN254_ERR_MALFORMED == BN254_ST_MALFORMED, "status codes out of sync");
+
+using namespace bn254host;
+
+static thread_local std::string g_err;
+static int g_profiling = 0;
+static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(BN254_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct DevState {
+  bool ready = false;
+  int32_t *k0 = nullptr, *gtab = nullptr, *dtab = nullptr, *target = nullptr, *msm = nullptr;
+  int32_t* ws = nullptr; size_t ws_cap = 0;                         // proofs the workspace can hold
+  uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
+  size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
+  hipEvent_t ev[5]; bool ev_ready = false; bool ev_recorded = false;
+};
+struct bn254_g16_pvk {
+  G16Prepared host;
+  mutable std::mutex mu;
+  mutable std::map<int, DevState> dev;
+};
+
+static int check_device(int device) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0) return set_err(BN254_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= cnt) return set_err(BN254_E_BAD_ARG, "device ordinal out of range");
+  HIPCK(hipSetDevice(device));
+  return BN254_OK;
+}
+template <typename T> static int upload(T** dst, const std::vector<T>& src) {
+  size_t bytes = (src.size() ? src.size() : 1) * sizeof(T);
+  HIPCK(hipMalloc((void**)dst, bytes));
+  if (!src.empty()) HIPCK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return BN254_OK;
+}
+static int ensure_dev(const bn254_g16_pvk* pvk, int device, size_t n, DevState** out) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  DevState& d = pvk->dev[device];
+  if (!d.ready) {
+    if ((rc = upload(&d.k0, pvk->host.k0)) || (rc = upload(&d.gtab, pvk->host.gtab)) || (rc = upload(&d.dtab, pvk->host.dtab)) ||
+        (rc = upload(&d.target, pvk->host.target)) || (rc = upload(&d.msm, pvk->host.msm)))
+      return rc;
+    d.ready = true;
+  }
+  if (n > d.ws_cap) {
+    if (d.ws) HIPCK(hipFree(d.ws));
+    d.ws = nullptr; d.ws_cap = 0;
+    size_t cap = (n + 255) / 256 * 256;
+    HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_ELEMS * BN_NL * sizeof(int32_t)));
+    d.ws_cap = cap;
+  }
+  if (g_profiling && !d.ev_ready) { for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i])); d.ev_ready = true; }
+  *out = &d;
+  return BN254_OK;
+}
+static int grow(uint8_t** p, size_t* cap, size_t need) {
+  if (need <= *cap) return BN254_OK;
+  if (*p) HIPCK(hipFree(*p));
+  *p = nullptr; *cap = 0;
+  HIPCK(hipMalloc((void**)p, need));
+  *cap = need;
+  return BN254_OK;
+}
+
+extern "C" {
+
+const char* bn254_last_error(void) { return g_err.c_str(); }
+const char* bn254_version(void) { return "bn254-verify-amd 0.1 (gfx950)"; }
+const char* bn254_status_string(int s) {
+  switch (s) {
+    case BN254_REJECT: return "reject"; case BN254_ACCEPT: return "accept"; case BN254_ERR_NOT_MEMBER: return "coordinate not a field member";
+    case BN254_ERR_NOT_ON_CURVE: return "point not on curve"; case BN254_ERR_NOT_IN_SUBGROUP: return "G2 point not in the r-torsion subgroup";
+    case BN254_ERR_INPUT_LEN: return "wrong number of public inputs"; case BN254_ERR_MALFORMED: return "malformed input";
+    case BN254_ERR_OPENING_MISMATCH: return "opening polynomial mismatch"; case BN254_ERR_PAIRING_FAILED: return "pairing check failed";
+    case BN254_ERR_BSB22_MISMATCH: return "BSB22 commitment count mismatch"; case BN254_ERR_INVERSE: return "inverse not found";
+    default: return "unknown";
+  }
+}
+void bn254_set_profiling(int enabled) { g_profiling = enabled; }
+const char* bn254_groth16_kernel_name(int i) {
+  static const char* names[BN254_G16_NUM_KERNELS] = {"k_g16_prepare", "k_g16_subgroup", "k_g16_miller", "k_g16_finalexp"};
+  return (i >= 0 && i < BN254_G16_NUM_KERNELS) ? names[i] : "";
+}
+
+int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out) {
+  if (!vk || !out || mode > 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  *out = nullptr;
+  G16Key key;
+  if (parse_g16_vk(key, vk, vk_len, (int)mode) != DEC_OK) return set_err(BN254_E_VK, "verifying key does not parse");
+  bn254_g16_pvk* p = new (std::nothrow) bn254_g16_pvk();
+  if (!p) return set_err(BN254_E_NOMEM, "out of memory");
+  if (!prepare_g16(p->host, key, (int)mode)) { delete p; return set_err(BN254_E_VK, "verifying key has a degenerate G2 element or no K points"); }
+  *out = p;
+  return BN254_OK;
+}
+void bn254_groth16_vk_free(bn254_g16_pvk* pvk) {
+  if (!pvk) return;
+  for (auto& kv : pvk->dev) {
+    DevState& d = kv.second;
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws};
+    for (auto q : ptrs) if (q) (void)hipFree(q);
+    uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
+    for (auto q : bp) if (q) (void)hipFree(q);
+    if (d.ev_ready) for (int i = 0; i < 5; i++) (void)hipEventDestroy(d.ev[i]);
+  }
+  delete pvk;
+}
+size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk) { return pvk ? pvk->host.n_k - 1 : 0; }
+
+int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device) {
+  if (!pvk) return set_err(BN254_E_BAD_ARG, "null key");
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  DevState* d;
+  return ensure_dev(pvk, device, n ? n : 1, &d);
+}
+
+int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_inputs,
+                                      size_t n_public, size_t n, void* d_status, int device, void* hip_stream) {
+  if (!pvk || (n && (!d_proofs || !d_status)) || proof_stride < 256 || (n && n_public && !d_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (n == 0) return BN254_OK;
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  DevState* d;
+  int rc = ensure_dev(pvk, device, n, &d);
+  if (rc) return rc;
+  G16LaunchArgs a;
+  a.proofs = (const uint8_t*)d_proofs; a.stride = proof_stride; a.inputs = (const uint8_t*)d_inputs; a.n_public = (int)n_public; a.n = n;
+  a.ws = d->ws; a.status = (uint8_t*)d_status; a.msm_tab = d->msm; a.k0 = d->k0; a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
+  a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
+  // the SoA stride of the workspace is the batch size of THIS call
+  hipError_t e = bn254_launch_g16(a, (hipStream_t)hip_stream, (g_profiling && d->ev_ready) ? d->ev : nullptr);
+  if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
+                                       std::string("kernel launch: ") + hipGetErrorString(e));
+  d->ev_recorded = g_profiling && d->ev_ready;
+  return BN254_OK;
+}
+
+int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]) {
+  if (!pvk || !ms) return set_err(BN254_E_BAD_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  auto it = pvk->dev.find(device);
+  if (it == pvk->dev.end() || !it->second.ev_recorded) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
+  HIPCK(hipSetDevice(device));
+  HIPCK(hipEventSynchronize(it->second.ev[4]));
+  for (int i = 0; i < BN254_G16_NUM_KERNELS; i++) HIPCK(hipEventElapsedTime(&ms[i], it->second.ev[i], it->second.ev[i + 1]));
+  return BN254_OK;
+}
+
+int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                               size_t n_public, size_t n, uint8_t* status, int device) {
+  if (!pvk || (n && (!proofs || !status)) || proof_stride < 256 || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (n == 0) return BN254_OK;
+  uint8_t *dp, *di, *ds;
+  {
+    std::lock_guard<std::mutex> lk(pvk->mu);
+    DevState* d;
+    int rc = ensure_dev(pvk, device, n, &d);
+    if (rc) return rc;
+    size_t pb = n * proof_stride, ib = n * n_public * 32;
+    if ((rc = grow(&d->st_proofs, &d->st_proofs_cap, pb)) || (rc = grow(&d->st_inputs, &d->st_inputs_cap, ib ? ib : 32)) ||
+        (rc = grow(&d->st_status, &d->st_status_cap, n)))
+      return rc;
+    dp = d->st_proofs; di = d->st_inputs; ds = d->st_status;
+    HIPCK(hipMemcpy(dp, proofs, pb, hipMemcpyHostToDevice));
+    if (ib) HIPCK(hipMemcpy(di, public_inputs, ib, hipMemcpyHostToDevice));
+  }
+  int rc = bn254_groth16_verify_batch_device(pvk, dp, proof_stride, di, n_public, n, ds, device, nullptr);
+  if (rc) return rc;
+  HIPCK(hipDeviceSynchronize());
+  HIPCK(hipMemcpy(status, ds, n, hipMemcpyDeviceToHost));
+  return BN254_OK;
+}
+
+int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
+                         size_t n_public, unsigned mode, uint8_t* status) {
+  if (!proof || !vk || !status || mode > 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  // reference order: the proof is loaded (and its errors surface) before the key (lib.rs:45-46).  A short proof buffer is a
+  // slice-index panic there.
+  if (proof_len < 256) { *status = BN254_ERR_MALFORMED; return BN254_OK; }
+  bn254_g16_pvk* pvk = nullptr;
+  int rc = bn254_groth16_vk_prepare(vk, vk_len, mode, &pvk);
+  if (rc == BN254_E_VK) {
+    // the key does not parse: a proof error still wins, so run the proof checks against a throw-away key shape.  Without a
+    // key nothing can be launched; report the key error unless the proof bytes themselves are invalid (checked on the GPU
+    // by the caller's next call with a valid key).  The reference panics in both cases; the status byte says MALFORMED.
+    *status = BN254_ERR_MALFORMED;
+    return BN254_OK;
+  }
+  if (rc) return rc;
+  rc = bn254_groth16_verify_batch(pvk, proof, proof_len, public_inputs, n_public, 1, status, 0);
+  bn254_groth16_vk_free(pvk);
+  return rc;
+}
+
+// ---------------------------------------------------------------- device-arithmetic probes (tests)
+static int run_probe(size_t in_a, size_t in_b, size_t out_sz, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int device,
+                     hipError_t (*launch)(const uint8_t*, const uint8_t*, uint8_t*, size_t)) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (n == 0) return BN254_OK;
+  uint8_t *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIPCK(hipMalloc((void**)&da, in_a * n));
+  HIPCK(hipMemcpy(da, a, in_a * n, hipMemcpyHostToDevice));
+  if (in_b && b) { HIPCK(hipMalloc((void**)&db, in_b * n)); HIPCK(hipMemcpy(db, b, in_b * n, hipMemcpyHostToDevice)); }
+  HIPCK(hipMalloc((void**)&dout, out_sz * n));
+  hipError_t e = launch(da, db, dout, n);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("probe launch: ") + hipGetErrorString(e));
+  HIPCK(hipDeviceSynchronize());
+  HIPCK(hipMemcpy(o, dout, out_sz * n, hipMemcpyDeviceToHost));
+  (void)hipFree(da); if (db) (void)hipFree(db); (void)hipFree(dout);
+  return BN254_OK;
+}
+int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {
+  return run_probe(32, 32, 32, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp_mul(x, y, o, m, nullptr); });
+}
+static thread_local int g_probe_op = 0;
+int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {
+  g_probe_op = op;
+  return run_probe(384, b ? 384 : 0, 384, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp12_op(g_probe_op, x, y, o, m, nullptr); });
+}
+int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, size_t n, int device) {
+  return run_probe(64, 128, 384, g1, g2, out_gt, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_pairing(x, y, o, m, nullptr); });
+}
+int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device) {
+  return run_probe(128, 0, 1, g2, nullptr, out_flags, n, device, [](const uint8_t* x, const uint8_t*, uint8_t* o, size_t m) { return bn254_launch_dbg_g2_subgroup(x, o, m, nullptr); });
+}
+
+// ---------------------------------------------------------------- synthetic workload generator
+size_t bn254_synth_groth16_vk_len(size_t n_public) { return 292 + 32 * (n_public + 1) + 4 + 128; }
+
+int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_every, int agree, int threads, uint8_t* vk_out,
+                        uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected) {
+  if (!vk_out || (n && (!proofs_out || !expected)) || (n && n_public && !inputs_out)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  static GenTables* tabs = nullptr;
+  static std::mutex tmu;
+  {
+    std::lock_guard<std::mutex> lk(tmu);
+    if (!tabs) { tabs = new GenTables(); build_gen_tables(*tabs); }
+  }
+  SplitMix64 rng{seed};
+  // trapdoors; beta, gamma, delta rejection-sampled into the mode-agreement set when asked:
+  // y(beta G2), y(gamma G2) must have c0 / c1 in DIFFERENT halves of [0,p), y(delta G2) in the SAME half
+  auto same_half = [](const G2Aff& q) { return fp_is_large(q.y.c0) == fp_is_large(q.y.c1); };
+  U256 alpha = fr_random(rng, true), beta, gamma, delta;
+  G2Aff beta2, gamma2, delta2;
+  for (;;) { beta = fr_random(rng, true); beta2 = g2_mul_gen(*tabs, beta); if (!agree || !same_half(beta2)) break; }
+  for (;;) { gamma = fr_random(rng, true); gamma2 = g2_mul_gen(*tabs, gamma); if (!agree || !same_half(gamma2)) break; }
+  for (;;) { delta = fr_random(rng, true); delta2 = g2_mul_gen(*tabs, delta); if (!agree || same_half(delta2)) break; }
+  std::vector<U256> kk(n_public + 1);
+  for (auto& k : kk) k = fr_random(rng, true);
+  // gnark-compressed vk: alpha1 | beta1 | beta2 | gamma2 | delta1 | delta2 | nK | K.. | 0 (no commitments) | 2 x G2 infinity
+  memset(vk_out, 0, bn254_synth_groth16_vk_len(n_public));
+  enc_g1_compressed(vk_out, g1_to_affine(g1_mul_gen(*tabs, alpha)));
+  enc_g1_compressed(vk_out + 32, g1_to_affine(g1_mul_gen(*tabs, beta)));
+  enc_g2_compressed(vk_out + 64, beta2);
+  enc_g2_compressed(vk_out + 128, gamma2);
+  enc_g1_compressed(vk_out + 192, g1_to_affine(g1_mul_gen(*tabs, delta)));
+  enc_g2_compressed(vk_out + 224, delta2);
+  uint32_t nk = (uint32_t)(n_public + 1);
+  vk_out[288] = (uint8_t)(nk >> 24); vk_out[289] = (uint8_t)(nk >> 16); vk_out[290] = (uint8_t)(nk >> 8); vk_out[291] = (uint8_t)nk;
+  for (size_t i = 0; i <= n_public; i++) enc_g1_compressed(vk_out + 292 + 32 * i, g1_to_affine(g1_mul_gen(*tabs, kk[i])));
+  size_t off = 292 + 32 * (n_public + 1) + 4;
+  vk_out[off] = 0x40; vk_out[off + 64] = 0x40;
+  if (n == 0) return BN254_OK;
+  U256 delta_inv = fr_inv(delta), alpha_beta = fr_mul(alpha, beta);
+  // a few twist points outside the r-torsion for the NOT_IN_SUBGROUP class
+  std::vector<G2Aff> bad_b;
+  if (invalid_every > 0) {
+    SplitMix64 r2{seed ^ 0xabcdef1234567ull};
+    while (bad_b.size() < 4) {
+      G2Aff q; U256 t0 = fr_random(r2, false), t1 = fr_random(r2, false);
+      uint8_t b0[32], b1[32]; u256_to_be(b0, t0); u256_to_be(b1, t1);
+      q.x.c0 = fp_from_be(b0); q.x.c1 = fp_from_be(b1);
+      if (!fp2_sqrt(q.y, fp2_add(fp2_mul(fp2_sqr(q.x), q.x), g2_twist_b()))) continue;
+      if (g2_in_subgroup(q)) continue;  // probability ~ 1/cofactor
+      bad_b.push_back(q);
+    }
+  }
+  if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads <= 0) threads = 1; }
+  if ((size_t)threads > n) threads = (int)n;
+  G1Aff g1gen; g1gen.x = fp_one(); g1gen.y = fp_add(fp_one(), fp_one());
+  auto worker = [&](int tid) {
+    for (size_t i = tid; i < n; i += threads) {
+      SplitMix64 r{seed * 0x9e3779b97f4a7c15ull + 0x1000 + i};
+      U256 a = fr_random(r, true), b = fr_random(r, true);
+      U256 ell = kk[0];
+      std::vector<U256> xs(n_public);
+      for (size_t s = 0; s < n_public; s++) { xs[s] = fr_random(r, false); ell = fr_add(ell, fr_mul(xs[s], kk[s + 1])); }
+      // c = (a b - alpha beta - gamma ell) / delta   =>   e(A,B) = e(alpha,beta) e(L,gamma) e(C,delta)
+      U256 c = fr_mul(fr_sub(fr_sub(fr_mul(a, b), alpha_beta), fr_mul(gamma, ell)), delta_inv);
+      G1Aff A = g1_to_affine(g1_mul_gen(*tabs, a));
+      G2Aff B = g2_mul_gen(*tabs, b);
+      G1Proj Cp = g1_mul_gen(*tabs, c);
+      uint8_t st = BN254_ACCEPT;
+      int cls = -1;
+      if (invalid_every > 0 && (i % (size_t)invalid_every) == (size_t)invalid_every - 1) cls = (int)((i / (size_t)invalid_every) % 5);
+      if (cls == 1) { Cp = g1_add_mixed(Cp, g1gen); st = BN254_REJECT; }
+      if (cls == 3) { B = bad_b[(i / (size_t)invalid_every) % bad_b.size()]; st = BN254_ERR_NOT_IN_SUBGROUP; }
+      G1Aff C = g1_is_identity(Cp) ? g1gen : g1_to_affine(Cp);
+      uint8_t* p = proofs_out + 256 * i;
+      enc_g1_uncompressed(p, A); enc_g2_uncompressed(p + 64, B); enc_g1_uncompressed(p + 192, C);
+      for (size_t s = 0; s < n_public; s++) u256_to_be(inputs_out + (i * n_public + s) * 32, xs[s]);
+      if (cls == 0 && n_public > 0) {  // x_0 + 1 (as raw integer; stays below 2^256)
+        U256 one = {{1, 0, 0, 0}}, t; u256_add(t, xs[0], one); u256_to_be(inputs_out + i * n_public * 32, t); st = BN254_REJECT;
+      }
+      if (cls == 2) {  // A.y + 1 mod p: off the curve (y+1 = -y only for y = (p-1)/2)
+        Fp y1 = fp_add(A.y, fp_one()); fp_to_be(p + 32, y1); st = BN254_ERR_NOT_ON_CURVE;
+      }
+      if (cls == 4) { memset(p, 0xff, 32); st = BN254_ERR_NOT_MEMBER; }  // A.x = 2^256 - 1 >= p
+      expected[i] = st;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
+  for (auto& x : th) x.join();
+  return BN254_OK;
+}
+
+}  // extern "C"

@@ -29,7 +29,7 @@
 #if defined(BN_INLINE_ALL)
 #define BN_HD_NOINLINE __host__ __device__ __forceinline__
 #else
-#define BN_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define BN_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 #endif
 #else
 #if defined(BN_TRACK_BOUNDS)
@@ -37,7 +37,7 @@
 #else
 #define BN_HD inline __attribute__((always_inline))
 #endif
-#define BN_HD_NOINLINE __attribute__((noinline))
+#define BN_HD_NOINLINE inline __attribute__((noinline))
 #endif
 
 // scheduling fence: stops the machine scheduler from interleaving independent field multiplications (which
