@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- Groth16 batch-verify throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the whole hot path (parse + checks + public-input MSM, G2 subgroup test, 3-pair Miller loop, final
+exponentiation, status bytes) over one batch of synthetic gnark-format proofs that are ALREADY RESIDENT IN HBM, followed by
+the one collective of the path: the all_gather of the accept/reject bytes (RCCL over xGMI; a no-op at N = 1).
+Workload at N = 1: BASELINE.json configs[2], batch 2^20, 2 public inputs, 1/16 of the proofs invalid (5 failure classes).
+For N > 1 every rank verifies its own 2^20-proof shard of an N * 2^20 batch (weak scaling, no data-path communication).
+After the timed region the statuses are compared with the generator's expected statuses: a wrong answer aborts the bench.
+
+One JSON line on rank 0, with `roofline` for the dominant kernel (k_g16_miller, durations from HIP events recorded on the
+launch stream inside the timed region) and `cpu_baseline` (the CPU oracle = C port of the reference algorithm, timed on this
+box's host cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per proof of the path = 256 B proof + 64 B public inputs in, 1 B status out
+ALGO_BYTES_PER_PROOF = 321
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+# exact Fp-multiplication count per proof of THIS implementation (DESIGN.md "Work model"; counted by tests/hostsim)
+VALU_PEAK_MAD_PER_S = 35.1e12   # measured v_mad_u64_u32 lane-rate, profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-log2", type=int, default=20, help="proofs per GPU = 2^this (default: BASELINE 2^20)")
+    ap.add_argument("--n-public", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="proofs timed on the host for cpu_baseline")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    sharding = importlib.import_module("snark-bn254-verifier_amd.sharding")
+    L = pkg.lib()
+
+    n = 1 << args.batch_log2                      # per-GPU shard
+    n_total = n * world
+    threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    t0 = time.time()
+    # one verifying key for the whole job (seed fixed), per-rank proofs (the generator derives proof i from seed and index;
+    # different ranks use different seeds for the proofs but must share the key, so generate the key from the common seed and
+    # offset only the proof stream)
+    seed = 0xB2540002
+    vk, proofs, inputs, expected = pkg.synth_groth16(seed, args.n_public, n, invalid_every=16, agree=True, threads=threads)
+    if world > 1 and rank > 0:
+        # same key (same seed), a different slice of the proof stream: rotate this rank's data so shards are not byte-identical
+        k = (rank * 7919) % n
+        proofs = proofs[256 * k:] + proofs[:256 * k]
+        sz = 32 * args.n_public
+        inputs = inputs[sz * k:] + inputs[:sz * k]
+        expected = expected[k:] + expected[:k]
+    gen_s = time.time() - t0
+
+    pvk = pkg.PreparedVk(vk, pkg.VK_REFERENCE)
+    pvk.reserve(n, local_rank)
+    d_proofs = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
+    d_inputs = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(dev)
+    d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    L.bn254_set_profiling(1)
+
+    def step():
+        pvk.verify_batch_device(d_proofs.data_ptr(), d_inputs.data_ptr(), d_status.data_ptr(), n, 256, args.n_public, local_rank, stream.cuda_stream)
+        return sharding.gather_status(d_status, n_total, world)   # the only collective of the path
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = {}
+    t_start = time.perf_counter()
+    full = None
+    for _ in range(args.steps):
+        full = step()
+        # per-kernel HIP-event durations of this step (events were recorded on the launch stream); reading them waits for the
+        # step's last event only, which the next step would have to wait for anyway (same stream)
+        for k, v in pvk.last_kernel_ms(local_rank).items():
+            kernel_ms.setdefault(k, []).append(v)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of the timed work
+    got = bytes(d_status.cpu().numpy().tobytes())
+    assert got == expected, "rank %d: GPU statuses differ from the expected statuses" % rank
+    if world > 1:
+        lo, hi = sharding.shard_bounds(n_total, world, rank)
+        assert bytes(full[lo:hi].cpu().numpy().tobytes()) == expected, "gathered statuses are wrong"
+        assert full.numel() == n_total
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n_total * args.steps / elapsed
+        avg = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
+        dom = max(avg, key=avg.get)
+        dom_s = avg[dom] * 1e-3
+        achieved = ALGO_BYTES_PER_PROOF * n / dom_s / 1e9
+        out = {
+            "metric": "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X",
+            "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch 2^%d Groth16 proofs per GPU, %d public inputs, gnark-format bytes, 1/16 invalid"
+                                   % (args.batch_log2, args.n_public),
+                       "batch_per_gpu": n, "global_batch": n_total, "n_public": args.n_public, "vk_mode": "reference",
+                       "parallelism": "independent proof shards x%d + all_gather of status bytes" % world,
+                       "gen_seconds": round(gen_s, 1)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(dom),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PROOF * n, "avg_launch_ms": avg[dom],
+                         "note": "integer-VALU bound, not HBM bound (SURVEY.md 8(d)); see kernels_ms and DESIGN.md for the VALU roofline"},
+            "kernels_ms": avg,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = _cpu_baseline(args, vk, proofs, inputs, expected)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _measured_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from a committed PMC run (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(p)).get(kernel)
+    except Exception:
+        return None
+
+
+def _cpu_baseline(args, vk, proofs, inputs, expected):
+    """The oracle (C port of the reference algorithm, reference-faithful: vk re-parsed per call, 4 Miller loops + 2 final
+    exponentiations, naive subgroup check) on the host cores of this box, on a prefix of the same workload."""
+    from oracle import oracle as O
+    O.build(); O.lib()
+    m = min(args.cpu_sample, len(expected))
+    cores = len(os.sched_getaffinity(0))  # OpenMP's default team size: every CPU this process may run on
+    sz = 32 * args.n_public
+    O.groth16_verify_many(proofs[:256 * 8], 256, vk, inputs[:sz * 8], args.n_public, 8, O.MODE_REFERENCE)
+    t = time.perf_counter()
+    st = O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:sz * m], args.n_public, m, O.MODE_REFERENCE)
+    dt = time.perf_counter() - t
+    assert st == expected[:m], "oracle disagrees with the expected statuses"
+    return {"value": m / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "first %d proofs of the same batch, %.1f s wall, OpenMP over %d threads; C restatement of the reference algorithm, not the Rust binary" % (m, dt, cores)}
+
+
+if __name__ == "__main__":
+    main()

@@ -116,7 +116,7 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   bool memb = words_lt_p(wx) & words_lt_p(wy);
   G1Aff A; A.x = fp_from_words(wx); A.y = fp_from_words(wy);
   if (!memb) err = BN254_ST_NOT_MEMBER; else if (!g1_on_curve(A)) err = BN254_ST_NOT_ON_CURVE;
-  ws_st(ws, E_AX, ii, A.x); ws_st(ws, E_AY, ii, A.y);
+  if (live) { ws_st(ws, E_AX, i, A.x); ws_st(ws, E_AY, i, A.y); }
 
   // ---- B : x.c1 | x.c0 | y.c1 | y.c0
   G2Aff B;
@@ -134,7 +134,7 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   for (int k = 0; k < 8; k++) d[k] = my[40 + k];
   be_field_to_words(wx, d); membb &= words_lt_p(wx); B.y.c0 = fp_from_words(wx);
   if (err == 0) { if (!membb) err = BN254_ST_NOT_MEMBER; else if (!g2_on_curve(B)) err = BN254_ST_NOT_ON_CURVE; }
-  ws_st2(ws, E_BX, ii, B.x); ws_st2(ws, E_BY, ii, B.y);
+  if (live) { ws_st2(ws, E_BX, i, B.x); ws_st2(ws, E_BY, i, B.y); }
 
   // ---- C
 #pragma unroll
@@ -146,7 +146,7 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   memb = words_lt_p(wx) & words_lt_p(wy);
   G1Aff C; C.x = fp_from_words(wx); C.y = fp_from_words(wy);
   if (!memb) err_c = BN254_ST_NOT_MEMBER; else if (!g1_on_curve(C)) err_c = BN254_ST_NOT_ON_CURVE;
-  ws_st(ws, E_CX, ii, C.x); ws_st(ws, E_CY, ii, C.y);
+  if (live) { ws_st(ws, E_CX, i, C.x); ws_st(ws, E_CY, i, C.y); }
 
   // ---- L = K0 + sum_i x_i K_i, x_i taken as raw 256-bit integers (no range check, as bn::Fr::from_slice)
   G1Aff K0; K0.x = uni_ld(k0); K0.y = uni_ld(k0 + BN_NL);
@@ -176,7 +176,7 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
       }
     }
   }
-  ws_st(ws, E_LX, ii, fp_reduce(L.x)); ws_st(ws, E_LY, ii, fp_reduce(L.y)); ws_st(ws, E_LZ, ii, fp_reduce(L.z));
+  if (live) { ws_st(ws, E_LX, i, fp_reduce(L.x)); ws_st(ws, E_LY, i, fp_reduce(L.y)); ws_st(ws, E_LZ, i, fp_reduce(L.z)); }
   if (live) status[i] = err ? (uint8_t)err : (uint8_t)(BN254_ST_PENDING | err_c);
 }
 

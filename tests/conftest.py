@@ -1,0 +1,48 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+
+    oracle.build()
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module("snark-bn254-verifier_amd")
+
+
+@pytest.fixture(scope="session")
+def fixtures():
+    import json
+
+    g = os.path.join(ROOT, "tests", "golden")
+    fx = json.load(open(os.path.join(g, "fixtures.json")))
+    vk = open(os.path.join(g, "plonk_vk.bin"), "rb").read()
+    return fx, vk
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    """The product's device arithmetic compiled for the host with the bound tracker (tests/hostsim)."""
+    import ctypes
+    import subprocess
+
+    d = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-s", "-C", d, "HSFLAGS=-DHS_WITH_CURVE"])
+    return ctypes.CDLL(os.path.join(d, "libhostsim.so"))

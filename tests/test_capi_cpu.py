@@ -1,0 +1,105 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/bn254_verify.h declares, shares the
+oracle's status codes, prepares keys on the host, refuses to verify without a GPU (no CPU fallback), and its synthetic
+workload generator emits gnark bytes that the ORACLE judges exactly as the generator predicts."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+def test_exports_match_header(pkg):
+    hdr = open(os.path.join(ROOT, "include", "bn254_verify.h")).read()
+    names = set(re.findall(r"\b(bn254_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"bn254_g16_pvk"}
+    assert len(names) >= 18
+    L = pkg.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), "missing export " + n
+    assert L.bn254_version().startswith(b"bn254-verify-amd")
+
+
+def test_status_codes_shared_with_oracle(pkg, O):
+    hdr = open(os.path.join(ROOT, "include", "bn254_verify.h")).read()
+    ohdr = open(os.path.join(ROOT, "oracle", "oracle.h")).read()
+    for name in ("REJECT", "ACCEPT", "ERR_NOT_MEMBER", "ERR_NOT_ON_CURVE", "ERR_NOT_IN_SUBGROUP", "ERR_INPUT_LEN", "ERR_MALFORMED",
+                 "ERR_OPENING_MISMATCH", "ERR_PAIRING_FAILED", "ERR_BSB22_MISMATCH", "ERR_INVERSE"):
+        a = int(re.search(r"BN254_%s = (\d+)" % name, hdr).group(1))
+        b = int(re.search(r"ORC_%s = (\d+)" % name, ohdr).group(1))
+        assert a == b == getattr(O, name)
+    assert (pkg.ACCEPT, pkg.REJECT, pkg.ERR_MALFORMED) == (O.ACCEPT, O.REJECT, O.ERR_MALFORMED)
+
+
+def test_synth_workload_judged_by_oracle(pkg, O):
+    n = 20
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540001, 2, n, invalid_every=2, agree=True, threads=4)
+    assert len(vk) == 520 and len(proofs) == 256 * n and len(inputs) == 64 * n
+    assert set(exp) == {O.ACCEPT, O.REJECT, O.ERR_NOT_ON_CURVE, O.ERR_NOT_IN_SUBGROUP, O.ERR_NOT_MEMBER}
+    # on an agreement-set key the reference-literal and the gnark reading of the key coincide on every proof
+    for mode in (O.MODE_REFERENCE, O.MODE_GNARK):
+        assert O.groth16_verify_many(proofs, 256, vk, inputs, 2, n, mode) == exp
+    # deterministic
+    assert pkg.synth_groth16(0xB2540001, 2, n, invalid_every=2, agree=True, threads=2) == (vk, proofs, inputs, exp)
+
+
+def test_mode_disagreement_outside_agreement_set(pkg, O):
+    """for most gnark keys the reference's literal equation rejects valid proofs."""
+    seen_disagree = False
+    for seed in range(1, 12):
+        vk, proofs, inputs, exp = pkg.synth_groth16(seed, 1, 2, invalid_every=0, agree=False, threads=2)
+        g = O.groth16_verify_many(proofs, 256, vk, inputs, 1, 2, O.MODE_GNARK)
+        r = O.groth16_verify_many(proofs, 256, vk, inputs, 1, 2, O.MODE_REFERENCE)
+        assert g == bytes([O.ACCEPT] * 2)
+        if r != g:
+            seen_disagree = True
+            assert r == bytes([O.REJECT] * 2)
+            break
+    assert seen_disagree
+
+
+def test_vk_prepare_on_host(pkg):
+    vk, _, _, _ = pkg.synth_groth16(3, 2, 0, invalid_every=0, agree=True, threads=1)
+    for mode in (pkg.VK_REFERENCE, pkg.VK_GNARK):
+        p = pkg.PreparedVk(vk, mode)
+        assert p.n_public == 2
+        p.close()
+    L = pkg.lib()
+    h = C.c_void_p()
+    assert L.bn254_groth16_vk_prepare(vk[:100], 100, 0, C.byref(h)) == -4          # short buffer (slice panic in the reference)
+    bad = bytearray(vk); bad[0] &= 0x3F                                           # flag 0b00 (constants.rs:24 panics)
+    assert L.bn254_groth16_vk_prepare(bytes(bad), len(bad), 0, C.byref(h)) == -4
+    bad = bytearray(vk); bad[0] = 0x40; bad[1:32] = bytes(31)                    # compressed G1 infinity: x = 0, 3 is a non-residue
+    assert L.bn254_groth16_vk_prepare(bytes(bad), len(bad), 0, C.byref(h)) == -4
+    bad = bytearray(vk); bad[288:292] = (1000).to_bytes(4, "big")                # nK runs past the buffer
+    assert L.bn254_groth16_vk_prepare(bytes(bad), len(bad), 0, C.byref(h)) == -4
+    assert L.bn254_groth16_vk_prepare(vk, len(vk), 7, C.byref(h)) == -1           # bad mode
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback(pkg):
+    """The product path must fail loudly, not route through any CPU implementation."""
+    vk, proofs, inputs, _ = pkg.synth_groth16(3, 2, 2, invalid_every=0, agree=True, threads=1)
+    p = pkg.PreparedVk(vk)
+    with pytest.raises(pkg.Bn254Error) as ei:
+        p.verify_batch(proofs, inputs)
+    assert "-2" in str(ei.value) or "-3" in str(ei.value)
+    with pytest.raises(pkg.Bn254Error):
+        pkg.Groth16Verifier.verify(proofs[:256], vk, [1, 2])
+
+
+def test_product_does_not_reference_oracle():
+    pk = os.path.join(ROOT, "snark-bn254-verifier_amd")
+    for dp, _, fns in os.walk(pk):
+        if "build" in dp:
+            continue
+        for fn in fns:
+            if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert not re.search(r'#include\s*[<"][^">]*oracle|liboracle|^\s*(from|import)\s+oracle', txt, re.M), fn

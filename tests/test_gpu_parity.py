@@ -1,0 +1,279 @@
+"""GPU parity tests (run on the MI355X box): everything goes through the C ABI of libbn254_verify_amd.so and is compared
+bit-for-bit with the CPU oracle (integer work: no tolerance anywhere)."""
+import ctypes as C
+import json
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def be(v):
+    return int(v).to_bytes(32, "big")
+
+
+def _chk(L, rc):
+    assert rc == 0, L.bn254_last_error()
+
+
+@pytest.fixture(scope="module")
+def L(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; the product has no CPU fallback"
+    return pkg.lib()
+
+
+@pytest.fixture(scope="module")
+def workload(pkg):
+    """512 synthetic proofs, every 4th invalid, cycling through the 5 failure classes."""
+    return pkg.synth_groth16(0xB2540001, 2, 512, invalid_every=4, agree=True, threads=16)
+
+
+def test_device_fp_mul(L):
+    rng = random.Random(5)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 1 << 253, (1 << 254) - 1, 3, 9]
+    xs = edge + [rng.randrange(P) for _ in range(4096 - len(edge))]
+    ys = list(reversed(edge)) + [rng.randrange(P) for _ in range(4096 - len(edge))]
+    n = len(xs)
+    out = (C.c_uint8 * (32 * n))()
+    _chk(L, L.bn254_dbg_fp_mul(b"".join(map(be, xs)), b"".join(map(be, ys)), out, C.c_size_t(n), 0))
+    out = bytes(out)
+    for i in range(n):
+        assert int.from_bytes(out[32 * i:32 * i + 32], "big") == xs[i] * ys[i] % P, i
+
+
+def test_device_fp12_ops(L, O):
+    rng = random.Random(6)
+    n = 64
+    a = b"".join(be(rng.randrange(P)) for _ in range(12 * n)); b = b"".join(be(rng.randrange(P)) for _ in range(12 * n))
+    for op, oop in ((0, 0), (1, 1), (2, 2), (4, 3)):  # mul, sqr, inv, frobenius
+        out = (C.c_uint8 * (384 * n))()
+        _chk(L, L.bn254_dbg_fp12_op(op, a, b if op == 0 else None, out, C.c_size_t(n), 0))
+        out = bytes(out)
+        for i in range(n):
+            assert out[384 * i:384 * i + 384] == O.fp12_op(oop, a[384 * i:384 * i + 384], b[384 * i:384 * i + 384] if op == 0 else None), (op, i)
+    # cyclotomic squaring after the easy part of the final exponentiation
+    out = (C.c_uint8 * (384 * 8))()
+    _chk(L, L.bn254_dbg_fp12_op(3, a, None, out, C.c_size_t(8), 0))
+    out = bytes(out)
+    for i in range(8):
+        x = a[384 * i:384 * i + 384]
+        c = O.fp12_op(0, O.fp12_op(7, x), O.fp12_op(2, x)); c = O.fp12_op(0, O.fp12_op(4, c), c)
+        assert out[384 * i:384 * i + 384] == O.fp12_op(1, c), i
+
+
+def test_device_pairing_and_bilinearity(L, O):
+    rng = random.Random(7)
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    n = 16
+    sa = [rng.randrange(1, R) for _ in range(n)]; sb = [rng.randrange(1, R) for _ in range(n)]
+    g1s = b"".join(O.g1_mul(g1, a) for a in sa); g2s = b"".join(O.g2_mul(g2, b) for b in sb)
+    out = (C.c_uint8 * (384 * n))()
+    _chk(L, L.bn254_dbg_pairing(g1s, g2s, out, C.c_size_t(n), 0))
+    out = bytes(out)
+    for i in range(n):
+        assert out[384 * i:384 * i + 384] == O.pairing(g1s[64 * i:64 * i + 64], g2s[128 * i:128 * i + 128]), i
+    # e(aP, bQ) == e(abP, Q), on the device
+    g1ab = b"".join(O.g1_mul(g1, a * b % R) for a, b in zip(sa, sb))
+    out2 = (C.c_uint8 * (384 * n))()
+    _chk(L, L.bn254_dbg_pairing(g1ab, g2 * n, out2, C.c_size_t(n), 0))
+    assert bytes(out2) == out
+
+
+def _twist_point(O, rng):
+    bt = O.fp2_op(2, O.fp2_op(3, (9, 1)), (3, 0))
+    while True:
+        x = (rng.randrange(P), rng.randrange(P))
+        rhs = O.fp2_op(0, O.fp2_op(2, O.fp2_op(5, x), x), bt)
+        y = O.fp2_op(4, rhs)
+        if y != (0, 0) and O.fp2_op(5, y) == rhs:
+            return be(x[1]) + be(x[0]) + be(y[1]) + be(y[0])
+
+
+def test_device_g2_subgroup(L, O):
+    rng = random.Random(8)
+    g2 = O.g2_gen()
+    pts = [O.g2_mul(g2, rng.randrange(1, R)) for _ in range(6)] + [_twist_point(O, rng) for _ in range(6)]
+    tq = _twist_point(O, rng)
+    pts.append(O.g2_mul(tq, 2 * P - R))          # cofactor cleared: in G2
+    low = O.g2_mul(tq, R)                        # order divides the cofactor: not in G2
+    if low != bytes(128):
+        pts.append(low)
+    off = bytearray(pts[0]); off[127] ^= 1; pts.append(bytes(off))  # not on the twist at all
+    n = len(pts)
+    fl = (C.c_uint8 * n)()
+    _chk(L, L.bn254_dbg_g2_subgroup(b"".join(pts), fl, C.c_size_t(n), 0))
+    for i, q in enumerate(pts):
+        assert fl[i] == (1 if O.g2_subgroup_check(q) == 1 else 0), i
+
+
+def test_verify_batch_vs_oracle_all_classes(pkg, O, workload, L):
+    vk, proofs, inputs, exp = workload
+    n = 512
+    assert set(exp) == {0, 1, 2, 3, 4}
+    for mode, omode in ((pkg.VK_REFERENCE, O.MODE_REFERENCE), (pkg.VK_GNARK, O.MODE_GNARK)):
+        pvk = pkg.PreparedVk(vk, mode)
+        st = pvk.verify_batch(proofs, inputs)
+        assert st == exp
+        m = 96  # oracle (reference-faithful CPU path) on a prefix that contains every class
+        assert O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:64 * m], 2, m, omode) == st[:m]
+        pvk.close()
+
+
+def test_ragged_empty_and_strides(pkg, O, workload, L):
+    vk, proofs, inputs, exp = workload
+    pvk = pkg.PreparedVk(vk)
+    assert pvk.verify_batch(b"", b"", n=0) == b""
+    for n in (1, 63, 65, 257, 300):  # partial waves and partial blocks
+        assert pvk.verify_batch(proofs[:256 * n], inputs[:64 * n], n) == exp[:n], n
+    # gnark raw proofs are 324 bytes (A|B|C|u32 nCommitments|64-byte PoK); bytes past 256 are ignored (groth16/converter.rs:15-25)
+    n = 70
+    raw = b"".join(proofs[256 * i:256 * i + 256] + b"\0\0\0\0" + bytes(64) for i in range(n))
+    assert pvk.verify_batch(raw, inputs[:64 * n], n, proof_stride=324) == exp[:n]
+    # a stride that is not a multiple of 4 takes the unaligned load path
+    raw = b"".join(proofs[256 * i:256 * i + 256] + b"\xa5" for i in range(n))
+    assert pvk.verify_batch(raw, inputs[:64 * n], n, proof_stride=257) == exp[:n]
+    pvk.close()
+
+
+def test_real_sp1_groth16_proof_bytes(pkg, O, fixtures, workload, L):
+    """The 4 Groth16 fixtures of the reference (vk unavailable): their A, B, C must parse as valid points; against a synthetic key
+    the verdict is REJECT on both sides."""
+    fx, _ = fixtures
+    vk = workload[0]
+    pvk = pkg.PreparedVk(vk)
+    for name, f in sorted(fx.items()):
+        if f["variant"] != "groth16":
+            continue
+        raw = bytes.fromhex(f["raw_proof"])
+        pis = b"".join(be(int(x)) for x in f["public_inputs"])
+        got = pvk.verify_batch(raw, pis, 1, proof_stride=324)
+        assert got == bytes([O.groth16_verify(raw, vk, [int(x) for x in f["public_inputs"]])]) == bytes([pkg.REJECT]), name
+    pvk.close()
+
+
+def test_error_precedence_and_edge_inputs(pkg, O, workload, L):
+    vk, proofs, inputs, exp = workload
+    good = next(i for i in range(512) if exp[i] == 1)
+    base = bytearray(proofs[256 * good:256 * good + 256]); inp = inputs[64 * good:64 * good + 64]
+    cases = []
+
+    def add(p, i=inp):
+        cases.append((bytes(p), bytes(i)))
+
+    add(base)                                                          # valid
+    p = bytearray(base); p[0:64] = bytes(64); add(p)                   # A = (0,0): not on curve (infinity is not representable)
+    p = bytearray(base); p[0:32] = be(P); add(p)                       # A.x == p exactly: not a member
+    p = bytearray(base); p[32:64] = be(P - 1); add(p)                  # A.y = p-1: member, off curve
+    p = bytearray(base); p[64:96] = b"\xff" * 32; add(p)               # B.x.c1 >= p
+    p = bytearray(base); p[191] ^= 1; add(p)                           # B off the twist
+    p = bytearray(base); p[192:224] = b"\xff" * 32; add(p)             # C.x >= p
+    p = bytearray(base); p[255] ^= 1; add(p)                           # C off curve
+    p = bytearray(base); p[0:32] = b"\xff" * 32; p[255] ^= 1; add(p)   # A and C both bad: A's error wins
+    p = bytearray(base); p[191] ^= 1; p[255] ^= 1; add(p)              # B (curve) before C
+    bad_b = next(i for i in range(512) if exp[i] == 4)
+    p = bytearray(base); p[64:192] = proofs[256 * bad_b + 64:256 * bad_b + 192]; p[255] ^= 1; add(p)   # B subgroup error before C's
+    x0 = int.from_bytes(inp[:32], "big")
+    add(base, be(x0 + R) + inp[32:])                                   # public input >= r: same verdict as x (no range check, used mod r)
+    add(base, b"\xff" * 32 + inp[32:])                                 # 2^256 - 1
+    add(base, bytes(64))                                               # zero inputs: REJECT
+    pr = b"".join(c[0] for c in cases); ii = b"".join(c[1] for c in cases)
+    n = len(cases)
+    pvk = pkg.PreparedVk(vk)
+    got = pvk.verify_batch(pr, ii, n)
+    want = O.groth16_verify_many(pr, 256, vk, ii, 2, n, O.MODE_REFERENCE)
+    assert got == want
+    assert got[0] == 1 and got[1] == 3 and got[2] == 2 and got[8] == 2 and got[9] == 3 and got[10] == 4 and got[11] == 1 and got[13] == 0
+    # wrong number of public inputs: Err(PrepareInputsFailed) unless the proof itself is invalid (loader errors come first)
+    got = pvk.verify_batch(pr, ii + bytes(32 * n), n, n_public=3)
+    want = bytes(O.groth16_verify(cases[k][0], vk, [0, 0, 0]) for k in range(n))
+    assert got == want and got[0] == pkg.ERR_INPUT_LEN and got[1] == 3
+    pvk.close()
+
+
+def test_mode_disagreement_on_device(pkg, O, L):
+    for seed in range(1, 12):
+        vk, proofs, inputs, exp = pkg.synth_groth16(seed, 1, 4, invalid_every=0, agree=False, threads=2)
+        r = O.groth16_verify_many(proofs, 256, vk, inputs, 1, 4, O.MODE_REFERENCE)
+        if r != exp:
+            for mode, want in ((pkg.VK_REFERENCE, r), (pkg.VK_GNARK, exp)):
+                pvk = pkg.PreparedVk(vk, mode)
+                assert pvk.verify_batch(proofs, inputs) == want
+                pvk.close()
+            return
+    pytest.fail("no disagreeing key found")
+
+
+def test_single_verify_mirrors_reference_api(pkg, O, workload, L):
+    vk, proofs, inputs, exp = workload
+    V = pkg.Groth16Verifier
+    for i in (0, 3, 11, 15, 19):
+        xs = [int.from_bytes(inputs[64 * i + 32 * k:64 * i + 32 * k + 32], "big") for k in range(2)]
+        assert V.verify(proofs[256 * i:256 * i + 256], vk, xs) == exp[i] == O.groth16_verify(proofs[256 * i:256 * i + 256], vk, xs)
+    assert V.verify(proofs[:200], vk, [1, 2]) == pkg.ERR_MALFORMED == O.groth16_verify(proofs[:200], vk, [1, 2])
+    assert V.verify(proofs[:256], vk[:300], [1, 2]) == pkg.ERR_MALFORMED == O.groth16_verify(proofs[:256], vk[:300], [1, 2])
+    st = V.verify_batch([proofs[256 * i:256 * i + 256] for i in range(8)], vk,
+                        [[int.from_bytes(inputs[64 * i + 32 * k:64 * i + 32 * k + 32], "big") for k in range(2)] for i in range(8)])
+    assert bytes(st) == exp[:8]
+
+
+def test_device_resident_entry_and_streams(pkg, workload, L):
+    import torch
+    vk, proofs, inputs, exp = workload
+    dev = torch.device("cuda:0")
+    pvk = pkg.PreparedVk(vk)
+    n = 512
+    pvk.reserve(n)
+    dp = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
+    di = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(dev)
+    side = torch.cuda.Stream(dev)
+    for stream in (torch.cuda.current_stream(dev), side):
+        ds = torch.full((n,), 0xEE, dtype=torch.uint8, device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        pvk.verify_batch_device(dp.data_ptr(), di.data_ptr(), ds.data_ptr(), n, 256, 2, 0, stream.cuda_stream)
+        stream.synchronize()
+        assert bytes(ds.cpu().numpy().tobytes()) == exp
+    pvk.close()
+
+
+def test_batch_4096_properties(pkg, O, L):
+    """BASELINE config 2 size: statuses must equal the generator's prediction for all 4096 proofs; idempotence; a permuted
+    batch gives the permuted statuses (proofs are independent); an oracle spot-check on a strided sample."""
+    n = 4096
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540002, 2, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert st == exp
+    assert pvk.verify_batch(proofs, inputs) == st
+    rng = random.Random(9)
+    perm = list(range(n)); rng.shuffle(perm)
+    pp = b"".join(proofs[256 * j:256 * j + 256] for j in perm); ip = b"".join(inputs[64 * j:64 * j + 64] for j in perm)
+    assert pvk.verify_batch(pp, ip) == bytes(exp[j] for j in perm)
+    sample = list(range(0, n, 97))
+    sp = b"".join(proofs[256 * j:256 * j + 256] for j in sample); si = b"".join(inputs[64 * j:64 * j + 64] for j in sample)
+    assert O.groth16_verify_many(sp, 256, vk, si, 2, len(sample), O.MODE_REFERENCE) == bytes(st[j] for j in sample)
+    pvk.close()
+
+
+def test_batch_65536_expected_statuses(pkg, L):
+    n = 1 << 16
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540003, 2, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert st == exp
+    assert st.count(bytes([1])) == n - n // 16
+    pvk.close()
+
+
+def test_more_public_inputs(pkg, O, L):
+    """nPublic = 5: a different key shape through the same kernels (window tables per input)."""
+    n = 40
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540004, 5, n, invalid_every=4, agree=True, threads=8)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert st == exp == O.groth16_verify_many(proofs, 256, vk, inputs, 5, n, O.MODE_REFERENCE)
+    pvk.close()

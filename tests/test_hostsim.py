@@ -1,0 +1,155 @@
+"""The product's device arithmetic (snark-bn254-verifier_amd/csrc/*.h), compiled for the HOST with the bound tracker on
+(tests/hostsim), against the oracle.  This is how the exact algorithms of the HIP kernels are checked in a GPU-less
+container; every call also asserts the value-/limb-bound assumptions of bn254_fp.h.  `inflate` shifts inputs by
+multiples of p so that the lazy (unreduced) ranges are exercised, not only canonical values."""
+import ctypes as C
+import random
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def be(v):
+    return int(v).to_bytes(32, "big")
+
+
+def b2(x):
+    return be(x[0]) + be(x[1])
+
+
+def test_fp(hostsim):
+    hs = hostsim
+
+    def fp(op, a, b=0, inf=0):
+        o = (C.c_uint8 * 32)(); hs.hs_fp_op(op, o, be(a), be(b), inf); return int.from_bytes(bytes(o), "big")
+
+    random.seed(7)
+    vals = [0, 1, 2, P - 1, P - 2, 1 << 253, (1 << 254) - 1, P // 2, 3, 9] + [random.randrange(P) for _ in range(150)]
+    for inf in (0, 1, 3):
+        for i, a in enumerate(vals):
+            b = vals[(i * 7 + 3) % len(vals)]
+            assert fp(0, a, b, inf) == (a + b) % P and fp(1, a, b, inf) == (a - b) % P
+            assert fp(2, a, b, inf) == a * b % P and fp(6, a, 0, inf) == a * a % P
+            assert fp(5, a, 0, inf) == (-a) % P and fp(7, a, 0, inf) == a % P
+            assert fp(8, a, b, inf) == (9 * a - b) % P
+            assert fp(9, a, 0, inf) == (1 if a % P == 0 else 0)
+    for a in vals[:25]:
+        assert fp(3, a) == (pow(a, -1, P) if a else 0)
+
+
+def test_fp2_fp12(hostsim, O):
+    hs = hostsim
+
+    def fp2(op, a, b=(0, 0), inf=0):
+        o = (C.c_uint8 * 64)(); hs.hs_fp2_op(op, o, b2(a), b2(b), inf); r = bytes(o)
+        return int.from_bytes(r[:32], "big"), int.from_bytes(r[32:], "big")
+
+    def fp12(op, a, b=None, inf=0):
+        o = (C.c_uint8 * 384)(); hs.hs_fp12_op(op, o, a, b if b is not None else bytes(384), inf); return bytes(o)
+
+    random.seed(8)
+    rnd2 = lambda: (random.randrange(P), random.randrange(P))
+    for inf in (0, 2):
+        for _ in range(40):
+            a, b = rnd2(), rnd2()
+            for op in (0, 1, 2):
+                assert fp2(op, a, b, inf) == O.fp2_op(op, a, b)
+            assert fp2(5, a, b, inf) == O.fp2_op(5, a)
+            assert fp2(6, a, b, inf) == O.fp2_op(2, a, (9, 1))
+    for _ in range(5):
+        a = rnd2(); assert fp2(3, a) == O.fp2_op(3, a)
+    r12 = lambda: b"".join(be(random.randrange(P)) for _ in range(12))
+    for inf in (0, 1, 2):
+        for _ in range(8):
+            a, b = r12(), r12()
+            assert fp12(0, a, b, inf) == O.fp12_op(0, a, b)
+            assert fp12(1, a, None, inf) == O.fp12_op(1, a)
+            for op in (3, 4, 5, 7):
+                assert fp12(op, a, None, inf) == O.fp12_op(op, a), op
+            d0, d3, d4 = rnd2(), rnd2(), rnd2()
+            dense = b2(d0) + bytes(128) + b2(d3) + b2(d4) + bytes(64)  # d0 + (d3 + d4 v) w
+            assert fp12(8, a, b2(d0) + b2(d3) + b2(d4), inf) == O.fp12_op(0, a, dense)
+            dense = b2((d0[0], 0)) + bytes(128) + b2(d3) + b2(d4) + bytes(64)
+            assert fp12(9, a, b2((d0[0], 0)) + b2(d3) + b2(d4), inf) == O.fp12_op(0, a, dense)
+    a = r12()
+    assert fp12(2, a) == O.fp12_op(2, a)
+    c = O.fp12_op(0, O.fp12_op(7, a), O.fp12_op(2, a)); c = O.fp12_op(0, O.fp12_op(4, c), c)  # easy part: cyclotomic subgroup
+    for inf in (0, 1):
+        assert fp12(6, c, None, inf) == O.fp12_op(1, c)
+
+
+def _twist_point(O, rng):
+    bt = O.fp2_op(2, O.fp2_op(3, (9, 1)), (3, 0))
+    while True:
+        x = (rng.randrange(P), rng.randrange(P))
+        rhs = O.fp2_op(0, O.fp2_op(2, O.fp2_op(5, x), x), bt)
+        y = O.fp2_op(4, rhs)
+        if y != (0, 0) and O.fp2_op(5, y) == rhs:
+            return be(x[1]) + be(x[0]) + be(y[1]) + be(y[0])
+
+
+def test_g1_complete_addition(hostsim, O):
+    hs = hostsim
+
+    def g1op(op, p, q=bytes(64)):
+        o = (C.c_uint8 * 64)(); hs.hs_g1_op(op, o, p, q); return bytes(o)
+
+    rng = random.Random(11)
+    g1 = O.g1_gen(); Z = bytes(64)
+    pts = [O.g1_mul(g1, rng.randrange(1, R)) for _ in range(8)]
+    for i, p in enumerate(pts):
+        q = pts[(i + 1) % len(pts)]
+        neg = p[:32] + be(P - int.from_bytes(p[32:], "big"))
+        assert g1op(0, p, q) == O.g1_add(p, q) and g1op(2, p, q) == O.g1_add(p, q)
+        assert g1op(1, p) == O.g1_add(p, p) and g1op(0, p, p) == O.g1_add(p, p)    # P = Q through the addition law
+        assert g1op(0, p, neg) == Z and g1op(2, p, neg) == Z                      # P = -Q -> identity
+        assert g1op(0, Z, q) == q and g1op(2, p, Z) == p and g1op(2, Z, Z) == Z   # identity operands
+        assert g1op(3, p)[0] == 1
+        assert g1op(3, p[:32] + be((int.from_bytes(p[32:], "big") + 1) % P))[0] == 0
+    o = (C.c_uint8 * 64)(); hs.hs_g1_sum(o, b"".join(pts), len(pts))
+    acc = pts[0]
+    for p in pts[1:]:
+        acc = O.g1_add(acc, p)
+    assert bytes(o) == acc
+
+
+def test_g2_subgroup_check(hostsim, O):
+    """psi-based check == the reference's naive [r-1]Q + Q == O (oracle), on G2 points, random twist points, cofactor-cleared
+    points and points of order dividing the cofactor."""
+    hs = hostsim
+    rng = random.Random(12)
+    g2 = O.g2_gen()
+    for _ in range(3):
+        q = O.g2_mul(g2, rng.randrange(1, R))
+        assert hs.hs_g2_on_curve(q) == 1 and hs.hs_g2_in_subgroup(q) == 1
+    rejected = 0
+    for _ in range(5):
+        q = _twist_point(O, rng)
+        assert hs.hs_g2_on_curve(q) == 1
+        exp = O.g2_subgroup_check(q)
+        assert hs.hs_g2_in_subgroup(q) == exp
+        rejected += exp == 0
+    assert rejected >= 4
+    h2 = 2 * P - R
+    tq = _twist_point(O, rng)
+    q = O.g2_mul(tq, h2)
+    assert O.g2_subgroup_check(q) == 1 and hs.hs_g2_in_subgroup(q) == 1
+    q = O.g2_mul(tq, R)
+    if q != bytes(128):
+        assert O.g2_subgroup_check(q) == 0 and hs.hs_g2_in_subgroup(q) == 0
+
+
+def test_pairing_matches_oracle_bytes(hostsim, O):
+    hs = hostsim
+    rng = random.Random(13)
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    a, b, c, d = [rng.randrange(1, R) for _ in range(4)]
+    pa, qb = O.g1_mul(g1, a), O.g2_mul(g2, b)
+    o = (C.c_uint8 * 384)()
+    assert hs.hs_miller(o, pa, qb, 0, None, None) == 1
+    hs.hs_final_exp(o, bytes(o))
+    assert bytes(o) == O.pairing(pa, qb)
+    pf = O.g1_mul(g1, c) + O.g1_mul(g1, d); qf = O.g2_mul(g2, c + 5) + O.g2_mul(g2, d + 7)
+    assert hs.hs_miller(o, pa, qb, 2, pf, qf) == 1
+    hs.hs_final_exp(o, bytes(o))
+    assert bytes(o) == O.pairing(pa + pf, qb + qf)

@@ -1,0 +1,137 @@
+"""The oracle against every known-answer the reference's own files hold for this path.
+PlonK: 4 end-to-end fixtures (examples/binaries/*_plonk_proof.bin + the vk recovered from examples/program/elf/plonk), the
+transcript stage goldens and vk decompression goldens.  Groth16: parse-level pins only (the vk is absent from the reference tree)."""
+import hashlib
+
+import pytest
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _plonk(fixtures):
+    fx, vk = fixtures
+    return {k: v for k, v in fx.items() if v["variant"] == "plonk"}, vk
+
+
+def test_fixture_inventory(fixtures):
+    fx, vk = fixtures
+    assert len(fx) == 8 and sum(v["variant"] == "plonk" for v in fx.values()) == 4
+    assert len(vk) == 34368
+    assert hashlib.sha256(vk).hexdigest() == "4aca240a3e5296e6a565f98dc728c6f48f8de4792a8fa365038c3b86952176f5"
+    for v in fx.values():
+        raw = bytes.fromhex(v["raw_proof"])
+        assert len(raw) == (904 if v["variant"] == "plonk" else 324)
+        assert v["vkey_hash"].startswith("4aca240a" if v["variant"] == "plonk" else "6a2906ac")
+
+
+def test_plonk_fixtures_accept(O, fixtures):
+    """reference examples/script/src/main.rs:182-245 (test_programs): every fixture must verify."""
+    fx, vk = _plonk(fixtures)
+    for name, f in fx.items():
+        proof = bytes.fromhex(f["raw_proof"])
+        pis = [int(x) for x in f["public_inputs"]]
+        assert O.plonk_verify(proof, vk, pis) == O.ACCEPT, name
+        # the KZG batching scalar is random in the reference (plonk/kzg.rs:149-154): the verdict must not depend on it
+        assert O.plonk_verify(proof, vk, pis, lam=123456789) == O.ACCEPT, name
+
+
+def test_plonk_negative(O, fixtures):
+    fx, vk = _plonk(fixtures)
+    f = fx["fibonacci_plonk"]
+    proof = bytearray(bytes.fromhex(f["raw_proof"]))
+    pis = [int(x) for x in f["public_inputs"]]
+    assert O.plonk_verify(bytes(proof), vk, [pis[0], pis[1] + 1]) == O.ERR_OPENING_MISMATCH
+    assert O.plonk_verify(bytes(proof), vk, pis[:1]) == O.ERR_INPUT_LEN
+    # batched opening proof H (offset 448) is not bound by any transcript: replacing it by the generator breaks only the pairing
+    bad = bytearray(proof)
+    bad[448:512] = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+    assert O.plonk_verify(bytes(bad), vk, pis) == O.ERR_PAIRING_FAILED
+    bad = bytearray(proof)
+    bad[0:32] = b"\xff" * 32  # L.x >= p
+    assert O.plonk_verify(bytes(bad), vk, pis) == O.ERR_NOT_MEMBER
+    bad = bytearray(proof)
+    bad[63] ^= 1  # L.y off the curve
+    assert O.plonk_verify(bytes(bad), vk, pis) == O.ERR_NOT_ON_CURVE
+    assert O.plonk_verify(bytes(proof[:500]), vk, pis) == O.ERR_MALFORMED
+
+
+def test_plonk_stage_goldens(O, fixtures):
+    """SURVEY.md Appendix B.3 (fixture fibonacci_plonk)."""
+    fx, vk = _plonk(fixtures)
+    f = fx["fibonacci_plonk"]
+    proof = bytes.fromhex(f["raw_proof"])
+    h = hashlib.sha256(proof).hexdigest()
+    assert h.startswith("b3ecd92e") and h.endswith("8908")
+    st, d = O.plonk_stage_digests(proof, vk, [int(x) for x in f["public_inputs"]])
+    assert st == O.ACCEPT
+    assert d["gamma"].hex() == "951872d0ce665e93d69d9b1e06fbc513e005aba63d7fd22505ee6eed8c240030"
+    assert d["beta"].hex() == "018d8c732c3e7e38e395ad477a9102f50ec73fe56bae66ddd5a4fbe46a6cdcea"
+    assert d["alpha"].hex() == "e479ad415901c6793e729032800fc9ef62d6dce3efe2b90aca08200ced576a4a"
+    assert d["zeta"].hex() == "f834ee0886ca1e0a5bb2b6cff1af55067ba6f0218092d60369646b2ee09a6507"
+    assert d["h2f"].hex() == "4ed0ec0b9febdbd1a0ddc19e34e284b7146bad6c6e1d7d280158ce06f79a9ad2b2b00696a478f3ea1f47e0f8a9d137fb"
+    assert int.from_bytes(d["gamma"], "big") % R == 0x03EB87782AD17E16ADACC9FA8277BBFC6769F2CCD05380713A488E31BC24002D
+    assert int.from_bytes(d["h2f"], "big") % R == 0x0F96B0D99F9958D68DBAA54E785873546F6444FD047EE467A6CF86DBDB28BC61
+
+
+def test_plonk_vk_decompression_goldens(O, fixtures):
+    """SURVEY.md Appendix B.2."""
+    _, vk = fixtures
+    st, s1 = O.decompress_g1(vk[112:144])
+    assert st == O.ACCEPT
+    assert s1[:32].hex() == "0f68498bcb8bad722bb26d7fdf86ec47e0608f5c7426553b32b6475f107d2f6f"
+    assert s1[32:].hex() == "02c32c714551e3a5ae040a4d1ab1c202a8e60ee284dc28854d5315d87cef56f8"
+    assert vk[112:144].hex().startswith("8f68498b") and vk[112:144].hex().endswith("2f6f")
+    off = 372 + 32  # one qcp
+    st, g1 = O.decompress_g1(vk[off:off + 32])
+    assert st == O.ACCEPT and g1[32:].hex() == "1a01ae7fac6228e39d3cb5a5e71fd31160f3241e79a5f48ffb3737e6c389b721"
+    assert g1[:32].hex().startswith("1fa4be93") and g1[:32].hex().endswith("c9b03b")
+    # kzg.g2[0] is the standard generator; kzg.g2[1] = [alpha]G2 with the golden y; both modes agree on these two points
+    for mode in (O.MODE_REFERENCE, O.MODE_GNARK):
+        st, g20 = O.decompress_g2(vk[off + 32:off + 96], mode)
+        assert st == O.ACCEPT and g20 == O.g2_gen()
+        st, g21 = O.decompress_g2(vk[off + 96:off + 160], mode)
+        assert st == O.ACCEPT
+        assert g21[96:128].hex() == "0efd30ac7b6f8d0d3ccbc2207587c2acbad1532dc0293f0d034cf8258cd428b3"  # y.c0
+        assert g21[64:96].hex() == "159f15b842ba9c8449aa3268f981010d4c7142e5193473d80b464e964845c3f8"   # y.c1
+    # compress(decompress(x)) round trip with gnark flags
+    assert O.compress_g1(s1) == vk[112:144]
+    assert O.compress_g2(g21) == vk[off + 96:off + 160]
+    # parsed sizes: size = 2^25, nb_public = 2, coset_shift = 5
+    assert int.from_bytes(vk[0:8], "big") == 1 << 25
+    assert int.from_bytes(vk[72:80], "big") == 2 and int.from_bytes(vk[80:112], "big") == 5
+
+
+def test_groth16_fixture_parse_pins(O, fixtures):
+    """raw proof 324 B, nCommitments = 0, A and C on G1, B on the twist and in the r-torsion, inputs < r."""
+    fx, _ = fixtures
+    for name, f in fx.items():
+        if f["variant"] != "groth16":
+            continue
+        raw = bytes.fromhex(f["raw_proof"])
+        assert raw[256:260] == b"\0\0\0\0" and raw[260:] == bytes(64), name
+        assert raw[:256].hex() == f["encoded_proof"], name
+        for off in (0, 192):
+            x, y = int.from_bytes(raw[off:off + 32], "big"), int.from_bytes(raw[off + 32:off + 64], "big")
+            assert x < P and y < P and (y * y - x * x * x - 3) % P == 0, name
+        assert O.g2_subgroup_check(raw[64:192]) == 1, name
+        assert all(int(x) < R for x in f["public_inputs"]), name
+        # the naive [r]B check (bn's AffineG2::new) through scalar multiplication as well
+        assert O.g2_mul(raw[64:192], R) == bytes(128), name
+
+
+def test_sha256_and_xmd(O):
+    for m in (b"", b"abc", b"a" * 55, b"a" * 56, b"a" * 64, b"a" * 1000):
+        assert O.sha256(m) == hashlib.sha256(m).digest()
+
+    def xmd(msg, dst, n):  # RFC 9380 5.3.1, written independently with hashlib
+        ell = (n + 31) // 32
+        dp = dst + bytes([len(dst)])
+        b0 = hashlib.sha256(bytes(64) + msg + n.to_bytes(2, "big") + b"\0" + dp).digest()
+        bs = [hashlib.sha256(b0 + b"\1" + dp).digest()]
+        for i in range(2, ell + 1):
+            bs.append(hashlib.sha256(bytes(x ^ y for x, y in zip(b0, bs[-1])) + bytes([i]) + dp).digest())
+        return b"".join(bs)[:n]
+
+    for msg, n in ((b"", 48), (b"abc", 48), (b"x" * 64, 48), (b"q" * 100, 96)):
+        assert O.expand_msg_xmd(msg, b"BSB22-Plonk", n) == xmd(msg, b"BSB22-Plonk", n)
