@@ -171,7 +171,8 @@ def _cpu_baseline(args, vk, proofs, inputs, expected):
     from oracle import oracle as O
     O.build(); O.lib()
     m = min(args.cpu_sample, len(expected))
-    cores = len(os.sched_getaffinity(0))  # OpenMP's default team size: every CPU this process may run on
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # the 1-GPU box's CPU share is 16 cores
+    O.set_threads(cores)
     sz = 32 * args.n_public
     O.groth16_verify_many(proofs[:256 * 8], 256, vk, inputs[:sz * 8], args.n_public, 8, O.MODE_REFERENCE)
     t = time.perf_counter()

@@ -10,7 +10,7 @@
 typedef unsigned __int128 u128;
 
 fctx FP, FR;
-uint64_t orc_fp_mul_count = 0;
+__thread uint64_t orc_fp_mul_count = 0; /* per thread: a shared counter would serialise the OpenMP baseline on one cache line */
 static int g_init = 0;
 
 /* p and r, big-endian hex split into 64-bit little-endian limbs */

@@ -73,7 +73,7 @@ extern fctx FP, FR;
 void orc_init(void); /* idempotent; every exported entry point calls it */
 
 /* counters (Fp Montgomery multiplications incl. squarings) -- used to size the work model in DESIGN.md */
-extern uint64_t orc_fp_mul_count;
+extern __thread uint64_t orc_fp_mul_count;
 
 /* ---- u256 / prime field ---- */
 int u256_cmp(const u256* a, const u256* b);
@@ -198,7 +198,8 @@ void orc_compress_g1(uint8_t* o32, const uint8_t* b64);
 void orc_compress_g2(uint8_t* o64, const uint8_t* b128);
 void orc_sha256(uint8_t* o32, const uint8_t* d, size_t n);
 void orc_expand_msg_xmd(uint8_t* out, size_t len, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len);
-uint64_t orc_get_fp_mul_count(void);
+uint64_t orc_get_fp_mul_count(void);   /* of the calling thread */
+void orc_set_threads(int n);            /* OpenMP team size of orc_groth16_verify_many */
 void orc_reset_fp_mul_count(void);
 
 #ifdef __cplusplus

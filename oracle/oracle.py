@@ -154,6 +154,10 @@ def plonk_stage_digests(proof, vk, inputs):
     return st, {"gamma": r[0:32], "beta": r[32:64], "alpha": r[64:96], "zeta": r[96:128], "h2f": r[128:176]}
 
 
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
 def fp_mul_count(reset=False):
     v = lib().orc_get_fp_mul_count()
     if reset:

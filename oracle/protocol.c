@@ -4,6 +4,9 @@
 #include "oracle.h"
 #include <string.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static const u256 P_HALF = {{0x9e10460b6c3e7ea3ull, 0xcbc0b548b438e546ull, 0xdc2822db40c0ac2eull, 0x183227397098d014ull}}; /* (p-1)/2 */
 
@@ -665,4 +668,11 @@ void orc_compress_g1(uint8_t* o32, const uint8_t* b64) { orc_init(); g1a p; g1_f
 void orc_compress_g2(uint8_t* o64, const uint8_t* b128) { orc_init(); g2a p; g2_from_bytes_raw(&p, b128); enc_g2_compressed(o64, &p); }
 void orc_sha256(uint8_t* o32, const uint8_t* d, size_t n) { sha256_ctx c; sha256_init(&c); sha256_update(&c, d, n); sha256_final(&c, o32); }
 uint64_t orc_get_fp_mul_count(void) { return orc_fp_mul_count; }
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 void orc_reset_fp_mul_count(void) { orc_fp_mul_count = 0; }
