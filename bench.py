@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20, help="proofs per GPU = 2^this (default: BASELINE 2^20)")
     ap.add_argument("--n-public", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=768, help="proofs timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="proofs timed on the host for cpu_baseline (~30 CPU-seconds)")
     args = ap.parse_args()
 
     import torch

@@ -23,6 +23,7 @@ static int set_err(int code, const std::string& msg) { g_err = msg; return code;
 struct DevState {
   bool ready = false;
   int32_t *k0 = nullptr, *gtab = nullptr, *dtab = nullptr, *target = nullptr, *msm = nullptr;
+  uint8_t* step_kinds = nullptr;
   int32_t* ws = nullptr; size_t ws_cap = 0;                         // proofs the workspace can hold
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
   size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
@@ -58,11 +59,12 @@ static int ensure_dev(const bn254_g16_pvk* pvk, int device, size_t n, DevState**
       return rc;
     d.ready = true;
   }
-  if (n > d.ws_cap) {
+  if ((n > G16_MAX_BATCH ? (size_t)G16_MAX_BATCH : n) > d.ws_cap) {
     if (d.ws) HIPCK(hipFree(d.ws));
     d.ws = nullptr; d.ws_cap = 0;
     size_t cap = (n + 255) / 256 * 256;
-    HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_ELEMS * BN_NL * sizeof(int32_t)));
+    if (cap > G16_MAX_BATCH) cap = G16_MAX_BATCH;  // larger batches run in chunks (32-bit buffer offsets)
+    HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_BYTES_PER_PROOF));
     d.ws_cap = cap;
   }
   if (g_profiling && !d.ev_ready) { for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i])); d.ev_ready = true; }
@@ -114,7 +116,7 @@ void bn254_groth16_vk_free(bn254_g16_pvk* pvk) {
   for (auto& kv : pvk->dev) {
     DevState& d = kv.second;
     if (hipSetDevice(kv.first) != hipSuccess) continue;
-    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws};
+    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, (int32_t*)d.step_kinds};
     for (auto q : ptrs) if (q) (void)hipFree(q);
     uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
     for (auto q : bp) if (q) (void)hipFree(q);
@@ -139,14 +141,19 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
   DevState* d;
   int rc = ensure_dev(pvk, device, n, &d);
   if (rc) return rc;
-  G16LaunchArgs a;
-  a.proofs = (const uint8_t*)d_proofs; a.stride = proof_stride; a.inputs = (const uint8_t*)d_inputs; a.n_public = (int)n_public; a.n = n;
-  a.ws = d->ws; a.status = (uint8_t*)d_status; a.msm_tab = d->msm; a.k0 = d->k0; a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
-  a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
-  // the SoA stride of the workspace is the batch size of THIS call
-  hipError_t e = bn254_launch_g16(a, (hipStream_t)hip_stream, (g_profiling && d->ev_ready) ? d->ev : nullptr);
-  if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
-                                       std::string("kernel launch: ") + hipGetErrorString(e));
+  for (size_t off = 0; off < n; off += G16_MAX_BATCH) {
+    size_t m = n - off < (size_t)G16_MAX_BATCH ? n - off : (size_t)G16_MAX_BATCH;
+    G16LaunchArgs a;
+    a.proofs = (const uint8_t*)d_proofs + off * proof_stride; a.stride = proof_stride;
+    a.inputs = (const uint8_t*)d_inputs + off * n_public * 32; a.n_public = (int)n_public; a.n = m;
+    a.ws = d->ws; a.status = (uint8_t*)d_status + off; a.msm_tab = d->msm; a.k0 = d->k0; a.gtab = d->gtab; a.dtab = d->dtab;
+    a.target = d->target;
+    a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
+    // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
+    hipError_t e = bn254_launch_g16(a, (hipStream_t)hip_stream, (g_profiling && d->ev_ready) ? d->ev : nullptr);
+    if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
+                                         std::string("kernel launch: ") + hipGetErrorString(e));
+  }
   d->ev_recorded = g_profiling && d->ev_ready;
   return BN254_OK;
 }
@@ -230,12 +237,31 @@ int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
   return run_probe(32, 32, 32, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp_mul(x, y, o, m, nullptr); });
 }
 static thread_local int g_probe_op = 0;
+static thread_local int32_t* g_probe_ws = nullptr;
+static thread_local uint8_t* g_probe_kinds = nullptr;
+static int probe_ws_alloc(size_t n, int device) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  if (n > G16_MAX_BATCH) return set_err(BN254_E_BAD_ARG, "probe batch too large");
+  HIPCK(hipMalloc((void**)&g_probe_ws, (n ? n : 1) * (size_t)G16_WS_BYTES_PER_PROOF));
+  HIPCK(hipMalloc((void**)&g_probe_kinds, n ? n : 1));  // status bytes of the probe lanes
+  return BN254_OK;
+}
+static void probe_ws_free() { if (g_probe_ws) (void)hipFree(g_probe_ws); if (g_probe_kinds) (void)hipFree(g_probe_kinds); g_probe_ws = nullptr; g_probe_kinds = nullptr; }
 int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {
   g_probe_op = op;
-  return run_probe(384, b ? 384 : 0, 384, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp12_op(g_probe_op, x, y, o, m, nullptr); });
+  int rc = probe_ws_alloc(n, device);
+  if (rc) return rc;
+  rc = run_probe(384, b ? 384 : 0, 384, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp12_op(g_probe_op, x, y, o, m, g_probe_ws, g_probe_kinds, nullptr); });
+  probe_ws_free();
+  return rc;
 }
 int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, size_t n, int device) {
-  return run_probe(64, 128, 384, g1, g2, out_gt, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_pairing(x, y, o, m, nullptr); });
+  int rc = probe_ws_alloc(n, device);
+  if (rc) return rc;
+  rc = run_probe(64, 128, 384, g1, g2, out_gt, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_pairing(x, y, o, m, g_probe_ws, g_probe_kinds, nullptr); });
+  probe_ws_free();
+  return rc;
 }
 int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device) {
   return run_probe(128, 0, 1, g2, nullptr, out_flags, n, device, [](const uint8_t* x, const uint8_t*, uint8_t* o, size_t m) { return bn254_launch_dbg_g2_subgroup(x, o, m, nullptr); });

@@ -127,74 +127,74 @@ struct G2Line { Fp2 r0, r1, r2; };
 
 // doubling step (Costello-Lange-Naehrig, scaled by 4 to avoid halvings): T <- 2T, returns the tangent line at T
 BN_HD G2Line g2_double_step(G2Proj& t) {
-  Fp2 A = fp2_mul_nl(t.x, t.y);          // X Y          (= 2 A_cln)
-  Fp2 B = fp2_sqr_nl(t.y);               // Y^2
-  Fp2 C = fp2_sqr_nl(t.z);               // Z^2
-  Fp2 E = fp2_mul_nl(fp2_from_limbs(BN_TWIST_3B0, BN_TWIST_3B1), C);  // 3 b' Z^2
+  Fp2 A = fp2_mul(t.x, t.y);          // X Y          (= 2 A_cln)
+  Fp2 B = fp2_sqr(t.y);               // Y^2
+  Fp2 C = fp2_sqr(t.z);               // Z^2
+  Fp2 E = fp2_mul(fp2_from_limbs(BN_TWIST_3B0, BN_TWIST_3B1), C);  // 3 b' Z^2
   Fp2 F = fp2_mul_small(E, 3);           // 9 b' Z^2
-  Fp2 H = fp2_sub2(fp2_sqr_nl(fp2_add(t.y, t.z)), B, C);              // 2 Y Z
-  Fp2 J = fp2_sqr_nl(t.x);               // X^2
+  Fp2 H = fp2_sub2(fp2_sqr(fp2_add(t.y, t.z)), B, C);              // 2 Y Z
+  Fp2 J = fp2_sqr(t.x);               // X^2
   Fp2 BF = fp2_add(B, F);
   G2Line l;
   l.r0 = fp2_neg(H);
   l.r1 = fp2_mul_small(J, 3);
   l.r2 = fp2_sub(E, B);
   // X3 = 2 X Y (B - F), Y3 = (B + F)^2 - 12 E^2, Z3 = 4 B H   (all x4 relative to CLN: same projective point)
-  Fp2 E2 = fp2_sqr_nl(E);
-  t.x = fp2_dbl(fp2_mul_nl(A, fp2_sub(B, F)));
-  t.y = fp2_sub(fp2_sqr_nl(BF), fp2_mul_small(E2, 12));
-  t.z = fp2_mul_small(fp2_mul_nl(B, H), 4);
+  Fp2 E2 = fp2_sqr(E);
+  t.x = fp2_dbl(fp2_mul(A, fp2_sub(B, F)));
+  t.y = fp2_sub(fp2_sqr(BF), fp2_mul_small(E2, 12));
+  t.z = fp2_mul_small(fp2_mul(B, H), 4);
   return l;
 }
 // mixed addition step: T <- T + Q (Q affine), returns the line through T and Q
 BN_HD G2Line g2_add_step(G2Proj& t, const G2Aff& q) {
-  Fp2 O = fp2_sub(t.y, fp2_mul_nl(q.y, t.z));
-  Fp2 L = fp2_sub(t.x, fp2_mul_nl(q.x, t.z));
-  Fp2 C = fp2_sqr_nl(O), D = fp2_sqr_nl(L);
-  Fp2 E = fp2_mul_nl(L, D);
-  Fp2 F = fp2_mul_nl(t.z, C);
-  Fp2 G = fp2_mul_nl(t.x, D);
+  Fp2 O = fp2_sub(t.y, fp2_mul(q.y, t.z));
+  Fp2 L = fp2_sub(t.x, fp2_mul(q.x, t.z));
+  Fp2 C = fp2_sqr(O), D = fp2_sqr(L);
+  Fp2 E = fp2_mul(L, D);
+  Fp2 F = fp2_mul(t.z, C);
+  Fp2 G = fp2_mul(t.x, D);
   Fp2 H = fp2_sub(fp2_add(E, F), fp2_dbl(G));
   G2Line l;
   l.r0 = L;
   l.r1 = fp2_neg(O);
-  l.r2 = fp2_sub(fp2_mul_nl(q.x, O), fp2_mul_nl(L, q.y));
-  Fp2 t1 = fp2_mul_nl(t.y, E);
-  t.x = fp2_mul_nl(L, H);
-  t.y = fp2_sub(fp2_mul_nl(fp2_sub(G, H), O), t1);
-  t.z = fp2_mul_nl(E, t.z);
+  l.r2 = fp2_dotp(pp(q.x, O), pm(L, q.y));
+  Fp2 y3 = fp2_dotp(pp(fp2_sub(G, H), O), pm(t.y, E));
+  t.x = fp2_mul(L, H);
+  t.y = y3;
+  t.z = fp2_mul(E, t.z);
   return l;
 }
 // full projective addition (no line), same incomplete law; used once or twice per subgroup check
 BN_HD G2Proj g2_add_proj(const G2Proj& p, const G2Proj& q) {
   // bring both to the common denominator Z1 Z2 and reuse the mixed formulas' structure
-  Fp2 y2z1 = fp2_mul_nl(q.y, p.z), x2z1 = fp2_mul_nl(q.x, p.z);
-  Fp2 y1z2 = fp2_mul_nl(p.y, q.z), x1z2 = fp2_mul_nl(p.x, q.z);
-  Fp2 zz = fp2_mul_nl(p.z, q.z);
+  Fp2 y2z1 = fp2_mul(q.y, p.z), x2z1 = fp2_mul(q.x, p.z);
+  Fp2 y1z2 = fp2_mul(p.y, q.z), x1z2 = fp2_mul(p.x, q.z);
+  Fp2 zz = fp2_mul(p.z, q.z);
   Fp2 O = fp2_sub(y1z2, y2z1), L = fp2_sub(x1z2, x2z1);
-  Fp2 C = fp2_sqr_nl(O), D = fp2_sqr_nl(L);
-  Fp2 E = fp2_mul_nl(L, D);
-  Fp2 F = fp2_mul_nl(zz, C);
-  Fp2 G = fp2_mul_nl(x1z2, D);
+  Fp2 C = fp2_sqr(O), D = fp2_sqr(L);
+  Fp2 E = fp2_mul(L, D);
+  Fp2 F = fp2_mul(zz, C);
+  Fp2 G = fp2_mul(x1z2, D);
   Fp2 H = fp2_sub(fp2_add(E, F), fp2_dbl(G));
   G2Proj r;
-  r.x = fp2_mul_nl(L, H);
-  r.y = fp2_sub(fp2_mul_nl(fp2_sub(G, H), O), fp2_mul_nl(y1z2, E));
-  r.z = fp2_mul_nl(E, zz);
+  r.x = fp2_mul(L, H);
+  r.y = fp2_dotp(pp(fp2_sub(G, H), O), pm(y1z2, E));
+  r.z = fp2_mul(E, zz);
   return r;
 }
 // the untwist-Frobenius-twist endomorphism psi on projective points: (conj X * g2, conj Y * g3, conj Z)
 BN_HD G2Proj g2_psi(const G2Proj& p) {
   G2Proj r;
-  r.x = fp2_mul_nl(fp2_conj(p.x), frob_coeff(1, 2));
-  r.y = fp2_mul_nl(fp2_conj(p.y), frob_coeff(1, 3));
+  r.x = fp2_mul(fp2_conj(p.x), frob_coeff(1, 2));
+  r.y = fp2_mul(fp2_conj(p.y), frob_coeff(1, 3));
   r.z = fp2_conj(p.z);
   return r;
 }
 BN_HD G2Aff g2_psi_affine(const G2Aff& p) {
   G2Aff r;
-  r.x = fp2_mul_nl(fp2_conj(p.x), frob_coeff(1, 2));
-  r.y = fp2_mul_nl(fp2_conj(p.y), frob_coeff(1, 3));
+  r.x = fp2_mul(fp2_conj(p.x), frob_coeff(1, 2));
+  r.y = fp2_mul(fp2_conj(p.y), frob_coeff(1, 3));
   return r;
 }
 BN_HD G2Aff g2_psi2_affine(const G2Aff& p) {  // psi^2: constants lie in Fp
@@ -204,7 +204,7 @@ BN_HD G2Aff g2_psi2_affine(const G2Aff& p) {  // psi^2: constants lie in Fp
   return r;
 }
 BN_HD bool g2_proj_eq(const G2Proj& a, const G2Proj& b) {  // both finite
-  return fp2_eq(fp2_mul_nl(a.x, b.z), fp2_mul_nl(b.x, a.z)) & fp2_eq(fp2_mul_nl(a.y, b.z), fp2_mul_nl(b.y, a.z));
+  return fp2_eq(fp2_mul(a.x, b.z), fp2_mul(b.x, a.z)) & fp2_eq(fp2_mul(a.y, b.z), fp2_mul(b.y, a.z));
 }
 // [u]Q over the NAF of u, Q a finite point ON THE TWIST (any order): exceptional steps zero Z, which then sticks
 BN_HD G2Proj g2_mul_u(const G2Aff& q) {

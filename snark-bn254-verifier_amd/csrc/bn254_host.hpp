@@ -10,7 +10,7 @@
 #include <string>
 #include <thread>
 #include <vector>
-#include "bn254_pairing.h"
+#include "bn254_vm.h"
 #include "bn254_kernels.h"
 
 namespace bn254host {
@@ -154,14 +154,14 @@ inline int parse_g16_vk(G16Key& vk, const uint8_t* b, size_t n, int mode) {
 struct G16Prepared {
   size_t n_k = 0;                        // len(vk.K)
   std::vector<int32_t> k0;               // 18
-  std::vector<int32_t> gtab, dtab;       // BN_ATE_STEPS * 36
+  std::vector<int32_t> gtab, dtab;       // BN_ATE_STEPS * FIXED_LINE_DWORDS
   std::vector<int32_t> target;           // 108
   std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS
 };
 inline void put_fp2(int32_t* o, const Fp2& a) { fp_to_limbs(o, a.c0); fp_to_limbs(o + BN_NL, a.c1); }
-inline void put_fp12(int32_t* o, const Fp12& a) {
-  put_fp2(o, a.c0.c0); put_fp2(o + 2 * BN_NL, a.c0.c1); put_fp2(o + 4 * BN_NL, a.c0.c2);
-  put_fp2(o + 6 * BN_NL, a.c1.c0); put_fp2(o + 8 * BN_NL, a.c1.c1); put_fp2(o + 10 * BN_NL, a.c1.c2);
+inline void put_fp12(int32_t* o, const Fp12& a) {  // w-power (k) order, as the workspace stores Fp12 values (bn254_vm.h)
+  put_fp2(o, K0(a)); put_fp2(o + 2 * BN_NL, K1(a)); put_fp2(o + 4 * BN_NL, K2(a));
+  put_fp2(o + 6 * BN_NL, K3(a)); put_fp2(o + 8 * BN_NL, K4(a)); put_fp2(o + 10 * BN_NL, K5(a));
 }
 // batch conversion of projective points to affine with one inversion (Montgomery's trick); none may be the identity
 inline void g1_batch_to_affine(G1Aff* out, const G1Proj* in, size_t n) {
@@ -206,10 +206,12 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
   G2Aff b = (mode == 0) ? g2_neg(vk.beta) : vk.beta;
   std::vector<FixedLine> tg(BN_ATE_STEPS), td(BN_ATE_STEPS);
   if (!fixed_line_table(tg.data(), g) || !fixed_line_table(td.data(), d)) return false;
-  out.gtab.resize((size_t)BN_ATE_STEPS * 4 * BN_NL); out.dtab.resize((size_t)BN_ATE_STEPS * 4 * BN_NL);
+  out.gtab.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS); out.dtab.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS);
   for (int s = 0; s < BN_ATE_STEPS; s++) {
-    put_fp2(out.gtab.data() + (size_t)s * 4 * BN_NL, tg[s].m); put_fp2(out.gtab.data() + (size_t)s * 4 * BN_NL + 2 * BN_NL, tg[s].c);
-    put_fp2(out.dtab.data() + (size_t)s * 4 * BN_NL, td[s].m); put_fp2(out.dtab.data() + (size_t)s * 4 * BN_NL + 2 * BN_NL, td[s].c);
+    int32_t* g_ = out.gtab.data() + (size_t)s * FIXED_LINE_DWORDS;
+    int32_t* d_ = out.dtab.data() + (size_t)s * FIXED_LINE_DWORDS;
+    put_fp2(g_, tg[s].m); put_fp2(g_ + 2 * BN_NL, tg[s].c); put_fp2(g_ + 4 * BN_NL, tg[s].xc);
+    put_fp2(d_, td[s].m); put_fp2(d_ + 2 * BN_NL, td[s].c); put_fp2(d_ + 4 * BN_NL, td[s].xc);
   }
   Fp12 t = final_exponentiation(miller_loop<0>(vk.alpha, b, nullptr, nullptr));
   out.target.resize(12 * BN_NL);

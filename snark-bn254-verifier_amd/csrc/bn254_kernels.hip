@@ -6,42 +6,62 @@
 //   k_g16_subgroup  r-torsion test of B, status precedence                              (converter.rs:152)
 //   k_g16_miller    f = Miller(A,B) * lines_G(L) * lines_D(C), G/D tables shared by the batch (verify.rs:73-77)
 //   k_g16_finalexp  f^((p^12-1)/r) == e(alpha,beta) -> status byte                      (verify.rs:77)
-// Intermediate state lives in an SoA workspace in HBM: element e, limb l, proof i at ws[(e * 9 + l) * n + i], so
-// that every load and store of a wave is one contiguous 256-byte segment.
+//
+// Workspace (bn254_vm.h element map): element e, limb group g (3 limbs), proof i at byte ((e * 3 + g) * n + i) * 12, accessed
+// through ONE buffer descriptor: the row offset (e, g) is wave-uniform and travels in an SGPR (soffset), the lane offset i * 12 is
+// one VGPR shared by every access, so no per-access address arithmetic exists and a wave-level access is a contiguous 768-byte
+// segment (buffer_load_dwordx3 / buffer_store_dwordx3).
+//
+// The Miller loop and the final exponentiation are sequences of out-of-line Fp12-level operations on that workspace
+// (bn254_vm.h): each operation is compiled once, gets the full 256-VGPR budget of a 2-waves-per-SIMD kernel and keeps nothing
+// in registers between operations.
 #include <hip/hip_runtime.h>
-#include "bn254_pairing.h"
+#include <cstdlib>
+#include "bn254_vm.h"
 #include "bn254_kernels.h"
 
 namespace bn254 {
 
-// ---- SoA workspace accessors -------------------------------------------------------------------------------------
-struct Ws {
-  int32_t* base;
-  size_t n;
+typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+
+// ---- workspace accessor ----------------------------------------------------------------------------------------------------------
+struct DevWs {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t row_bytes;  // n * 4: one row per (element, limb)
+  uint32_t voff;       // lane * 4
+  __device__ __forceinline__ DevWs(int32_t* base, uint32_t n, uint32_t lane) {
+    uint64_t b = (uint64_t)base;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    uint32_t nn = __builtin_amdgcn_readfirstlane(n);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nn * (uint32_t)(G16_WS_ELEMS * 36), 0x00020000);
+    row_bytes = nn * 4u;
+    voff = lane * 4u;
+  }
+  __device__ __forceinline__ Fp ld(int e) const {
+    Fp r;
+    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) r.v[l] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
+    return r;
+  }
+  __device__ __forceinline__ void st(int e, const Fp& a) const {
+    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) __builtin_amdgcn_raw_buffer_store_b32(a.v[l], rsrc, voff, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
+  }
 };
-__device__ __forceinline__ Fp ws_ld(const Ws& w, int e, size_t i) {
-  Fp r;
-#pragma unroll
-  for (int l = 0; l < BN_NL; l++) r.v[l] = w.base[(size_t)(e * BN_NL + l) * w.n + i];
-  return r;
+
+// Lanes past the end of the batch get this lane index: lane * 4 lies beyond num_records, so the buffer bounds check makes their
+// loads return 0 and drops their stores.  (They must NOT alias a live proof: different waves run the in-place operations at
+// different times.)
+#define DEAD_LANE (0xffffffffu / 4u)
+
+// uniform (batch-constant) data: limbs stored contiguously per element; the pointer is wave-uniform -> scalar loads
+__device__ __forceinline__ const int32_t* uni_ptr(const int32_t* p) {
+  uint64_t b = (uint64_t)p;
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return (const int32_t*)(((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ void ws_st(const Ws& w, int e, size_t i, const Fp& a) {
-#pragma unroll
-  for (int l = 0; l < BN_NL; l++) w.base[(size_t)(e * BN_NL + l) * w.n + i] = a.v[l];
-}
-__device__ __forceinline__ Fp2 ws_ld2(const Ws& w, int e, size_t i) { Fp2 r; r.c0 = ws_ld(w, e, i); r.c1 = ws_ld(w, e + 1, i); return r; }
-__device__ __forceinline__ void ws_st2(const Ws& w, int e, size_t i, const Fp2& a) { ws_st(w, e, i, a.c0); ws_st(w, e + 1, i, a.c1); }
-__device__ __forceinline__ Fp12 ws_ld12(const Ws& w, int e, size_t i) {
-  Fp12 r;
-  r.c0.c0 = ws_ld2(w, e, i); r.c0.c1 = ws_ld2(w, e + 2, i); r.c0.c2 = ws_ld2(w, e + 4, i);
-  r.c1.c0 = ws_ld2(w, e + 6, i); r.c1.c1 = ws_ld2(w, e + 8, i); r.c1.c2 = ws_ld2(w, e + 10, i);
-  return r;
-}
-__device__ __forceinline__ void ws_st12(const Ws& w, int e, size_t i, const Fp12& a) {
-  ws_st2(w, e, i, a.c0.c0); ws_st2(w, e + 2, i, a.c0.c1); ws_st2(w, e + 4, i, a.c0.c2);
-  ws_st2(w, e + 6, i, a.c1.c0); ws_st2(w, e + 8, i, a.c1.c1); ws_st2(w, e + 10, i, a.c1.c2);
-}
-// uniform (batch-constant) data: limbs stored contiguously per element
 __device__ __forceinline__ Fp uni_ld(const int32_t* p) {
   Fp r;
 #pragma unroll
@@ -49,14 +69,48 @@ __device__ __forceinline__ Fp uni_ld(const int32_t* p) {
   return r;
 }
 __device__ __forceinline__ Fp2 uni_ld2(const int32_t* p) { Fp2 r; r.c0 = uni_ld(p); r.c1 = uni_ld(p + BN_NL); return r; }
-__device__ __forceinline__ FixedLine uni_ld_line(const int32_t* tab, int idx) {
-  FixedLine l;
-  l.m = uni_ld2(tab + (size_t)idx * 4 * BN_NL);
-  l.c = uni_ld2(tab + (size_t)idx * 4 * BN_NL + 2 * BN_NL);
-  return l;
-}
 
-enum { E_AX = 0, E_AY = 1, E_BX = 2, E_BY = 4, E_CX = 6, E_CY = 7, E_LX = 8, E_LY = 9, E_LZ = 10, E_F = 11 };
+// ---- every VM operation (bn254_vm.h) is its own kernel ------------------------------------------------------------------------
+// The VM programs (vm_miller_program, vm_final_exp_program) are host-compilable: the host walks them and enqueues one launch
+// per operation (~700 per batch, all asynchronous on one stream, so launch overhead hides behind the previous kernel for any
+// batch that matters).  No device-side function calls: each kernel gets exactly the registers it needs and no stack.
+// A wave whose 64 proofs have all failed earlier checks exits at once.
+#define VM_KERNEL_PROLOGUE()                                                                     \
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;                                           \
+  const uint8_t st = status[i < n ? i : n - 1];                                                 \
+  if (__builtin_amdgcn_ballot_w64((st & BN254_ST_PENDING) != 0) == 0) return;                   \
+  DevWs w(ws, n, i < n ? i : DEAD_LANE)
+
+__global__ void __launch_bounds__(256, 2) k_vm_init(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status) {  // f = 1, T = B
+  VM_KERNEL_PROLOGUE();
+  w.st(VE_F, fp_one());
+  for (int e = 1; e < 12; e++) w.st(VE_F + e, fp_zero());
+  for (int e = 0; e < 4; e++) w.st(VE_T + e, w.ld(VE_B + e));
+  w.st(VE_T + 4, fp_one()); w.st(VE_T + 5, fp_zero());
+}
+__global__ void __launch_bounds__(256, 2) k_f12_sqr(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e) { VM_KERNEL_PROLOGUE(); vm_f12_sqr(w, e); }
+__global__ void __launch_bounds__(256, 2) k_f12_mul_line_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, int e_line, int e_px) {
+  VM_KERNEL_PROLOGUE(); vm_f12_mul_line_var(w, e, e_line, e_px);
+}
+__global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, const int32_t* __restrict__ entry, int e_px, int use_inf) {
+  VM_KERNEL_PROLOGUE();
+  FixedLine l; l.m = uni_ld2(entry); l.c = uni_ld2(entry + 2 * BN_NL); l.xc = uni_ld2(entry + 4 * BN_NL);
+  vm_f12_mul_line_fixed(w, e, l, e_px, use_inf && (st & BN254_ST_LINF));
+}
+__global__ void __launch_bounds__(256, 2) k_g2_dbl(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line) { VM_KERNEL_PROLOGUE(); vm_g2_dbl(w, e_t, e_line); }
+__global__ void __launch_bounds__(256, 2) k_g2_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line, int e_b, int which) {
+  VM_KERNEL_PROLOGUE(); vm_g2_add(w, e_t, e_line, e_b, which);
+}
+__global__ void __launch_bounds__(256, 2) k_f12_mul(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int b) { VM_KERNEL_PROLOGUE(); vm_f12_mul(w, d, a, b); }
+__global__ void __launch_bounds__(256, 2) k_f12_cyclo_sqr(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_cyclo_sqr(w, d, a); }
+__global__ void __launch_bounds__(256, 2) k_f12_conj(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_conj(w, d, a); }
+__global__ void __launch_bounds__(256, 2) k_f12_frob(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int j) { VM_KERNEL_PROLOGUE(); vm_f12_frob(w, d, a, j); }
+__global__ void __launch_bounds__(256, 2) k_f12_inv(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_inv(w, d, a); }
+__global__ void __launch_bounds__(256, 2) k_g16_compare(int32_t* ws, uint32_t n, uint8_t* __restrict__ status, const int32_t* __restrict__ target) {
+  VM_KERNEL_PROLOGUE();
+  bool acc = vm_f12_eq_const(w, VE_S0, target);
+  if (i < n && (st & BN254_ST_PENDING)) status[i] = acc ? BN254_ST_ACCEPT : BN254_ST_REJECT;
+}
 
 // big-endian 32-byte field (8 dwords as loaded little-endian from memory) -> little-endian words
 __device__ __forceinline__ void be_field_to_words(uint32_t w[8], const uint32_t* d) {
@@ -70,37 +124,39 @@ __device__ __forceinline__ bool words_lt_p(const uint32_t w[8]) { return !words_
 // =====================================================================================================================
 #define PREP_LDS_ROW 65  // 64 proof dwords + 1 pad: lane-per-proof reads hit 64 different banks
 __global__ void __launch_bounds__(256, 2)
-k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs, int n_public, size_t n,
-              Ws ws, uint8_t* __restrict__ status, const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0,
+k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs, int n_public, uint32_t n,
+              int32_t* ws, uint8_t* __restrict__ status, const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0,
               int inputs_match_key) {
   __shared__ uint32_t lds[4 * 64 * PREP_LDS_ROW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t first = (size_t)blockIdx.x * 256 + (size_t)wave * 64;
+  const uint32_t first = blockIdx.x * 256u + (uint32_t)wave * 64u;
   uint32_t* wl = lds + wave * 64 * PREP_LDS_ROW;
   const bool aligned = ((((uintptr_t)proofs) | stride) & 3) == 0;
   if (aligned) {
     // record j of this wave: one 256-byte contiguous segment per load instruction
     for (int j = 0; j < 64; j++) {
-      size_t rec = first + j;
+      uint32_t rec = first + j;
       uint32_t v = 0;
-      if (rec < n) v = *(const uint32_t*)(proofs + rec * stride + (size_t)lane * 4);
+      if (rec < n) v = *(const uint32_t*)(proofs + (size_t)rec * stride + (size_t)lane * 4);
       wl[j * PREP_LDS_ROW + lane] = v;
     }
   } else {
     for (int j = 0; j < 64; j++) {
-      size_t rec = first + j;
+      uint32_t rec = first + j;
       uint32_t v = 0;
       if (rec < n) {
-        const uint8_t* p = proofs + rec * stride + (size_t)lane * 4;
+        const uint8_t* p = proofs + (size_t)rec * stride + (size_t)lane * 4;
         v = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
       }
       wl[j * PREP_LDS_ROW + lane] = v;
     }
   }
   __syncthreads();
-  const size_t i = first + lane;
+  const uint32_t i = first + lane;
   const bool live = i < n;
-  const size_t ii = live ? i : n - 1;
+  const uint32_t ii = live ? i : n - 1;
+  // dead lanes get an out-of-range lane offset: the descriptor's bounds check drops their stores
+  DevWs w(ws, n, live ? i : DEAD_LANE);
   const uint32_t* my = wl + lane * PREP_LDS_ROW;
   uint32_t d[8], wx[8], wy[8];
   int err = 0;       // first error in the reference's order: A, then B (member, curve), B subgroup (next kernel), then C
@@ -116,7 +172,7 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   bool memb = words_lt_p(wx) & words_lt_p(wy);
   G1Aff A; A.x = fp_from_words(wx); A.y = fp_from_words(wy);
   if (!memb) err = BN254_ST_NOT_MEMBER; else if (!g1_on_curve(A)) err = BN254_ST_NOT_ON_CURVE;
-  if (live) { ws_st(ws, E_AX, i, A.x); ws_st(ws, E_AY, i, A.y); }
+  w.st(VE_AX, A.x); w.st(VE_AY, A.y);
 
   // ---- B : x.c1 | x.c0 | y.c1 | y.c0
   G2Aff B;
@@ -134,7 +190,7 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   for (int k = 0; k < 8; k++) d[k] = my[40 + k];
   be_field_to_words(wx, d); membb &= words_lt_p(wx); B.y.c0 = fp_from_words(wx);
   if (err == 0) { if (!membb) err = BN254_ST_NOT_MEMBER; else if (!g2_on_curve(B)) err = BN254_ST_NOT_ON_CURVE; }
-  if (live) { ws_st2(ws, E_BX, i, B.x); ws_st2(ws, E_BY, i, B.y); }
+  vst2(w, VE_B, B.x); vst2(w, VE_B + 2, B.y);
 
   // ---- C
 #pragma unroll
@@ -146,14 +202,14 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   memb = words_lt_p(wx) & words_lt_p(wy);
   G1Aff C; C.x = fp_from_words(wx); C.y = fp_from_words(wy);
   if (!memb) err_c = BN254_ST_NOT_MEMBER; else if (!g1_on_curve(C)) err_c = BN254_ST_NOT_ON_CURVE;
-  if (live) { ws_st(ws, E_CX, i, C.x); ws_st(ws, E_CY, i, C.y); }
+  w.st(VE_CX, C.x); w.st(VE_CY, C.y);
 
   // ---- L = K0 + sum_i x_i K_i, x_i taken as raw 256-bit integers (no range check, as bn::Fr::from_slice)
   G1Aff K0; K0.x = uni_ld(k0); K0.y = uni_ld(k0 + BN_NL);
   G1Proj L = g1_from_affine(K0);
   if (inputs_match_key) {
     for (int s = 0; s < n_public; s++) {
-      const uint8_t* sp = inputs + (ii * (size_t)n_public + s) * 32;
+      const uint8_t* sp = inputs + ((size_t)ii * (size_t)n_public + s) * 32;
       uint32_t sw[8];
       if ((((uintptr_t)inputs) & 3) == 0) {
 #pragma unroll
@@ -163,11 +219,11 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
         for (int k = 0; k < 8; k++) sw[k] = (uint32_t)sp[4 * k] | (uint32_t)sp[4 * k + 1] << 8 | (uint32_t)sp[4 * k + 2] << 16 | (uint32_t)sp[4 * k + 3] << 24;
       }
       // byte j of the big-endian scalar is sw[j / 4] >> (8 (j % 4)); window w (weight 2^(8w)) is byte 31 - w
-      for (int w = 0; w < 32; w++) {
-        int j = 31 - w;
+      for (int wi = 0; wi < 32; wi++) {
+        int j = 31 - wi;
         uint32_t dig = (sw[j >> 2] >> (8 * (j & 3))) & 0xff;
         if (dig != 0) {
-          const int32_t* e = msm_tab + ((size_t)(s * 32 + w) * 255 + (dig - 1)) * MSM_ENTRY_DWORDS;
+          const int32_t* e = msm_tab + ((size_t)(s * 32 + wi) * 255 + (dig - 1)) * MSM_ENTRY_DWORDS;
           G1Aff q;
 #pragma unroll
           for (int l = 0; l < BN_NL; l++) { q.x.v[l] = e[l]; q.y.v[l] = e[BN_NL + l]; }
@@ -176,96 +232,37 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
       }
     }
   }
-  if (live) { ws_st(ws, E_LX, i, fp_reduce(L.x)); ws_st(ws, E_LY, i, fp_reduce(L.y)); ws_st(ws, E_LZ, i, fp_reduce(L.z)); }
-  if (live) status[i] = err ? (uint8_t)err : (uint8_t)(BN254_ST_PENDING | err_c);
+  // to affine (one inversion per proof); the identity -- unreachable without a discrete-log relation between the K_i -- is kept
+  // as (0, 1) plus a flag bit, and the Miller kernel makes its line value 1 (bn::pairing_batch skips such pairs)
+  bool l_inf = g1_is_identity(L);
+  G1Aff La = g1_to_affine(L);
+  La.y = fp_select(l_inf, fp_one(), La.y);
+  w.st(VE_LX, La.x); w.st(VE_LY, La.y);
+  if (live) status[i] = err ? (uint8_t)err : (uint8_t)(BN254_ST_PENDING | (l_inf ? BN254_ST_LINF : 0) | err_c);
 }
 
 // =====================================================================================================================
 // k_g16_subgroup
 // =====================================================================================================================
 __global__ void __launch_bounds__(256, 2)
-k_g16_subgroup(size_t n, Ws ws, uint8_t* __restrict__ status, int inputs_match_key) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+k_g16_subgroup(uint32_t n, int32_t* ws, uint8_t* __restrict__ status, int inputs_match_key) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const bool live = i < n;
-  const size_t ii = live ? i : n - 1;
+  const uint32_t ii = live ? i : n - 1;
   uint8_t st = status[ii];
   // a wave whose proofs all failed earlier has nothing to do
   if (__builtin_amdgcn_ballot_w64((st & BN254_ST_PENDING) != 0) == 0) return;
-  G2Aff B; B.x = ws_ld2(ws, E_BX, ii); B.y = ws_ld2(ws, E_BY, ii);
+  DevWs w(ws, n, ii);
+  G2Aff B; B.x = vld2(w, VE_B); B.y = vld2(w, VE_B + 2);
   bool ok = g2_in_subgroup(B);
   if (live && (st & BN254_ST_PENDING)) {
     uint8_t out;
     if (!ok) out = BN254_ST_NOT_IN_SUBGROUP;
-    else if (st & 0x7f) out = st & 0x7f;                      // deferred error of C
+    else if (st & 0x3f) out = st & 0x3f;                      // deferred error of C
     else if (!inputs_match_key) out = BN254_ST_INPUT_LEN;     // PrepareInputsFailed comes after every loader error
-    else out = BN254_ST_PENDING;
+    else out = BN254_ST_PENDING | (st & BN254_ST_LINF);
     status[i] = out;
   }
-}
-
-// =====================================================================================================================
-// k_g16_miller : (A, B) variable, (L, G) and (C, D) against the key's line tables
-// =====================================================================================================================
-__global__ void __launch_bounds__(256, 2)
-k_g16_miller(size_t n, Ws ws, const uint8_t* __restrict__ status, const int32_t* __restrict__ gtab, const int32_t* __restrict__ dtab) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t ii = i < n ? i : n - 1;
-  if (__builtin_amdgcn_ballot_w64(status[ii] == BN254_ST_PENDING) == 0) return;
-  G1Aff A; A.x = ws_ld(ws, E_AX, ii); A.y = ws_ld(ws, E_AY, ii);
-  G1Aff C; C.x = ws_ld(ws, E_CX, ii); C.y = ws_ld(ws, E_CY, ii);
-  G1Proj L; L.x = ws_ld(ws, E_LX, ii); L.y = ws_ld(ws, E_LY, ii); L.z = ws_ld(ws, E_LZ, ii);
-  G2Aff B; B.x = ws_ld2(ws, E_BX, ii); B.y = ws_ld2(ws, E_BY, ii);
-  G2Aff nB = g2_neg(B);
-  G2Proj T = g2_from_affine(B);
-  Fp12 f = fp12_one();
-  int idx = 0;
-  for (int it = 1; it < BN_ATE_NAF_LEN; it++) {
-    f = fp12_sqr(f);
-    {
-      G2Line l = g2_double_step(T);
-      f = miller_mul_var(f, l, A);
-      f = miller_mul_fixed_proj(f, uni_ld_line(gtab, idx), L);
-      f = miller_mul_fixed_aff(f, uni_ld_line(dtab, idx), C);
-      idx++;
-    }
-    int dgt = BN_ATE_NAF[it];
-    if (dgt != 0) {  // public constant: wave-uniform
-      G2Line l = g2_add_step(T, dgt > 0 ? B : nB);
-      f = miller_mul_var(f, l, A);
-      f = miller_mul_fixed_proj(f, uni_ld_line(gtab, idx), L);
-      f = miller_mul_fixed_aff(f, uni_ld_line(dtab, idx), C);
-      idx++;
-    }
-  }
-  G2Aff Q1 = g2_psi_affine(B);
-  G2Aff Q2 = g2_neg(g2_psi2_affine(B));
-#pragma unroll 1
-  for (int s = 0; s < 2; s++) {
-    G2Line l = g2_add_step(T, s == 0 ? Q1 : Q2);
-    f = miller_mul_var(f, l, A);
-    f = miller_mul_fixed_proj(f, uni_ld_line(gtab, idx), L);
-    f = miller_mul_fixed_aff(f, uni_ld_line(dtab, idx), C);
-    idx++;
-  }
-  if (i < n) ws_st12(ws, E_F, i, fp12_reduce(f));
-}
-
-// =====================================================================================================================
-// k_g16_finalexp
-// =====================================================================================================================
-__global__ void __launch_bounds__(256, 2)
-k_g16_finalexp(size_t n, Ws ws, uint8_t* __restrict__ status, const int32_t* __restrict__ target) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t ii = i < n ? i : n - 1;
-  uint8_t st = status[ii];
-  if (__builtin_amdgcn_ballot_w64(st == BN254_ST_PENDING) == 0) return;
-  Fp12 f = ws_ld12(ws, E_F, ii);
-  Fp12 e = final_exponentiation(f);
-  Fp12 t;
-  t.c0.c0 = uni_ld2(target); t.c0.c1 = uni_ld2(target + 2 * BN_NL); t.c0.c2 = uni_ld2(target + 4 * BN_NL);
-  t.c1.c0 = uni_ld2(target + 6 * BN_NL); t.c1.c1 = uni_ld2(target + 8 * BN_NL); t.c1.c2 = uni_ld2(target + 10 * BN_NL);
-  bool acc = fp12_eq(e, t);
-  if (i < n && st == BN254_ST_PENDING) status[i] = acc ? BN254_ST_ACCEPT : BN254_ST_REJECT;
 }
 
 // =====================================================================================================================
@@ -281,40 +278,36 @@ __device__ __forceinline__ void probe_st_fp(uint8_t* p, const Fp& a) {
   fp_to_words(w, a);
   words_to_be(p, w);
 }
-__device__ Fp12 probe_ld_fp12(const uint8_t* p) {
-  Fp12 r;
-  Fp2* c[6] = {&r.c0.c0, &r.c0.c1, &r.c0.c2, &r.c1.c0, &r.c1.c1, &r.c1.c2};
-  for (int k = 0; k < 6; k++) { c[k]->c0 = probe_ld_fp(p + 64 * k); c[k]->c1 = probe_ld_fp(p + 64 * k + 32); }
-  return r;
-}
-__device__ void probe_st_fp12(uint8_t* p, const Fp12& a) {
-  const Fp2* c[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
-  for (int k = 0; k < 6; k++) { probe_st_fp(p + 64 * k, c[k]->c0); probe_st_fp(p + 64 * k + 32, c[k]->c1); }
-}
 __global__ void __launch_bounds__(256, 2) k_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   probe_st_fp(o + 32 * i, fp_mul(probe_ld_fp(a + 32 * i), probe_ld_fp(b + 32 * i)));
 }
-__global__ void __launch_bounds__(256, 2) k_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+// Fp12 / pairing probes: bytes (tower order) <-> workspace (k order); the operations themselves are the product's VM kernels
+__global__ void __launch_bounds__(256, 2) k_dbg_load(int32_t* ws, uint32_t n, uint8_t* status, int e, const uint8_t* src, int kind) {
+  // kind 0: Fp12 (384 B, tower order) -> element e; kind 1: G1 (64 B) -> VE_AX; kind 2: G2 (128 B, gnark order) -> VE_B; also marks the lane pending
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  Fp12 x = probe_ld_fp12(a + 384 * i), r = x;
-  if (op == 0) r = fp12_mul(x, probe_ld_fp12(b + 384 * i));
-  else if (op == 1) r = fp12_sqr(x);
-  else if (op == 2) r = fp12_inv(x);
-  else if (op == 3) r = fp12_cyclo_sqr(final_exp_easy(x));
-  else if (op == 4) r = fp12_frob(x, 1);
-  probe_st_fp12(o + 384 * i, r);
+  DevWs w(ws, n, i);
+  if (kind == 0) {
+    const int korder[6] = {0, 2, 4, 1, 3, 5};
+    const uint8_t* p = src + 384 * (size_t)i;
+    for (int t = 0; t < 6; t++) { w.st(e + 2 * korder[t], probe_ld_fp(p + 64 * t)); w.st(e + 2 * korder[t] + 1, probe_ld_fp(p + 64 * t + 32)); }
+  } else if (kind == 1) {
+    w.st(VE_AX, probe_ld_fp(src + 64 * (size_t)i)); w.st(VE_AY, probe_ld_fp(src + 64 * (size_t)i + 32));
+  } else {
+    const uint8_t* q = src + 128 * (size_t)i;
+    w.st(VE_B + 1, probe_ld_fp(q)); w.st(VE_B, probe_ld_fp(q + 32)); w.st(VE_B + 3, probe_ld_fp(q + 64)); w.st(VE_B + 2, probe_ld_fp(q + 96));
+  }
+  status[i] = BN254_ST_PENDING;
 }
-__global__ void __launch_bounds__(256, 2) k_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256, 2) k_dbg_store(int32_t* ws, uint32_t n, int e, uint8_t* dst) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  G1Aff p; p.x = probe_ld_fp(g1 + 64 * i); p.y = probe_ld_fp(g1 + 64 * i + 32);
-  G2Aff q; q.x.c1 = probe_ld_fp(g2 + 128 * i); q.x.c0 = probe_ld_fp(g2 + 128 * i + 32);
-  q.y.c1 = probe_ld_fp(g2 + 128 * i + 64); q.y.c0 = probe_ld_fp(g2 + 128 * i + 96);
-  Fp12 f = miller_loop<0>(p, q, nullptr, nullptr);
-  probe_st_fp12(o + 384 * i, final_exponentiation(f));
+  DevWs w(ws, n, i);
+  const int korder[6] = {0, 2, 4, 1, 3, 5};
+  uint8_t* p = dst + 384 * (size_t)i;
+  for (int t = 0; t < 6; t++) { probe_st_fp(p + 64 * t, w.ld(e + 2 * korder[t])); probe_st_fp(p + 64 * t + 32, w.ld(e + 2 * korder[t] + 1)); }
 }
 __global__ void __launch_bounds__(256, 2) k_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -330,18 +323,46 @@ __global__ void __launch_bounds__(256, 2) k_dbg_g2_subgroup(const uint8_t* g2, u
 using namespace bn254;
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
+// host-side OPS for the VM programs: every operation is one kernel launch on the stream
+struct LaunchOps {
+  int32_t* ws; uint32_t n; const uint8_t* status; unsigned grid; hipStream_t s;
+  const int32_t* tab[2];
+  int uni(int x) { return x; }
+  void f12_sqr(int e) { hipLaunchKernelGGL(k_f12_sqr, dim3(grid), dim3(256), 0, s, ws, n, status, e); }
+  void g2_dbl(int et, int el) { hipLaunchKernelGGL(k_g2_dbl, dim3(grid), dim3(256), 0, s, ws, n, status, et, el); }
+  void g2_add(int et, int el, int eb, int which) { hipLaunchKernelGGL(k_g2_add, dim3(grid), dim3(256), 0, s, ws, n, status, et, el, eb, which); }
+  void f12_mul_line_var(int e, int el, int ep) { hipLaunchKernelGGL(k_f12_mul_line_var, dim3(grid), dim3(256), 0, s, ws, n, status, e, el, ep); }
+  void f12_mul_line_fixed(int e, int t, int st_, int ep) {
+    hipLaunchKernelGGL(k_f12_mul_line_fixed, dim3(grid), dim3(256), 0, s, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, t == 0 ? 1 : 0);
+  }
+  void f12_mul(int d, int a, int b) { hipLaunchKernelGGL(k_f12_mul, dim3(grid), dim3(256), 0, s, ws, n, status, d, a, b); }
+  void f12_cyclo_sqr(int d, int a) { hipLaunchKernelGGL(k_f12_cyclo_sqr, dim3(grid), dim3(256), 0, s, ws, n, status, d, a); }
+  void f12_conj(int d, int a) { hipLaunchKernelGGL(k_f12_conj, dim3(grid), dim3(256), 0, s, ws, n, status, d, a); }
+  void f12_frob(int d, int a, int j) { hipLaunchKernelGGL(k_f12_frob, dim3(grid), dim3(256), 0, s, ws, n, status, d, a, j); }
+  void f12_inv(int d, int a) { hipLaunchKernelGGL(k_f12_inv, dim3(grid), dim3(256), 0, s, ws, n, status, d, a); }
+};
+static uint8_t g_step_kinds[BN_ATE_STEPS];
+static const uint8_t* step_kinds_host() {
+  static bool init = false;
+  if (!init) { for (int s_ = 0; s_ < BN_ATE_STEPS; s_++) g_step_kinds[s_] = (uint8_t)miller_step_kind(s_); init = true; }
+  return g_step_kinds;
+}
+
 hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev /* 5 events or nullptr */) {
-  Ws ws{a.ws, a.n};
   unsigned g = grid_for(a.n);
+  uint32_t n = (uint32_t)a.n;
   if (ev) (void)hipEventRecord(ev[0], s);
-  hipLaunchKernelGGL(k_g16_prepare, dim3(g), dim3(256), 0, s, a.proofs, a.stride, a.inputs, a.n_public, a.n, ws, a.status,
+  hipLaunchKernelGGL(k_g16_prepare, dim3(g), dim3(256), 0, s, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status,
                      a.msm_tab, a.k0, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[1], s);
-  hipLaunchKernelGGL(k_g16_subgroup, dim3(g), dim3(256), 0, s, a.n, ws, a.status, a.inputs_match_key);
+  hipLaunchKernelGGL(k_g16_subgroup, dim3(g), dim3(256), 0, s, n, a.ws, a.status, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[2], s);
-  hipLaunchKernelGGL(k_g16_miller, dim3(g), dim3(256), 0, s, a.n, ws, (const uint8_t*)a.status, a.gtab, a.dtab);
+  LaunchOps ops{a.ws, n, a.status, g, s, {a.gtab, a.dtab}};
+  hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status);
+  vm_miller_program(ops, step_kinds_host(), true);
   if (ev) (void)hipEventRecord(ev[3], s);
-  hipLaunchKernelGGL(k_g16_finalexp, dim3(g), dim3(256), 0, s, a.n, ws, a.status, a.target);
+  vm_final_exp_program(ops);
+  hipLaunchKernelGGL(k_g16_compare, dim3(g), dim3(256), 0, s, a.ws, n, a.status, a.target);
   if (ev) (void)hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
@@ -349,12 +370,32 @@ hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* 
   hipLaunchKernelGGL(k_dbg_fp_mul, dim3(grid_for(n)), dim3(256), 0, s, a, b, o, n);
   return hipGetLastError();
 }
-hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_dbg_fp12_op, dim3(grid_for(n)), dim3(256), 0, s, op, a, b, o, n);
+// op: 0 mul 1 sqr 2 inv 3 cyclo_sqr(easy part) 4 frob1.  status: n scratch bytes on the device
+hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
+  unsigned g = grid_for(n);
+  uint32_t nn = (uint32_t)n;
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}};
+  hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, (int)VE_F, a, 0);
+  if (op == 0) { hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, (int)VE_S1, b, 0); ops.f12_mul(VE_S0, VE_F, VE_S1); }
+  else if (op == 1) { ops.f12_sqr(VE_F); ops.f12_conj(VE_S0, VE_F); ops.f12_conj(VE_S0, VE_S0); }
+  else if (op == 2) ops.f12_inv(VE_S0, VE_F);
+  else if (op == 3) {
+    ops.f12_inv(VE_S0, VE_F); ops.f12_conj(VE_S1, VE_F); ops.f12_mul(VE_S0, VE_S1, VE_S0); ops.f12_frob(VE_S1, VE_S0, 2);
+    ops.f12_mul(VE_S0, VE_S1, VE_S0); ops.f12_cyclo_sqr(VE_S0, VE_S0);
+  } else ops.f12_frob(VE_S0, VE_F, 1);
+  hipLaunchKernelGGL(k_dbg_store, dim3(g), dim3(256), 0, s, ws, nn, (int)VE_S0, o);
   return hipGetLastError();
 }
-hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_dbg_pairing, dim3(grid_for(n)), dim3(256), 0, s, g1, g2, o, n);
+hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
+  unsigned g = grid_for(n);
+  uint32_t nn = (uint32_t)n;
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}};
+  hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g1, 1);
+  hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g2, 2);
+  hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, ws, nn, (const uint8_t*)status);
+  vm_miller_program(ops, step_kinds_host(), false);
+  vm_final_exp_program(ops);
+  hipLaunchKernelGGL(k_dbg_store, dim3(g), dim3(256), 0, s, ws, nn, (int)VE_S0, o);
   return hipGetLastError();
 }
 hipError_t bn254_launch_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n, hipStream_t s) {

@@ -8,24 +8,26 @@
 // Line of the D-type twist (untwist (x', y') -> (x' w^2, y' w^3)), up to factors in proper subfields of Fp12, which the
 // final exponentiation removes:   l(P) = r0 yP + (r1 xP) w + r2 w^3   (variable Q, projective T: G2Line)
 //                                  l(P) = yP + (m xP) w + c w^3          (fixed Q, affine T: m = -lambda, c = lambda x_T - y_T)
-// For a projective G1 point (X : Y : Z) the fixed-Q line is scaled by Z: Y + (m X) w + (c Z) w^3.
 #pragma once
 #include "bn254_curve.h"
 
 namespace bn254 {
 
-// one precomputed step of a fixed G2 argument: 2 Fp2 = 36 limbs = 144 bytes
-struct FixedLine { Fp2 m, c; };
+// one precomputed step of a fixed G2 argument: m, c and xi*c (3 Fp2 = 54 limbs = 216 bytes)
+struct FixedLine { Fp2 m, c, xc; };
 
 // ---- multiply f by line values ---------------------------------------------------------------------------------
 BN_HD Fp12 miller_mul_var(const Fp12& f, const G2Line& l, const G1Aff& p) {
   return fp12_mul_by_034(f, fp2_mul_fp(l.r0, p.y), fp2_mul_fp(l.r1, p.x), l.r2);
 }
 BN_HD Fp12 miller_mul_fixed_aff(const Fp12& f, const FixedLine& l, const G1Aff& p) {
-  return fp12_mul_by_034_fp(f, p.y, fp2_mul_fp(l.m, p.x), l.c);
+  return fp12_mul_by_034_fp(f, p.y, fp2_mul_fp(l.m, p.x), l.c, l.xc);
 }
-BN_HD Fp12 miller_mul_fixed_proj(const Fp12& f, const FixedLine& l, const G1Proj& p) {
-  return fp12_mul_by_034_fp(f, p.y, fp2_mul_fp(l.m, p.x), fp2_mul_fp(l.c, p.z));
+// same for a G1 argument that may be the identity (encoded x = 0, y = 1, inf = true): the line value must then be 1, i.e. the
+// w^3 coefficient has to vanish as well (bn::pairing_batch skips pairs with an identity operand)
+BN_HD Fp12 miller_mul_fixed_aff_or_inf(const Fp12& f, const FixedLine& l, const G1Aff& p, bool inf) {
+  Fp2 z = fp2_zero();
+  return fp12_mul_by_034_fp(f, p.y, fp2_mul_fp(l.m, p.x), fp2_select(inf, z, l.c), fp2_select(inf, z, l.xc));
 }
 
 // ---- host-side table construction for a fixed Q (runs once per verifying key) -------------------------------------
@@ -41,6 +43,7 @@ inline bool fixed_line_table(FixedLine* out /* BN_ATE_STEPS */, const G2Aff& q) 
     Fp2 lam = fp2_mul(fp2_mul_small(fp2_sqr(t.x), 3), fp2_inv(den));
     out[n].m = fp2_neg(lam);
     out[n].c = fp2_sub(fp2_mul(lam, t.x), t.y);
+    out[n].xc = fp2_mul_xi(out[n].c);
     n++;
     Fp2 x3 = fp2_sub(fp2_sqr(lam), fp2_dbl(t.x));
     Fp2 y3 = fp2_sub(fp2_mul(lam, fp2_sub(t.x, x3)), t.y);
@@ -53,6 +56,7 @@ inline bool fixed_line_table(FixedLine* out /* BN_ATE_STEPS */, const G2Aff& q) 
     Fp2 lam = fp2_mul(fp2_sub(t.y, s.y), fp2_inv(den));
     out[n].m = fp2_neg(lam);
     out[n].c = fp2_sub(fp2_mul(lam, t.x), t.y);
+    out[n].xc = fp2_mul_xi(out[n].c);
     n++;
     Fp2 x3 = fp2_sub(fp2_sub(fp2_sqr(lam), t.x), s.x);
     Fp2 y3 = fp2_sub(fp2_mul(lam, fp2_sub(t.x, x3)), t.y);

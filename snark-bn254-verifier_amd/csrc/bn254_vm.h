@@ -1,0 +1,249 @@
+// bn254_vm.h -- the Miller loop and the final exponentiation as a sequence of out-of-line Fp12-level operations whose operands
+// live in the per-proof SoA workspace (HBM / Infinity Cache), not in registers.
+//
+// Why: an Fp12 value is 108 registers; squaring it needs the 6 input coefficients, 3 xi-multiples and an output coefficient
+// live at once (~200 VGPRs).  Keeping f, the G2 point T, the current line and the caller's temporaries in registers ACROSS
+// operations is what made the first version spill 4-5 KB per lane (profiles/r01_ubench_tower_karatsuba.txt).  Here every
+// operation loads its operands, has the whole 256-VGPR budget of a 2-waves-per-SIMD kernel to itself, and stores its result:
+// ~400 KB of workspace traffic per proof (DESIGN.md "Workspace traffic"), all of it 12-byte-per-lane coalesced rows.
+//
+// Everything is templated on the workspace accessor W (ld/st of an Fp by element index): the kernels instantiate it with buffer
+// loads (bn254_kernels.hip: SGPR row offset + one VGPR lane offset), tests/hostsim with plain arrays, so the exact operation
+// sequence the GPU runs is checked against the oracle on the CPU.
+#pragma once
+#include "bn254_pairing.h"
+
+namespace bn254 {
+
+// ---- workspace element map (unit: one Fp = 9 limbs).  Fp12 values are stored in w-power order k0..k5, 2 Fp each. ----------------
+enum {
+  VE_AX = 0, VE_AY = 1, VE_B = 2 /* x.c0 x.c1 y.c0 y.c1 */, VE_CX = 6, VE_CY = 7, VE_LX = 8, VE_LY = 9,
+  VE_F = 10,                 // Miller accumulator, then m = easy part of the final exponentiation
+  VE_T = 22, VE_LINE = 28,   // Miller loop: running G2 point (X, Y, Z) and the current line (r0, r1, r2)
+  VE_S0 = 22, VE_S1 = 34, VE_S2 = 46, VE_S3 = 58, VE_S4 = 70, VE_XC = 82,  // final exponentiation slots (S0 aliases T + LINE)
+  VE_TMPA = 94, VE_TMPB = 100,  // two Fp6 temporaries of the general Fp12 product
+  VE_COUNT = 106
+};
+
+template <class W> BN_HD Fp2 vld2(W& w, int e) { Fp2 r; r.c0 = w.ld(e); r.c1 = w.ld(e + 1); return r; }
+template <class W> BN_HD void vst2(W& w, int e, const Fp2& a) { w.st(e, a.c0); w.st(e + 1, a.c1); }
+template <class W> BN_HD Fp6 vld6(W& w, int e) { Fp6 r; r.c0 = vld2(w, e); r.c1 = vld2(w, e + 2); r.c2 = vld2(w, e + 4); return r; }
+template <class W> BN_HD void vst6(W& w, int e, const Fp6& a) { vst2(w, e, a.c0); vst2(w, e + 2, a.c1); vst2(w, e + 4, a.c2); }
+
+// ---- f <- f^2 (in place) ------------------------------------------------------------------------------------------------------------
+template <class W>
+BN_HD void vm_f12_sqr(W& w, int e) {
+  Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+  Fp2 x3 = fp2_mul_xi(k3), x4 = fp2_mul_xi(k4), x5 = fp2_mul_xi(k5);
+  vst2(w, e, fp2_dotp(pp(k0, k0), pp2(k1, x5), pp2(k2, x4), pp(k3, x3)));
+  vst2(w, e + 2, fp2_dotp(pp2(k0, k1), pp2(k2, x5), pp2(k3, x4)));
+  vst2(w, e + 4, fp2_dotp(pp2(k0, k2), pp(k1, k1), pp2(k3, x5), pp(k4, x4)));
+  vst2(w, e + 6, fp2_dotp(pp2(k0, k3), pp2(k1, k2), pp2(k4, x5)));
+  vst2(w, e + 8, fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5)));
+  vst2(w, e + 10, fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3)));
+}
+// ---- f <- f * (d0 + d3 w + d4 w^3), all coefficients in Fp2 (variable-Q line): d0 = r0 yP, d3 = r1 xP, d4 = r2 ----------------------
+template <class W>
+BN_HD void vm_f12_mul_line_var(W& w, int e, int e_line, int e_px) {
+  Fp px = w.ld(e_px), py = w.ld(e_px + 1);
+  Fp2 d0 = fp2_mul_fp(vld2(w, e_line), py), d3 = fp2_mul_fp(vld2(w, e_line + 2), px), d4 = vld2(w, e_line + 4);
+  Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
+  Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+  vst2(w, e, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3)));
+  vst2(w, e + 2, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4)));
+  vst2(w, e + 4, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5)));
+  vst2(w, e + 6, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0)));
+  vst2(w, e + 8, fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1)));
+  vst2(w, e + 10, fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2)));
+}
+// ---- f <- f * (yP + (m xP) w + c w^3): precomputed affine line of a fixed G2 argument; inf: the G1 point is the identity -----------
+template <class W>
+BN_HD void vm_f12_mul_line_fixed(W& w, int e, const FixedLine& l, int e_px, bool inf) {
+  Fp px = w.ld(e_px), d0 = w.ld(e_px + 1);
+  Fp2 d3 = fp2_mul_fp(l.m, px);
+  Fp2 x3 = fp2_mul_xi(d3);
+  Fp2 z = fp2_zero();
+  Fp2 d4 = fp2_select(inf, z, l.c), x4 = fp2_select(inf, z, l.xc);
+  Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+  vst2(w, e, fp2_dot_line(d0, k0, x3, k5, x4, k3));
+  vst2(w, e + 2, fp2_dot_line(d0, k1, d3, k0, x4, k4));
+  vst2(w, e + 4, fp2_dot_line(d0, k2, d3, k1, x4, k5));
+  vst2(w, e + 6, fp2_dot_line(d0, k3, d3, k2, d4, k0));
+  vst2(w, e + 8, fp2_dot_line(d0, k4, d3, k3, d4, k1));
+  vst2(w, e + 10, fp2_dot_line(d0, k5, d3, k4, d4, k2));
+}
+// ---- G2 steps on the workspace: T <- 2T / T <- T + Q, line written to e_line -----------------------------------------------------
+template <class W>
+BN_HD void vm_g2_dbl(W& w, int e_t, int e_line) {
+  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+  G2Line l = g2_double_step(t);
+  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  vst2(w, e_line, l.r0); vst2(w, e_line + 2, l.r1); vst2(w, e_line + 4, l.r2);
+}
+// which: 0 = +B, 1 = -B, 2 = pi(B), 3 = -pi^2(B)
+template <class W>
+BN_HD void vm_g2_add(W& w, int e_t, int e_line, int e_b, int which) {
+  G2Aff q; q.x = vld2(w, e_b); q.y = vld2(w, e_b + 2);
+  if (which == 1) q = g2_neg(q);
+  else if (which == 2) q = g2_psi_affine(q);
+  else if (which == 3) q = g2_neg(g2_psi2_affine(q));
+  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+  G2Line l = g2_add_step(t, q);
+  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  vst2(w, e_line, l.r0); vst2(w, e_line + 2, l.r1); vst2(w, e_line + 4, l.r2);
+}
+
+// ---- general Fp12 product dst <- a * b (dst may alias a or b), Karatsuba over Fp6 with two workspace temporaries ----------------------
+// tower halves in k-order storage: c0 = (k0, k2, k4), c1 = (k1, k3, k5)
+template <class W> BN_HD Fp6 vld_half(W& w, int e, int h) { Fp6 r; r.c0 = vld2(w, e + 2 * h); r.c1 = vld2(w, e + 4 + 2 * h); r.c2 = vld2(w, e + 8 + 2 * h); return r; }
+template <class W> BN_HD void vst_half(W& w, int e, int h, const Fp6& a) { vst2(w, e + 2 * h, a.c0); vst2(w, e + 4 + 2 * h, a.c1); vst2(w, e + 8 + 2 * h, a.c2); }
+template <class W>
+BN_HD void vm_f12_mul(W& w, int e_dst, int e_a, int e_b) {
+  { Fp6 v0 = fp6_mul(vld_half(w, e_a, 0), vld_half(w, e_b, 0)); vst6(w, VE_TMPA, v0); }
+  { Fp6 v1 = fp6_mul(vld_half(w, e_a, 1), vld_half(w, e_b, 1)); vst6(w, VE_TMPB, v1); }
+  Fp6 s;
+  {
+    Fp6 sa = fp6_add(vld_half(w, e_a, 0), vld_half(w, e_a, 1));
+    Fp6 sb = fp6_add(vld_half(w, e_b, 0), vld_half(w, e_b, 1));
+    s = fp6_mul(sa, sb);
+  }
+  Fp6 v0 = vld6(w, VE_TMPA), v1 = vld6(w, VE_TMPB);
+  Fp6 c0, c1;
+  c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
+  c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
+  vst_half(w, e_dst, 0, c0); vst_half(w, e_dst, 1, c1);
+}
+// ---- Granger-Scott squaring dst <- src^2 on the cyclotomic subgroup (dst may alias src) ---------------------------------------------
+template <class W>
+BN_HD void vm_f12_cyclo_sqr(W& w, int e_dst, int e_src) {
+  // tower names -> k index: c0.c0 = k0, c1.c1 = k3, c1.c0 = k1, c0.c2 = k4, c0.c1 = k2, c1.c2 = k5.
+  // The first pair only touches (k0, k3); the other two pairs read and write (k1, k2, k4, k5), so those four are loaded before
+  // either result is stored (dst may alias src).  Splitting the work this way keeps the live set near 150 registers.
+  {
+    Fp2 k0 = vld2(w, e_src), k3 = vld2(w, e_src + 6);
+    Fp2 za, zb;
+    gs_pair(za, zb, k0, k3, k0, k3, false);
+    vst2(w, e_dst, za); vst2(w, e_dst + 6, zb);
+  }
+  {
+    Fp2 k1 = vld2(w, e_src + 2), k2 = vld2(w, e_src + 4), k4 = vld2(w, e_src + 8), k5 = vld2(w, e_src + 10);
+    Fp2 z2, z5, z4, z1;
+    gs_pair(z2, z5, k1, k4, k2, k5, false);   // z.c0.c1 (k2), z.c1.c2 (k5)
+    gs_pair(z4, z1, k2, k5, k4, k1, true);    // z.c0.c2 (k4), z.c1.c0 (k1)
+    vst2(w, e_dst + 4, z2); vst2(w, e_dst + 10, z5); vst2(w, e_dst + 8, z4); vst2(w, e_dst + 2, z1);
+  }
+}
+// ---- cheap unary operations ------------------------------------------------------------------------------------------------------------
+template <class W>
+BN_HD void vm_f12_conj(W& w, int e_dst, int e_src) {  // negate the odd coefficients
+  for (int k = 0; k < 6; k++) { Fp2 x = vld2(w, e_src + 2 * k); vst2(w, e_dst + 2 * k, (k & 1) ? fp2_neg(x) : x); }
+}
+template <class W>
+BN_HD void vm_f12_frob(W& w, int e_dst, int e_src, int j) {
+  const bool odd = (j & 1) != 0;
+  for (int k = 0; k < 6; k++) {
+    Fp2 x = vld2(w, e_src + 2 * k);
+    if (odd) x = fp2_conj(x);
+    if (k > 0) { Fp2 c = frob_coeff(j, k); x = (j == 2) ? fp2_mul_fp(x, c.c0) : fp2_mul(x, c); }
+    vst2(w, e_dst + 2 * k, x);
+  }
+}
+// ---- dst <- 1 / src --------------------------------------------------------------------------------------------------------------------
+template <class W>
+BN_HD void vm_f12_inv(W& w, int e_dst, int e_src) {
+  Fp6 d;
+  {
+    Fp6 s0 = fp6_sqr(vld_half(w, e_src, 0));
+    Fp6 s1 = fp6_mul_v(fp6_sqr(vld_half(w, e_src, 1)));
+    d = fp6_sub(s0, s1);
+  }
+  Fp6 di = fp6_inv(d);
+  { Fp6 r0 = fp6_mul(vld_half(w, e_src, 0), di); Fp6 r1 = fp6_neg(fp6_mul(vld_half(w, e_src, 1), di)); vst_half(w, e_dst, 0, r0); vst_half(w, e_dst, 1, r1); }
+}
+template <class W>
+BN_HD bool vm_f12_eq_const(W& w, int e, const int32_t* target /* 12 Fp in k-order, uniform memory */) {
+  bool ok = true;
+  for (int k = 0; k < 12; k++) {
+    Fp t;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) t.v[l] = target[k * BN_NL + l];
+    BN_SETB(t, 1.0, 0.5);
+    ok &= fp_eq(w.ld(e + k), t);
+  }
+  return ok;
+}
+
+// =======================================================================================================================================
+// Programs.  OPS is the dispatcher that decides how an operation is invoked (the kernels route each one through a noinline
+// device function so that every operation is compiled once; hostsim calls them directly).
+// =======================================================================================================================================
+// step table of the optimal-ate loop: one entry per Miller step (BN_ATE_STEPS = 88): 0 = doubling (with f squaring),
+// 1 = add +B, 2 = add -B, 3 = add pi(B), 4 = add -pi^2(B)
+BN_HD int miller_step_kind(int s) {
+  // expand NAF(6u+2) on the fly: steps are (dbl [, add]) per digit after the leading one, then the two Frobenius additions
+  int idx = 0;
+  for (int it = 1; it < BN_ATE_NAF_LEN; it++) {
+    if (idx == s) return 0;
+    idx++;
+    int d = BN_ATE_NAF[it];
+    if (d != 0) { if (idx == s) return d > 0 ? 1 : 2; idx++; }
+  }
+  return s == idx ? 3 : 4;
+}
+
+template <class OPS>
+BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS, uniform */, bool with_fixed_pairs = true) {
+  // f = 1, T = B are set by the caller
+  for (int s = 0; s < BN_ATE_STEPS; s++) {
+    int kind = ops.uni(step_kinds[s]);
+    if (kind == 0) { if (s != 0) ops.f12_sqr(VE_F); ops.g2_dbl(VE_T, VE_LINE); }
+    else ops.g2_add(VE_T, VE_LINE, VE_B, kind - 1);
+    ops.f12_mul_line_var(VE_F, VE_LINE, VE_AX);
+    if (with_fixed_pairs) {
+      ops.f12_mul_line_fixed(VE_F, 0, s, VE_LX);  // table 0 (paired with L), step s
+      ops.f12_mul_line_fixed(VE_F, 1, s, VE_CX);  // table 1 (paired with C)
+    }
+  }
+}
+// x^u on the cyclotomic subgroup over NAF(u): dst <- src^u; e_xc receives conj(src); dst != src
+template <class OPS>
+BN_HD void vm_exp_u(OPS& ops, int e_dst, int e_src, int e_xc) {
+  ops.f12_conj(e_xc, e_src);
+  ops.f12_conj(e_dst, e_xc);  // dst = src (conj twice: a copy)
+  for (int i = 1; i < BN_U_NAF_LEN; i++) {
+    ops.f12_cyclo_sqr(e_dst, e_dst);
+    int d = BN_U_NAF[i];
+    if (d != 0) ops.f12_mul(e_dst, e_dst, d > 0 ? e_src : e_xc);
+  }
+}
+// final exponentiation of VE_F; the result ends in VE_S0 (same exponent as bn254_pairing.h::final_exponentiation)
+template <class OPS>
+BN_HD void vm_final_exp_program(OPS& ops) {
+  // easy part: m = f^((p^6-1)(p^2+1)) -> VE_F
+  ops.f12_inv(VE_S0, VE_F);
+  ops.f12_conj(VE_S1, VE_F);
+  ops.f12_mul(VE_S0, VE_S1, VE_S0);
+  ops.f12_frob(VE_S1, VE_S0, 2);
+  ops.f12_mul(VE_F, VE_S1, VE_S0);
+  // hard part
+  vm_exp_u(ops, VE_S0, VE_F, VE_XC); ops.f12_conj(VE_S0, VE_S0);      // t0 = m^-u
+  ops.f12_cyclo_sqr(VE_S0, VE_S0);                                     // -2u
+  ops.f12_cyclo_sqr(VE_S1, VE_S0);                                     // -4u
+  ops.f12_mul(VE_S1, VE_S0, VE_S1);                                    // t1 = -6u
+  vm_exp_u(ops, VE_S2, VE_S1, VE_XC); ops.f12_conj(VE_S2, VE_S2);     // t2 = 6u^2
+  ops.f12_conj(VE_S3, VE_S1);                                          // t3 = 6u
+  ops.f12_mul(VE_S1, VE_S2, VE_S3);                                    // t1 = 6u^2 + 6u
+  ops.f12_cyclo_sqr(VE_S3, VE_S2);                                     // t3 = 12u^2
+  vm_exp_u(ops, VE_S4, VE_S3, VE_XC);                                  // t4 = 12u^3
+  ops.f12_mul(VE_S4, VE_S1, VE_S4);                                    // t4 = 12u^3 + 6u^2 + 6u
+  ops.f12_mul(VE_S3, VE_S0, VE_S4);                                    // t3 = 12u^3 + 6u^2 + 4u
+  ops.f12_mul(VE_S0, VE_S2, VE_S4);                                    // t0 = 12u^3 + 12u^2 + 6u
+  ops.f12_mul(VE_S0, VE_F, VE_S0);                                     // + 1
+  ops.f12_frob(VE_S2, VE_S3, 1); ops.f12_mul(VE_S0, VE_S2, VE_S0);
+  ops.f12_frob(VE_S2, VE_S4, 2); ops.f12_mul(VE_S0, VE_S2, VE_S0);
+  ops.f12_conj(VE_S2, VE_F); ops.f12_mul(VE_S2, VE_S2, VE_S3);        // 12u^3 + 6u^2 + 4u - 1
+  ops.f12_frob(VE_S2, VE_S2, 3);
+  ops.f12_mul(VE_S0, VE_S2, VE_S0);
+}
+
+}  // namespace bn254

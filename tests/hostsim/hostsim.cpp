@@ -8,6 +8,7 @@
 #ifdef HS_WITH_CURVE
 #include "../../snark-bn254-verifier_amd/csrc/bn254_curve.h"
 #include "../../snark-bn254-verifier_amd/csrc/bn254_pairing.h"
+#include "../../snark-bn254-verifier_amd/csrc/bn254_vm.h"
 #endif
 #include <cstring>
 using namespace bn254;
@@ -76,7 +77,7 @@ void hs_fp12_op(int op, uint8_t* o, const uint8_t* a, const uint8_t* b, int infl
     case 6: r = fp12_cyclo_sqr(x); break;
     case 7: r = fp12_conj(x); break;
     case 8: r = fp12_mul_by_034(x, fp2_in(b, inflate), fp2_in(b + 64, inflate), fp2_in(b + 128, inflate)); break;
-    case 9: r = fp12_mul_by_034_fp(x, fp_in(b, inflate), fp2_in(b + 64, inflate), fp2_in(b + 128, inflate)); break;
+    case 9: { Fp2 d4 = fp2_in(b + 128, inflate); r = fp12_mul_by_034_fp(x, fp_in(b, inflate), fp2_in(b + 64, inflate), d4, fp2_mul_xi(d4)); break; }
   }
   fp12_out(o, r);
 }
