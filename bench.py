@@ -10,9 +10,11 @@ Workload at N = 1: BASELINE.json configs[2], batch 2^20, 2 public inputs, 1/16 o
 For N > 1 every rank verifies its own 2^20-proof shard of an N * 2^20 batch (weak scaling, no data-path communication).
 After the timed region the statuses are compared with the generator's expected statuses: a wrong answer aborts the bench.
 
-One JSON line on rank 0, with `roofline` for the dominant kernel (k_g16_miller, durations from HIP events recorded on the
-launch stream inside the timed region) and `cpu_baseline` (the CPU oracle = C port of the reference algorithm, timed on this
-box's host cores on a bounded sample; rank 0, N = 1 only).
+One JSON line on rank 0, with `roofline` for the dominant kernel -- the kernel kind with the largest summed duration over a
+batch (k_f12_mul, the general Fp12 product of the final exponentiation, on this code) -- whose launches are bracketed by HIP
+events on their launch stream INSIDE the timed region, and `cpu_baseline` (the CPU oracle = C port of the reference algorithm,
+timed on this box's host cores on a bounded sample; rank 0, N = 1 only).  The last warm-up step brackets every launch of every
+kernel kind instead (`kernels_ms`, informational; ~1400 event records, outside the timed region).
 """
 import argparse
 import importlib
@@ -26,6 +28,17 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per proof of the path = 256 B proof + 64 B public inputs in, 1 B status out
 ALGO_BYTES_PER_PROOF = 321
+# Algorithmic HBM bytes per proof and LAUNCH of each kernel kind = operands read + results written in the per-proof workspace
+# (one Fp = 9 x 4 B, Fp2 = 72 B, Fp12 = 432 B; DESIGN.md "Kernels").  The workspace is the data these kernels exist to move:
+# an Fp12-level operation cannot keep its 432-byte operands in registers across launches.
+KERNEL_ALGO_BYTES = {
+    "k_f12_mul": 3 * 432,                    # a, b in; a*b out
+    "k_f12_sqr": 2 * 432, "k_f12_cyclo_sqr": 2 * 432, "k_f12_conj": 2 * 432, "k_f12_frob": 2 * 432, "k_f12_inv": 2 * 432,
+    "k_f12_mul_line_var": 2 * 432 + 216 + 72,    # f in/out, line (3 Fp2), G1 point
+    "k_f12_mul_line_fixed": 2 * 432 + 72,        # f in/out, G1 point (the line table entry is wave-uniform: scalar loads)
+    "k_g2_dbl": 2 * 216 + 216, "k_g2_add": 2 * 216 + 216 + 144,   # T in/out, line out (, Q in)
+    "k_g16_prepare": 321 + 10 * 36, "k_g16_subgroup": 144, "k_vm_init": 432 + 216, "k_g16_compare": 432 + 1,
+}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # exact Fp-multiplication count per proof of THIS implementation (DESIGN.md "Work model"; counted by tests/hostsim)
 VALU_PEAK_MAD_PER_S = 35.1e12   # measured v_mad_u64_u32 lane-rate, profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64)
@@ -98,24 +111,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    pkg.set_profile_kernels(None)                 # warm-up: bracket every launch (per-kind breakdown)
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms = {}
+    breakdown = None
+    if args.warmup:
+        breakdown, _per = pvk.kernel_profile(local_rank)
+        dom = max(breakdown, key=lambda k: breakdown[k][1])
+        pkg.set_profile_kernels([dom])            # timed region: events around the dominant kernel's launches only
+    prof = {}
+    phase_ms = {}
+    per_launch = n
     t_start = time.perf_counter()
     full = None
     for _ in range(args.steps):
         full = step()
-        # per-kernel HIP-event durations of this step (events were recorded on the launch stream); reading them waits for the
-        # step's last event only, which the next step would have to wait for anyway (same stream)
+        # HIP-event durations of this step (events were recorded on the launch stream); reading them waits for the step's
+        # last event only, which the next step would have to wait for anyway (same stream)
+        kp, per_launch = pvk.kernel_profile(local_rank)
+        for k, (cnt, ms) in kp.items():
+            c0, m0 = prof.get(k, (0, 0.0))
+            prof[k] = (c0 + cnt, m0 + ms)
         for k, v in pvk.last_kernel_ms(local_rank).items():
-            kernel_ms.setdefault(k, []).append(v)
+            phase_ms.setdefault(k, []).append(v)
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if breakdown is None:
+        breakdown = {k: (c // args.steps, m / args.steps) for k, (c, m) in prof.items()}
+    dom = max(prof, key=lambda k: prof[k][1])
 
     # correctness of the timed work
     got = bytes(d_status.cpu().numpy().tobytes())
@@ -128,10 +156,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = n_total * args.steps / elapsed
-        avg = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
-        dom = max(avg, key=avg.get)
-        dom_s = avg[dom] * 1e-3
-        achieved = ALGO_BYTES_PER_PROOF * n / dom_s / 1e9
+        launches, total_ms = prof[dom]
+        avg_launch_ms = total_ms / launches
+        algo_launch = KERNEL_ALGO_BYTES[dom] * per_launch
+        achieved = algo_launch / (avg_launch_ms * 1e-3) / 1e9
         out = {
             "metric": "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X",
             "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -141,12 +169,16 @@ def main():
                                    % (args.batch_log2, args.n_public),
                        "batch_per_gpu": n, "global_batch": n_total, "n_public": args.n_public, "vk_mode": "reference",
                        "parallelism": "independent proof shards x%d + all_gather of status bytes" % world,
+                       "streams_per_gpu": int(os.environ.get("BN254_STREAMS", "2")),
                        "gen_seconds": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(dom),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PROOF * n, "avg_launch_ms": avg[dom],
-                         "note": "integer-VALU bound, not HBM bound (SURVEY.md 8(d)); see kernels_ms and DESIGN.md for the VALU roofline"},
-            "kernels_ms": avg,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(dom, per_launch),
+                         "algorithmic_bytes_per_launch": algo_launch, "avg_launch_ms": avg_launch_ms,
+                         "launches_timed": launches, "proofs_per_launch": per_launch,
+                         "note": "HIP events around every launch of this kernel kind inside the timed region; the kernel is 64-bit "
+                                 "integer multiply-add (VALU) work, no MFMA: see DESIGN.md for its VALU roofline"},
+            "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},
+            "phases_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(args, vk, proofs, inputs, expected)
@@ -156,11 +188,13 @@ def main():
         dist.destroy_process_group()
 
 
-def _measured_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from a committed PMC run (profiles/), or None."""
+def _measured_traffic(kernel, proofs_per_launch):
+    """HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE per proof from the committed rocprofv3 --pmc
+    run (profiles/pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes) x the proofs one launch covers; or None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(p)).get(kernel)
+        e = json.load(open(p))[kernel]
+        return (e["read_bytes_per_proof"] + e["write_bytes_per_proof"]) * proofs_per_launch
     except Exception:
         return None
 

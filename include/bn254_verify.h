@@ -94,12 +94,21 @@ int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* 
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
 
 /* ---- measurement support ------------------------------------------------------------------------------------------
- * When enabled, verify_batch_device brackets each kernel with HIP events on the launch stream; after the stream has been
- * synchronised, bn254_groth16_last_kernel_ms returns their durations.  Names: bn254_groth16_kernel_name(i). */
-#define BN254_G16_NUM_KERNELS 4
+ * A batch runs as ~720 kernel launches: one per Fp12-level operation of the verification program (k_f12_sqr, k_f12_mul,
+ * k_f12_mul_line_fixed, ...), each over the whole (sub-)batch.  When profiling is enabled, verify_batch_device records HIP
+ * events on the launch stream (a) at the four phase boundaries (prepare | subgroup | Miller loop | final exponentiation) and
+ * (b) around every launch whose kernel kind is selected by bn254_set_profile_kernels (bit i = kind i, default all).
+ * After the stream has been synchronised bn254_groth16_last_kernel_ms returns the phase durations and
+ * bn254_groth16_kernel_profile the number of launches and the summed duration per kernel kind, together with the number of
+ * proofs each launch covered (the first sub-batch when the batch is split over concurrent streams, BN254_STREAMS). */
+#define BN254_G16_NUM_KERNELS 4   /* phases */
 void bn254_set_profiling(int enabled);
+void bn254_set_profile_kernels(unsigned mask);
 int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]);
-const char* bn254_groth16_kernel_name(int i);
+const char* bn254_groth16_kernel_name(int i);                 /* phase names */
+int bn254_groth16_num_kernel_kinds(void);
+const char* bn254_groth16_kernel_kind_name(int i);
+int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned launches[], float total_ms[], size_t* proofs_per_launch);
 
 /* ---- synthetic gnark-format workload generator (bench / tests; host threads, no GPU) --------------------------------
  * Deterministic (SplitMix64 seed).  Writes a gnark-compressed verifying key (292 + 32 (n_public+1) + 4 + 128 bytes), n

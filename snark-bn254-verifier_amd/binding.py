@@ -52,8 +52,23 @@ def lib():
         L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.bn254_synth_groth16.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.bn254_synth_groth16_vk_len.argtypes = [C.c_size_t]
+        L.bn254_groth16_kernel_kind_name.restype = C.c_char_p
+        L.bn254_groth16_kernel_kind_name.argtypes = [C.c_int]
+        L.bn254_set_profile_kernels.argtypes = [C.c_uint]
+        L.bn254_groth16_kernel_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
+
+
+def kernel_kinds():
+    return [lib().bn254_groth16_kernel_kind_name(i).decode() for i in range(lib().bn254_groth16_num_kernel_kinds())]
+
+
+def set_profile_kernels(names=None):
+    """Select the kernel kinds whose launches get HIP events (None = all)."""
+    kinds = kernel_kinds()
+    mask = 0xffffffff if names is None else sum(1 << kinds.index(x) for x in names)
+    lib().bn254_set_profile_kernels(mask)
 
 
 def _check(rc):
@@ -98,6 +113,13 @@ class PreparedVk:
         ms = (C.c_float * NUM_KERNELS)()
         _check(lib().bn254_groth16_last_kernel_ms(self._h, device, ms))
         return {lib().bn254_groth16_kernel_name(i).decode(): ms[i] for i in range(NUM_KERNELS)}
+
+    def kernel_profile(self, device=0):
+        """Per kernel kind: {name: (launches, total_ms)} of the last profiled batch, and the proofs each launch covered."""
+        k = lib().bn254_groth16_num_kernel_kinds()
+        cnt = (C.c_uint * k)(); ms = (C.c_float * k)(); per = C.c_size_t(0)
+        _check(lib().bn254_groth16_kernel_profile(self._h, device, cnt, ms, C.byref(per)))
+        return {lib().bn254_groth16_kernel_kind_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(k) if cnt[i]}, int(per.value)
 
     def close(self):
         if self._h:

@@ -2,6 +2,7 @@
 // Host orchestration only: key preparation (bn254_host.hpp), device buffers, kernel launches (bn254_kernels.hip).
 // There is deliberately no CPU implementation of verify here: if HIP is unusable the calls fail (BN254_E_NO_DEVICE).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -17,6 +18,7 @@ using namespace bn254host;
 
 static thread_local std::string g_err;
 static int g_profiling = 0;
+static unsigned g_prof_mask = 0xffffffffu;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(BN254_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -28,6 +30,9 @@ struct DevState {
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
   size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
   hipEvent_t ev[5]; bool ev_ready = false; bool ev_recorded = false;
+  hipStream_t aux[4]; hipEvent_t fork_ev, join_ev[4]; bool aux_ready = false;  // concurrent sub-batches (see verify_batch_device)
+  // per-launch timing of the first sub-batch (bn254_groth16_kernel_profile)
+  std::vector<hipEvent_t> prof_ev; std::vector<uint8_t> prof_kid; G16Prof prof{0, nullptr, nullptr, 0, 0}; size_t prof_n = 0;
 };
 struct bn254_g16_pvk {
   G16Prepared host;
@@ -67,7 +72,14 @@ static int ensure_dev(const bn254_g16_pvk* pvk, int device, size_t n, DevState**
     HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_BYTES_PER_PROOF));
     d.ws_cap = cap;
   }
-  if (g_profiling && !d.ev_ready) { for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i])); d.ev_ready = true; }
+  if (g_profiling && !d.ev_ready) {
+    for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i]));
+    const int cap = 1024;  // launches per sub-batch: ~720
+    d.prof_ev.resize(2 * cap); d.prof_kid.resize(cap);
+    for (auto& e : d.prof_ev) HIPCK(hipEventCreate(&e));
+    d.prof.ev = d.prof_ev.data(); d.prof.kid = d.prof_kid.data(); d.prof.cap = cap;
+    d.ev_ready = true;
+  }
   *out = &d;
   return BN254_OK;
 }
@@ -95,8 +107,11 @@ const char* bn254_status_string(int s) {
   }
 }
 void bn254_set_profiling(int enabled) { g_profiling = enabled; }
+void bn254_set_profile_kernels(unsigned mask) { g_prof_mask = mask; }
+int bn254_groth16_num_kernel_kinds(void) { return KID_COUNT; }
+const char* bn254_groth16_kernel_kind_name(int i) { return (i >= 0 && i < KID_COUNT) ? bn254_kernel_kind_names[i] : ""; }
 const char* bn254_groth16_kernel_name(int i) {
-  static const char* names[BN254_G16_NUM_KERNELS] = {"k_g16_prepare", "k_g16_subgroup", "k_g16_miller", "k_g16_finalexp"};
+  static const char* names[BN254_G16_NUM_KERNELS] = {"phase_prepare", "phase_subgroup", "phase_miller", "phase_finalexp"};
   return (i >= 0 && i < BN254_G16_NUM_KERNELS) ? names[i] : "";
 }
 
@@ -141,18 +156,39 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
   DevState* d;
   int rc = ensure_dev(pvk, device, n, &d);
   if (rc) return rc;
+  // BN254_STREAMS = 1..4 sub-batches in flight (default 2: +4.5 % over one stream at 2^20, profiles/r01_streams.txt)
+  static const int n_streams = [] { const char* e = getenv("BN254_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  hipStream_t user = (hipStream_t)hip_stream;
   for (size_t off = 0; off < n; off += G16_MAX_BATCH) {
     size_t m = n - off < (size_t)G16_MAX_BATCH ? n - off : (size_t)G16_MAX_BATCH;
-    G16LaunchArgs a;
-    a.proofs = (const uint8_t*)d_proofs + off * proof_stride; a.stride = proof_stride;
-    a.inputs = (const uint8_t*)d_inputs + off * n_public * 32; a.n_public = (int)n_public; a.n = m;
-    a.ws = d->ws; a.status = (uint8_t*)d_status + off; a.msm_tab = d->msm; a.k0 = d->k0; a.gtab = d->gtab; a.dtab = d->dtab;
-    a.target = d->target;
-    a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
-    // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
-    hipError_t e = bn254_launch_g16(a, (hipStream_t)hip_stream, (g_profiling && d->ev_ready) ? d->ev : nullptr);
-    if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
-                                         std::string("kernel launch: ") + hipGetErrorString(e));
+    // sub-batches on concurrent streams: the tail of one sub-batch's kernel overlaps the head of the other's
+    int parts = (n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
+    if (parts > 1 && !d->aux_ready) {
+      for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d->join_ev[i], hipEventDisableTiming)); }
+      HIPCK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
+      d->aux_ready = true;
+    }
+    if (parts > 1) HIPCK(hipEventRecord(d->fork_ev, user));
+    size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
+    for (int pi = 0; pi < parts; pi++) {
+      size_t lo = (size_t)pi * per, hi = lo + per < m ? lo + per : m;
+      if (lo >= hi) break;
+      hipStream_t st = parts > 1 ? d->aux[pi] : user;
+      if (parts > 1) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
+      G16LaunchArgs a;
+      a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
+      a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
+      a.ws = d->ws + lo * (size_t)(G16_WS_BYTES_PER_PROOF / 4); a.status = (uint8_t*)d_status + off + lo; a.msm_tab = d->msm; a.k0 = d->k0;
+      a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
+      a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
+      // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
+      const bool prof_this = g_profiling && d->ev_ready && pi == 0;
+      if (prof_this) { d->prof.mask = g_prof_mask; d->prof.used = 0; d->prof_n = a.n; }
+      hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : nullptr);
+      if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
+                                           std::string("kernel launch: ") + hipGetErrorString(e));
+      if (parts > 1) { HIPCK(hipEventRecord(d->join_ev[pi], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi], 0)); }
+    }
   }
   d->ev_recorded = g_profiling && d->ev_ready;
   return BN254_OK;
@@ -166,6 +202,24 @@ int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[
   HIPCK(hipSetDevice(device));
   HIPCK(hipEventSynchronize(it->second.ev[4]));
   for (int i = 0; i < BN254_G16_NUM_KERNELS; i++) HIPCK(hipEventElapsedTime(&ms[i], it->second.ev[i], it->second.ev[i + 1]));
+  return BN254_OK;
+}
+
+int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned launches[], float total_ms[], size_t* proofs_per_launch) {
+  if (!pvk || !launches || !total_ms) return set_err(BN254_E_BAD_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  auto it = pvk->dev.find(device);
+  if (it == pvk->dev.end() || !it->second.ev_recorded) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
+  DevState& d = it->second;
+  HIPCK(hipSetDevice(device));
+  for (int k = 0; k < KID_COUNT; k++) { launches[k] = 0; total_ms[k] = 0.f; }
+  for (int i = 0; i < d.prof.used; i++) {
+    HIPCK(hipEventSynchronize(d.prof.ev[2 * i + 1]));
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, d.prof.ev[2 * i], d.prof.ev[2 * i + 1]));
+    launches[d.prof.kid[i]]++; total_ms[d.prof.kid[i]] += ms;
+  }
+  if (proofs_per_launch) *proofs_per_launch = d.prof_n;
   return BN254_OK;
 }
 

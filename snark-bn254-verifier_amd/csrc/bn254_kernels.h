@@ -34,7 +34,20 @@ struct G16LaunchArgs {
   const int32_t* target;    // 108 dwords: the GT element the product must equal, w-power (k) order
   int inputs_match_key;     // n_public + 1 == len(vk.K)
 };
-hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev);
+// kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
+enum {
+  KID_PREPARE, KID_SUBGROUP, KID_VM_INIT, KID_F12_SQR, KID_G2_DBL, KID_G2_ADD, KID_MUL_LINE_VAR, KID_MUL_LINE_FIXED, KID_F12_MUL,
+  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_COUNT
+};
+extern const char* const bn254_kernel_kind_names[KID_COUNT];
+// optional per-launch timing: every launch whose kind is in `mask` is bracketed by two events from the pool
+struct G16Prof {
+  uint32_t mask;        // bit k: time launches of kind k
+  hipEvent_t* ev;       // 2 * cap events
+  uint8_t* kid;         // kind of pair i
+  int cap, used;
+};
+hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev, G16Prof* prof);
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

@@ -323,23 +323,35 @@ __global__ void __launch_bounds__(256, 2) k_dbg_g2_subgroup(const uint8_t* g2, u
 using namespace bn254;
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
+const char* const bn254_kernel_kind_names[KID_COUNT] = {
+  "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_g2_dbl", "k_g2_add", "k_f12_mul_line_var", "k_f12_mul_line_fixed",
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare"};
+struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
+  G16Prof* p; hipStream_t s; int slot;
+  ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
+    if (p && ((p->mask >> kid) & 1u) && p->used < p->cap) { slot = p->used++; p->kid[slot] = (uint8_t)kid; (void)hipEventRecord(p->ev[2 * slot], s); }
+  }
+  ~ProfScope() { if (slot >= 0) (void)hipEventRecord(p->ev[2 * slot + 1], s); }
+};
+#define BN_LAUNCH(KID, KERNEL, ...) do { ProfScope ps_(prof, KID, s); hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, s, __VA_ARGS__); } while (0)
 // host-side OPS for the VM programs: every operation is one kernel launch on the stream
 struct LaunchOps {
   int32_t* ws; uint32_t n; const uint8_t* status; unsigned grid; hipStream_t s;
   const int32_t* tab[2];
+  G16Prof* prof;
   int uni(int x) { return x; }
-  void f12_sqr(int e) { hipLaunchKernelGGL(k_f12_sqr, dim3(grid), dim3(256), 0, s, ws, n, status, e); }
-  void g2_dbl(int et, int el) { hipLaunchKernelGGL(k_g2_dbl, dim3(grid), dim3(256), 0, s, ws, n, status, et, el); }
-  void g2_add(int et, int el, int eb, int which) { hipLaunchKernelGGL(k_g2_add, dim3(grid), dim3(256), 0, s, ws, n, status, et, el, eb, which); }
-  void f12_mul_line_var(int e, int el, int ep) { hipLaunchKernelGGL(k_f12_mul_line_var, dim3(grid), dim3(256), 0, s, ws, n, status, e, el, ep); }
+  void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
+  void g2_dbl(int et, int el) { BN_LAUNCH(KID_G2_DBL, k_g2_dbl, ws, n, status, et, el); }
+  void g2_add(int et, int el, int eb, int which) { BN_LAUNCH(KID_G2_ADD, k_g2_add, ws, n, status, et, el, eb, which); }
+  void f12_mul_line_var(int e, int el, int ep) { BN_LAUNCH(KID_MUL_LINE_VAR, k_f12_mul_line_var, ws, n, status, e, el, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
-    hipLaunchKernelGGL(k_f12_mul_line_fixed, dim3(grid), dim3(256), 0, s, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, t == 0 ? 1 : 0);
+    BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, t == 0 ? 1 : 0);
   }
-  void f12_mul(int d, int a, int b) { hipLaunchKernelGGL(k_f12_mul, dim3(grid), dim3(256), 0, s, ws, n, status, d, a, b); }
-  void f12_cyclo_sqr(int d, int a) { hipLaunchKernelGGL(k_f12_cyclo_sqr, dim3(grid), dim3(256), 0, s, ws, n, status, d, a); }
-  void f12_conj(int d, int a) { hipLaunchKernelGGL(k_f12_conj, dim3(grid), dim3(256), 0, s, ws, n, status, d, a); }
-  void f12_frob(int d, int a, int j) { hipLaunchKernelGGL(k_f12_frob, dim3(grid), dim3(256), 0, s, ws, n, status, d, a, j); }
-  void f12_inv(int d, int a) { hipLaunchKernelGGL(k_f12_inv, dim3(grid), dim3(256), 0, s, ws, n, status, d, a); }
+  void f12_mul(int d, int a, int b) { BN_LAUNCH(KID_F12_MUL, k_f12_mul, ws, n, status, d, a, b); }
+  void f12_cyclo_sqr(int d, int a) { BN_LAUNCH(KID_CYCLO_SQR, k_f12_cyclo_sqr, ws, n, status, d, a); }
+  void f12_conj(int d, int a) { BN_LAUNCH(KID_F12_CONJ, k_f12_conj, ws, n, status, d, a); }
+  void f12_frob(int d, int a, int j) { BN_LAUNCH(KID_F12_FROB, k_f12_frob, ws, n, status, d, a, j); }
+  void f12_inv(int d, int a) { BN_LAUNCH(KID_F12_INV, k_f12_inv, ws, n, status, d, a); }
 };
 static uint8_t g_step_kinds[BN_ATE_STEPS];
 static const uint8_t* step_kinds_host() {
@@ -348,21 +360,20 @@ static const uint8_t* step_kinds_host() {
   return g_step_kinds;
 }
 
-hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev /* 5 events or nullptr */) {
-  unsigned g = grid_for(a.n);
+hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev /* 5 events or nullptr */, G16Prof* prof) {
+  unsigned grid = grid_for(a.n);
   uint32_t n = (uint32_t)a.n;
   if (ev) (void)hipEventRecord(ev[0], s);
-  hipLaunchKernelGGL(k_g16_prepare, dim3(g), dim3(256), 0, s, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status,
-                     a.msm_tab, a.k0, a.inputs_match_key);
+  BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[1], s);
-  hipLaunchKernelGGL(k_g16_subgroup, dim3(g), dim3(256), 0, s, n, a.ws, a.status, a.inputs_match_key);
+  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[2], s);
-  LaunchOps ops{a.ws, n, a.status, g, s, {a.gtab, a.dtab}};
-  hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status);
+  LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab}, prof};
+  BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
   vm_miller_program(ops, step_kinds_host(), true);
   if (ev) (void)hipEventRecord(ev[3], s);
   vm_final_exp_program(ops);
-  hipLaunchKernelGGL(k_g16_compare, dim3(g), dim3(256), 0, s, a.ws, n, a.status, a.target);
+  BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, a.status, a.target);
   if (ev) (void)hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
@@ -374,7 +385,7 @@ hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* 
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
   unsigned g = grid_for(n);
   uint32_t nn = (uint32_t)n;
-  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}};
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}, nullptr};
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, (int)VE_F, a, 0);
   if (op == 0) { hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, (int)VE_S1, b, 0); ops.f12_mul(VE_S0, VE_F, VE_S1); }
   else if (op == 1) { ops.f12_sqr(VE_F); ops.f12_conj(VE_S0, VE_F); ops.f12_conj(VE_S0, VE_S0); }
@@ -389,7 +400,7 @@ hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, 
 hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
   unsigned g = grid_for(n);
   uint32_t nn = (uint32_t)n;
-  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}};
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}, nullptr};
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g1, 1);
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g2, 2);
   hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, ws, nn, (const uint8_t*)status);

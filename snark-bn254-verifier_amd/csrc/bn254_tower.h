@@ -52,6 +52,128 @@ BN_HD Fp2 fp2_dotp(const P2<W>&... t) {
   r.c1 = fp_dot(dterm<W>(t.x.c0, t.y.c1)..., dterm<W>(t.x.c1, t.y.c0)...);
   return r;
 }
+
+// ---- Karatsuba form of the same sum: re and im of sum_t W_t x_t y_t retired TOGETHER, column by column ------------------------
+// Three 9x9 digit products per Fp2 product instead of four.  Per column and weight class |W| in {1, 2} two partial sums
+//   A = sum x0 y0,   B = sum (-x1) y1        (x1 negated once, digit-wise: balanced digits need no carry for that)
+// and, straight into the im accumulator, |W| (x0 + x1)(y0 + y1).  Then re += |W| (A + B), im += |W| (B - A).  The partial sums
+// live in 64-bit accumulators that may wrap (two's complement): only the combined columns have to fit, and they are the same
+// columns fp2_dotp forms.  A negative weight negates x.  Squares and Fp2 x Fp products go straight into re / im:
+//   ksq(x):  re += (x0+x1)(x0-x1), im += (2 x0) x1      kfp(x, f):  re += x0 f, im += x1 f
+struct KAcc { uint64_t re, im, a[2][2]; };
+#define BN_KCOL_RANGE constexpr int LO = K < BN_NL ? 0 : K - (BN_NL - 1); constexpr int HI = K < BN_NL ? K : BN_NL - 1
+BN_HD uint64_t bn_dmul(int32_t a, int32_t b) { return (uint64_t)((int64_t)a * (int64_t)b); }
+template <int AW>  // |weight| 1 or 2
+struct KProd {
+  Fp x0, nx1, y0, y1, sxw, sy;
+  static constexpr int cls = AW;
+  template <int K> BN_HD void col(KAcc& c) const {
+    BN_KCOL_RANGE;
+#pragma unroll
+    for (int i = LO; i <= HI; i++) {
+      c.a[AW - 1][0] += bn_dmul(x0.v[i], y0.v[K - i]);
+      c.a[AW - 1][1] += bn_dmul(nx1.v[i], y1.v[K - i]);
+      c.im += bn_dmul(sxw.v[i], sy.v[K - i]);
+    }
+  }
+#if BN_TRACKING
+  double cap_re() const { return 9.0 * AW * (x0.lb * y0.lb + nx1.lb * y1.lb); }
+  double cap_im() const { return 9.0 * AW * (x0.lb * y1.lb + nx1.lb * y0.lb); }
+  double val_re() const { return AW * (x0.vb * y0.vb + nx1.vb * y1.vb); }
+  double val_im() const { return AW * (x0.vb * y1.vb + nx1.vb * y0.vb); }
+  void check() const { if (sxw.lb > 3.99 || sy.lb > 3.99) fp_dbg_fail("fp2_dotk: operand sum overflows a digit", sxw.lb + sy.lb); }
+#endif
+};
+struct KDirect {  // re += u_re * v_re, im += u_im * v_im (plain products)
+  Fp ure, vre, uim, vim;
+  static constexpr int cls = 0;
+  template <int K> BN_HD void col(KAcc& c) const {
+    BN_KCOL_RANGE;
+#pragma unroll
+    for (int i = LO; i <= HI; i++) {
+      c.re += bn_dmul(ure.v[i], vre.v[K - i]);
+      c.im += bn_dmul(uim.v[i], vim.v[K - i]);
+    }
+  }
+#if BN_TRACKING
+  double cap_re() const { return 9.0 * ure.lb * vre.lb; }
+  double cap_im() const { return 9.0 * uim.lb * vim.lb; }
+  double val_re() const { return ure.vb * vre.vb; }
+  double val_im() const { return uim.vb * vim.vb; }
+  void check() const { if (ure.lb > 3.99 || vre.lb > 3.99 || uim.lb > 3.99 || vim.lb > 3.99) fp_dbg_fail("fp2_dotk: direct operand overflows a digit", ure.lb); }
+#endif
+};
+template <int AW, bool NEG> BN_HD KProd<AW> kprod(const Fp2& x, const Fp2& y) {
+  KProd<AW> t;
+  t.x0 = NEG ? fp_neg(x.c0) : x.c0; t.nx1 = NEG ? x.c1 : fp_neg(x.c1); t.y0 = y.c0; t.y1 = y.c1;
+  t.sy = fp_add_lazy(y.c0, y.c1);
+#pragma unroll
+  for (int i = 0; i < BN_NL; i++) t.sxw.v[i] = (NEG ? -AW : AW) * (x.c0.v[i] + x.c1.v[i]);
+  BN_SETB(t.sxw, AW * (BN_VB(x.c0) + BN_VB(x.c1)), AW * (BN_LBD(x.c0) + BN_LBD(x.c1)));
+  return t;
+}
+BN_HD KProd<1> kp(const Fp2& x, const Fp2& y) { return kprod<1, false>(x, y); }
+BN_HD KProd<1> km(const Fp2& x, const Fp2& y) { return kprod<1, true>(x, y); }
+BN_HD KProd<2> kp2(const Fp2& x, const Fp2& y) { return kprod<2, false>(x, y); }
+BN_HD KProd<2> km2(const Fp2& x, const Fp2& y) { return kprod<2, true>(x, y); }
+BN_HD KDirect ksq(const Fp2& x) {  // x^2
+  KDirect t; t.ure = fp_add_lazy(x.c0, x.c1); t.vre = fp_sub_lazy(x.c0, x.c1); t.uim = fp_dbl_lazy(x.c0); t.vim = x.c1; return t;
+}
+BN_HD KDirect kfp(const Fp2& x, const Fp& f) { KDirect t; t.ure = x.c0; t.vre = f; t.uim = x.c1; t.vim = f; return t; }
+
+template <int K, class... T>
+BN_HD void dotk_step(int64_t& cre, int64_t& cim, int32_t (&mre)[BN_NL], int32_t (&mim)[BN_NL], Fp2& r, const T&... t) {
+  constexpr bool has1 = ((T::cls == 1) || ...), has2 = ((T::cls == 2) || ...);
+  KAcc c; c.re = (uint64_t)cre; c.im = (uint64_t)cim;
+  c.a[0][0] = c.a[0][1] = c.a[1][0] = c.a[1][1] = 0;
+  (t.template col<K>(c), ...);
+  if constexpr (K < BN_NL) {
+#pragma unroll
+    for (int i = 0; i < K; i++) { c.re += bn_dmul(mre[i], bn_p_limb(K - i)); c.im += bn_dmul(mim[i], bn_p_limb(K - i)); }
+  } else {
+#pragma unroll
+    for (int i = K - (BN_NL - 1); i < BN_NL; i++) { c.re += bn_dmul(mre[i], bn_p_limb(K - i)); c.im += bn_dmul(mim[i], bn_p_limb(K - i)); }
+  }
+  if (has1) { c.re += c.a[0][0] + c.a[0][1]; c.im += c.a[0][1] - c.a[0][0]; }
+  if (has2) { c.re += (c.a[1][0] + c.a[1][1]) << 1; c.im += (c.a[1][1] - c.a[1][0]) << 1; }
+  if constexpr (K < BN_NL) {
+    mre[K] = bn_sext29((uint32_t)c.re * BN_PINV);
+    mim[K] = bn_sext29((uint32_t)c.im * BN_PINV);
+    c.re += bn_dmul(mre[K], bn_p_limb(0));
+    c.im += bn_dmul(mim[K], bn_p_limb(0));
+    cre = (int64_t)c.re >> BN_LB;  // exact: the low 29 bits are zero
+    cim = (int64_t)c.im >> BN_LB;
+  } else {
+    c.re += BN_HALF; c.im += BN_HALF;
+    r.c0.v[K - BN_NL] = (int32_t)((uint32_t)c.re & BN_MASK) - BN_HALF;
+    r.c1.v[K - BN_NL] = (int32_t)((uint32_t)c.im & BN_MASK) - BN_HALF;
+    cre = (int64_t)c.re >> BN_LB;
+    cim = (int64_t)c.im >> BN_LB;
+  }
+}
+template <int... KS, class... T>
+BN_HD void dotk_all(std::integer_sequence<int, KS...>, int64_t& cre, int64_t& cim, int32_t (&mre)[BN_NL], int32_t (&mim)[BN_NL], Fp2& r, const T&... t) {
+  (dotk_step<KS, T...>(cre, cim, mre, mim, r, t...), ...);
+}
+template <class... T>
+BN_HD Fp2 fp2_dotk(const T&... t) {
+  BN_SCHED_FENCE();
+  int64_t cre = 0, cim = 0;
+  int32_t mre[BN_NL], mim[BN_NL];
+  Fp2 r;
+  dotk_all(std::make_integer_sequence<int, 2 * BN_NL - 1>{}, cre, cim, mre, mim, r, t...);
+  r.c0.v[BN_NL - 1] = (int32_t)cre;
+  r.c1.v[BN_NL - 1] = (int32_t)cim;
+  BN_SCHED_FENCE();
+#if BN_TRACKING
+  (t.check(), ...);
+  double cr = (t.cap_re() + ...), ci = (t.cap_im() + ...);
+  if (cr + 9.0 * 0.25 + 0.01 > 32.0 || ci + 9.0 * 0.25 + 0.01 > 32.0) fp_dbg_fail("fp2_dotk: accumulator may overflow", cr > ci ? cr : ci);
+  BN_SETB(r.c0, 1.0 + (t.val_re() + ...) / 169.0 + 1e-6, 0.5);
+  BN_SETB(r.c1, 1.0 + (t.val_im() + ...) / 169.0 + 1e-6, 0.5);
+#endif
+  return r;
+}
 BN_HD Fp2 fp2_mul(const Fp2& a, const Fp2& b) { return fp2_dotp(pp(a, b)); }
 // complex squaring: (a0+a1)(a0-a1), 2 a0 a1: two single products with lazy operand sums
 BN_HD Fp2 fp2_sqr(const Fp2& a) {
