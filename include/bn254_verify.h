@@ -126,7 +126,8 @@ int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_ev
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);                 /* n x 32 B each */
 int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);        /* 0 mul 1 sqr 2 inv 3 cyclo_sqr(after easy part) 4 frob1 */
 int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, size_t n, int device);          /* e(P_i, Q_i), n x 384 B */
-int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device);                       /* 1 = in G2 */
+int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device);                       /* 1 = in G2 (gnark's psi relation, one kernel) */
+int bn254_dbg_g2_subgroup_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* out_flags, size_t n, int device); /* 1 = in G2: the product's test, from the Miller loop's final point (g1: any G1 points) */
 
 const char* bn254_status_string(int status_byte);
 const char* bn254_last_error(void);

@@ -111,7 +111,7 @@ void bn254_set_profile_kernels(unsigned mask) { g_prof_mask = mask; }
 int bn254_groth16_num_kernel_kinds(void) { return KID_COUNT; }
 const char* bn254_groth16_kernel_kind_name(int i) { return (i >= 0 && i < KID_COUNT) ? bn254_kernel_kind_names[i] : ""; }
 const char* bn254_groth16_kernel_name(int i) {
-  static const char* names[BN254_G16_NUM_KERNELS] = {"phase_prepare", "phase_subgroup", "phase_miller", "phase_finalexp"};
+  static const char* names[BN254_G16_NUM_KERNELS] = {"phase_prepare", "phase_miller", "phase_subgroup", "phase_finalexp"};
   return (i >= 0 && i < BN254_G16_NUM_KERNELS) ? names[i] : "";
 }
 
@@ -314,6 +314,13 @@ int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, siz
   int rc = probe_ws_alloc(n, device);
   if (rc) return rc;
   rc = run_probe(64, 128, 384, g1, g2, out_gt, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_pairing(x, y, o, m, g_probe_ws, g_probe_kinds, nullptr); });
+  probe_ws_free();
+  return rc;
+}
+int bn254_dbg_g2_subgroup_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* out_flags, size_t n, int device) {
+  int rc = probe_ws_alloc(n, device);
+  if (rc) return rc;
+  rc = run_probe(64, 128, 1, g1, g2, out_flags, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_g2_ate(x, y, o, m, g_probe_ws, g_probe_kinds, nullptr); });
   probe_ws_free();
   return rc;
 }

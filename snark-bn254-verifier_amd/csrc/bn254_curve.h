@@ -206,14 +206,20 @@ BN_HD G2Aff g2_psi2_affine(const G2Aff& p) {  // psi^2: constants lie in Fp
 BN_HD bool g2_proj_eq(const G2Proj& a, const G2Proj& b) {  // both finite
   return fp2_eq(fp2_mul(a.x, b.z), fp2_mul(b.x, a.z)) & fp2_eq(fp2_mul(a.y, b.z), fp2_mul(b.y, a.z));
 }
-// [u]Q over the NAF of u, Q a finite point ON THE TWIST (any order): exceptional steps zero Z, which then sticks
-BN_HD G2Proj g2_mul_u(const G2Aff& q) {
-  G2Proj t = g2_from_affine(q);
-  G2Aff nq = g2_neg(q);
+// [u]Q over the NAF of u, Q a finite point ON THE TWIST (any order): exceptional steps zero Z, which then sticks.
+// LQ is a callable returning Q: the kernels re-load it from the workspace at every addition instead of keeping Q (and -Q)
+// in 72 registers across the loop.
+template <class LQ>
+BN_HD G2Proj g2_mul_u_ld(const LQ& load_q) {
+  G2Proj t = g2_from_affine(load_q());
   for (int i = 1; i < BN_U_NAF_LEN; i++) {
     (void)g2_double_step(t);
     int d = BN_U_NAF[i];
-    if (d != 0) (void)g2_add_step(t, d > 0 ? q : nq);  // public constant: wave-uniform branch
+    if (d != 0) {  // public constant: wave-uniform branch
+      G2Aff q = load_q();
+      if (d < 0) q.y = fp2_neg(q.y);
+      (void)g2_add_step(t, q);
+    }
   }
   return t;
 }
@@ -222,16 +228,23 @@ BN_HD G2Proj g2_mul_u(const G2Aff& q) {
 // Same accept set as the reference's [r-1]Q + Q == O (bn's AffineG2::new, reference converter.rs:152).
 // Any exceptional case of the incomplete formulas means ord(Q) is small or a relation that no point of prime order r
 // satisfies, hence Q is not in G2; it leaves Z = 0 on one side, which is rejected.
-BN_HD bool g2_in_subgroup(const G2Aff& q) {
-  G2Proj a = g2_mul_u(q);            // [u]Q
-  G2Proj b = g2_psi(a);              // psi([u]Q)
-  G2Proj a1 = a; (void)g2_add_step(a1, q);  // [u+1]Q
-  G2Proj b2 = g2_psi(b);             // psi^2([u]Q)
-  G2Proj lhs = g2_add_proj(g2_add_proj(b2, b), a1);
-  G2Proj rhs = g2_psi(b2);           // psi^3([u]Q)
-  (void)g2_double_step(rhs);         // psi^3([2u]Q)
-  bool finite = !fp2_is_zero(lhs.z) & !fp2_is_zero(rhs.z);
-  return finite & g2_proj_eq(lhs, rhs);
+// Evaluation order: one accumulator and one running psi-image, so that at most two projective points are live.
+template <class LQ>
+BN_HD bool g2_in_subgroup_ld(const LQ& load_q) {
+  G2Proj b = g2_mul_u_ld(load_q);     // [u]Q
+  G2Proj acc = b;
+  { G2Aff q = load_q(); (void)g2_add_step(acc, q); }   // [u+1]Q
+  b = g2_psi(b);                      // psi([u]Q)
+  acc = g2_add_proj(b, acc);
+  b = g2_psi(b);                      // psi^2([u]Q)
+  acc = g2_add_proj(b, acc);
+  b = g2_psi(b);                      // psi^3([u]Q)
+  (void)g2_double_step(b);            // psi^3([2u]Q)
+  bool finite = !fp2_is_zero(acc.z) & !fp2_is_zero(b.z);
+  return finite & g2_proj_eq(acc, b);
 }
+struct G2AffRef { const G2Aff& q; BN_HD G2Aff operator()() const { return q; } };
+BN_HD G2Proj g2_mul_u(const G2Aff& q) { return g2_mul_u_ld(G2AffRef{q}); }
+BN_HD bool g2_in_subgroup(const G2Aff& q) { return g2_in_subgroup_ld(G2AffRef{q}); }
 
 }  // namespace bn254

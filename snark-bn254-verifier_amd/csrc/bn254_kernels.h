@@ -52,4 +52,5 @@ hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* 
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program
 hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
+hipError_t bn254_launch_dbg_g2_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 hipError_t bn254_launch_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n, hipStream_t s);

@@ -246,16 +246,10 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
 // =====================================================================================================================
 __global__ void __launch_bounds__(256, 2)
 k_g16_subgroup(uint32_t n, int32_t* ws, uint8_t* __restrict__ status, int inputs_match_key) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const bool live = i < n;
-  const uint32_t ii = live ? i : n - 1;
-  uint8_t st = status[ii];
-  // a wave whose proofs all failed earlier has nothing to do
-  if (__builtin_amdgcn_ballot_w64((st & BN254_ST_PENDING) != 0) == 0) return;
-  DevWs w(ws, n, ii);
-  G2Aff B; B.x = vld2(w, VE_B); B.y = vld2(w, VE_B + 2);
-  bool ok = g2_in_subgroup(B);
-  if (live && (st & BN254_ST_PENDING)) {
+  // runs AFTER the Miller loop: the r-torsion test of B reads the loop's final G2 point (bn254_vm.h::vm_g2_ate_check)
+  VM_KERNEL_PROLOGUE();
+  bool ok = vm_g2_ate_check(w, VE_T, VE_B);
+  if (i < n && (st & BN254_ST_PENDING)) {
     uint8_t out;
     if (!ok) out = BN254_ST_NOT_IN_SUBGROUP;
     else if (st & 0x3f) out = st & 0x3f;                      // deferred error of C
@@ -263,6 +257,11 @@ k_g16_subgroup(uint32_t n, int32_t* ws, uint8_t* __restrict__ status, int inputs
     else out = BN254_ST_PENDING | (st & BN254_ST_LINF);
     status[i] = out;
   }
+}
+__global__ void __launch_bounds__(256, 2) k_dbg_g2_ate(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, uint8_t* o) {
+  VM_KERNEL_PROLOGUE();
+  bool ok = vm_g2_ate_check(w, VE_T, VE_B);
+  if (i < n) o[i] = ok ? 1 : 0;
 }
 
 // =====================================================================================================================
@@ -366,11 +365,12 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[0], s);
   BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[1], s);
-  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
-  if (ev) (void)hipEventRecord(ev[2], s);
   LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab}, prof};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
   vm_miller_program(ops, step_kinds_host(), true);
+  if (ev) (void)hipEventRecord(ev[2], s);
+  // r-torsion test of B from the loop's final point; resolves the deferred statuses (C errors, input count)
+  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[3], s);
   vm_final_exp_program(ops);
   BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, a.status, a.target);
@@ -407,6 +407,18 @@ hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_
   vm_miller_program(ops, step_kinds_host(), false);
   vm_final_exp_program(ops);
   hipLaunchKernelGGL(k_dbg_store, dim3(g), dim3(256), 0, s, ws, nn, (int)VE_S0, o);
+  return hipGetLastError();
+}
+// r-torsion test through the product path: T from the Miller program (variable pair only, A = any G1 point), then the ate relation
+hipError_t bn254_launch_dbg_g2_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
+  unsigned g = grid_for(n);
+  uint32_t nn = (uint32_t)n;
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}, nullptr};
+  hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g1, 1);
+  hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g2, 2);
+  hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, ws, nn, (const uint8_t*)status);
+  vm_miller_program(ops, step_kinds_host(), false);
+  hipLaunchKernelGGL(k_dbg_g2_ate, dim3(g), dim3(256), 0, s, ws, nn, (const uint8_t*)status, o);
   return hipGetLastError();
 }
 hipError_t bn254_launch_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n, hipStream_t s) {

@@ -93,6 +93,25 @@ BN_HD void vm_g2_add(W& w, int e_t, int e_line, int e_b, int which) {
   vst2(w, e_line, l.r0); vst2(w, e_line + 2, l.r1); vst2(w, e_line + 4, l.r2);
 }
 
+// ---- r-torsion test of B from the point the Miller loop has already computed ----------------------------------------------------------
+// After vm_miller_program the running point is T = [6u+2]B + psi(B) - psi^2(B).  For B on the twist E'(Fp2):
+//     B in G2  <=>  T == -psi^3(B)          (T finite)
+// "=>" is the optimal-ate relation 6u+2 + p - p^2 + p^3 = 0 (mod r) with psi = [p] on G2.  "<=": #E'(Fp2) = r h2 with
+// gcd(r, h2) = 1, psi satisfies X^2 - tX + p on E', and the resultant of chi(X) = X^3 - X^2 + X + (6u+2) with X^2 - tX + p is
+// coprime to h2 (tests/test_oracle_arith.py::test_ate_relation_is_a_subgroup_test computes it), so chi(psi) is injective on the
+// h2-torsion: a point with a component outside G2 cannot satisfy the relation.  Exceptional cases of the incomplete addition
+// formulas (only possible outside G2) zero Z, which sticks and is rejected here.  Same accept set as the reference's
+// [r-1]Q + Q == O (bn's AffineG2::new, reference converter.rs:152) and as gnark's relation (bn254_curve.h::g2_in_subgroup),
+// at the cost of six Fp2 products instead of a 63-bit scalar multiplication.
+template <class W>
+BN_HD bool vm_g2_ate_check(W& w, int e_t, int e_b) {
+  G2Aff b; b.x = vld2(w, e_b); b.y = vld2(w, e_b + 2);
+  Fp2 sx = fp2_mul(fp2_conj(b.x), frob_coeff(3, 2));            // psi^3(B).x
+  Fp2 sy = fp2_neg(fp2_mul(fp2_conj(b.y), frob_coeff(3, 3)));   // -psi^3(B).y
+  Fp2 X = vld2(w, e_t), Y = vld2(w, e_t + 2), Z = vld2(w, e_t + 4);
+  return !fp2_is_zero(Z) & fp2_eq(X, fp2_mul(sx, Z)) & fp2_eq(Y, fp2_mul(sy, Z));
+}
+
 // ---- general Fp12 product dst <- a * b (dst may alias a or b), Karatsuba over Fp6 with two workspace temporaries ----------------------
 // tower halves in k-order storage: c0 = (k0, k2, k4), c1 = (k1, k3, k5)
 template <class W> BN_HD Fp6 vld_half(W& w, int e, int h) { Fp6 r; r.c0 = vld2(w, e + 2 * h); r.c1 = vld2(w, e + 4 + 2 * h); r.c2 = vld2(w, e + 8 + 2 * h); return r; }

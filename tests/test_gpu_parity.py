@@ -111,6 +111,32 @@ def test_device_g2_subgroup(L, O):
         assert fl[i] == (1 if O.g2_subgroup_check(q) == 1 else 0), i
 
 
+def test_device_g2_subgroup_from_miller_loop(L, O):
+    """The product's r-torsion test (ate relation on the Miller loop's final point) against the oracle's naive check: G2 points,
+    random twist points, cofactor-cleared points, points of the cofactor group (also of small prime order) and G2 + cofactor sums."""
+    rng = random.Random(18)
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    pts = [O.g2_mul(g2, rng.randrange(1, R)) for _ in range(40)] + [_twist_point(O, rng) for _ in range(16)]
+    tq = _twist_point(O, rng)
+    h2 = 2 * P - R
+    pts.append(O.g2_mul(tq, h2))
+    cof = O.g2_mul(tq, R)
+    assert cof != bytes(128)
+    pts.append(cof)
+    for ell in (10069, 5864401):
+        small = O.g2_mul(cof, h2 // ell)
+        if small != bytes(128):
+            pts.append(small)
+            pts.append(O.g2_add(O.g2_mul(g2, rng.randrange(1, R)), small))
+    n = len(pts)
+    g1s = b"".join(O.g1_mul(g1, rng.randrange(1, R)) for _ in range(n))
+    fl = (C.c_uint8 * n)()
+    _chk(L, L.bn254_dbg_g2_subgroup_ate(g1s, b"".join(pts), fl, C.c_size_t(n), 0))
+    exp = [1 if O.g2_subgroup_check(q) == 1 else 0 for q in pts]
+    assert list(fl) == exp
+    assert sum(exp) == 41 and len(exp) >= 60
+
+
 def test_verify_batch_vs_oracle_all_classes(pkg, O, workload, L):
     vk, proofs, inputs, exp = workload
     n = 512

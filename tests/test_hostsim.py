@@ -139,6 +139,36 @@ def test_g2_subgroup_check(hostsim, O):
         assert O.g2_subgroup_check(q) == 0 and hs.hs_g2_in_subgroup(q) == 0
 
 
+def test_g2_ate_relation_subgroup_check(hostsim, O):
+    """The product's r-torsion test (final point of the Miller program against -psi^3(B), bn254_vm.h::vm_g2_ate_check) has the
+    accept set of the reference's naive check (oracle): G2 points, random twist points, cofactor-cleared points, points whose
+    order divides the cofactor (including small prime orders) and sums of a G2 point with a cofactor point."""
+    hs = hostsim
+    rng = random.Random(21)
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    pa = O.g1_mul(g1, rng.randrange(1, R))
+    for _ in range(3):
+        q = O.g2_mul(g2, rng.randrange(1, R))
+        assert O.g2_subgroup_check(q) == 1 and hs.hs_vm_g2_ate_check(pa, q) == 1
+    for _ in range(4):
+        q = _twist_point(O, rng)
+        assert hs.hs_vm_g2_ate_check(pa, q) == O.g2_subgroup_check(q)
+    h2 = 2 * P - R
+    tq = _twist_point(O, rng)
+    q = O.g2_mul(tq, h2)
+    assert O.g2_subgroup_check(q) == 1 and hs.hs_vm_g2_ate_check(pa, q) == 1
+    cof = O.g2_mul(tq, R)                      # order divides h2
+    assert cof != bytes(128)
+    assert O.g2_subgroup_check(cof) == 0 and hs.hs_vm_g2_ate_check(pa, cof) == 0
+    for ell in (10069, 5864401):
+        assert h2 % ell == 0
+        small = O.g2_mul(cof, h2 // ell)       # order ell (or the identity)
+        if small != bytes(128):
+            assert O.g2_subgroup_check(small) == 0 and hs.hs_vm_g2_ate_check(pa, small) == 0
+            mixed = O.g2_add(O.g2_mul(g2, 12345), small)
+            assert O.g2_subgroup_check(mixed) == 0 and hs.hs_vm_g2_ate_check(pa, mixed) == 0
+
+
 def test_pairing_matches_oracle_bytes(hostsim, O):
     hs = hostsim
     rng = random.Random(13)

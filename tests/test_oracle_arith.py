@@ -190,3 +190,32 @@ def test_independent_pairing_value(O):
     slow = slow_pairing_plain(p, q)
     fast = tower_bytes_to_poly(O.final_exp(O.miller_loop(pb, qb), plain=True))
     assert slow == fast
+
+
+def test_ate_relation_is_a_subgroup_test():
+    """Number theory behind bn254_vm.h::vm_g2_ate_check.  On the twist E'(Fp2), of order r * h2, the endomorphism psi satisfies
+    m(X) = X^2 - t X + p.  A relation chi(psi) Q = O that holds on G2 (chi(p) = 0 mod r) characterises G2 iff chi(psi) is
+    injective on the h2-torsion, which holds when Res(chi, m) is coprime to h2.  Checked for the optimal-ate relation
+    chi(X) = X^3 - X^2 + X + (6u+2) used by the product and, as a control, for gnark's (u+1) + u X + u X^2 - 2u X^3."""
+    from math import gcd
+    u = 4965661367192848881
+    p = 36 * u**4 + 36 * u**3 + 24 * u**2 + 6 * u + 1
+    r = 36 * u**4 + 36 * u**3 + 18 * u**2 + 6 * u + 1
+    t = 6 * u * u + 1
+    assert p + 1 - t == r
+    h2 = p - 1 + t
+    assert h2 == 21888242871839275222246405745257275088844257914179612981679871602714643921549  # the G2 cofactor of alt_bn128
+    assert gcd(r, h2) == 1
+
+    def res_with_m(c3, c2, c1, c0):
+        # chi mod m = a X + b using X^2 = tX - p, X^3 = (t^2 - p) X - t p; Res(chi, m) = prod over the roots x of m of (a x + b)
+        a = c3 * (t * t - p) + c2 * t + c1
+        b = -c3 * t * p - c2 * p + c0
+        return a * a * p + a * b * t + b * b
+
+    assert (6 * u + 2 + p - p * p + p**3) % r == 0
+    res = res_with_m(1, -1, 1, 6 * u + 2)
+    assert res % r == 0 and gcd(res, h2) == 1
+    assert ((u + 1) + u * p + u * p * p - 2 * u * p**3) % r == 0
+    res_gnark = res_with_m(-2 * u, u, u, u + 1)
+    assert res_gnark % r == 0 and gcd(res_gnark, h2) == 1
