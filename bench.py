@@ -33,7 +33,7 @@ ALGO_BYTES_PER_PROOF = 321
 # an Fp12-level operation cannot keep its 432-byte operands in registers across launches.
 KERNEL_ALGO_BYTES = {
     "k_f12_mul": 3 * 432,                    # a, b in; a*b out
-    "k_f12_sqr": 2 * 432, "k_f12_cyclo_sqr": 2 * 432, "k_f12_conj": 2 * 432, "k_f12_frob": 2 * 432, "k_f12_inv": 2 * 432,
+    "k_f12_sqr": 2 * 432, "k_f12_cyclo_sqr": 2 * 432, "k_f12_cyclo_sqr_n": 2 * 432, "k_f12_conj": 2 * 432, "k_f12_copy": 2 * 432, "k_f12_frob": 2 * 432, "k_f12_inv": 2 * 432,
     "k_f12_mul_line_var": 2 * 432 + 216 + 72,    # f in/out, line (3 Fp2), G1 point
     "k_f12_mul_line_fixed": 2 * 432 + 72,        # f in/out, G1 point (the line table entry is wave-uniform: scalar loads)
     "k_g2_dbl": 2 * 216 + 216, "k_g2_add": 2 * 216 + 216 + 144,   # T in/out, line out (, Q in)

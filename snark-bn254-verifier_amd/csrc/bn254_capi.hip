@@ -163,18 +163,20 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
     size_t m = n - off < (size_t)G16_MAX_BATCH ? n - off : (size_t)G16_MAX_BATCH;
     // sub-batches on concurrent streams: the tail of one sub-batch's kernel overlaps the head of the other's
     int parts = (n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
-    if (parts > 1 && !d->aux_ready) {
+    while ((m + parts - 1) / parts > (size_t)G16_MAX_LAUNCH) parts++;      // 32-bit workspace offsets per launch
+    const bool concurrent = n_streams > 1 && parts > 1;
+    if (concurrent && !d->aux_ready) {
       for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d->join_ev[i], hipEventDisableTiming)); }
       HIPCK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
       d->aux_ready = true;
     }
-    if (parts > 1) HIPCK(hipEventRecord(d->fork_ev, user));
+    if (concurrent) HIPCK(hipEventRecord(d->fork_ev, user));
     size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
     for (int pi = 0; pi < parts; pi++) {
       size_t lo = (size_t)pi * per, hi = lo + per < m ? lo + per : m;
       if (lo >= hi) break;
-      hipStream_t st = parts > 1 ? d->aux[pi] : user;
-      if (parts > 1) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
+      hipStream_t st = concurrent ? d->aux[pi % 4] : user;
+      if (concurrent && pi < 4) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
       G16LaunchArgs a;
       a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
       a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
@@ -187,7 +189,7 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
       hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : nullptr);
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));
-      if (parts > 1) { HIPCK(hipEventRecord(d->join_ev[pi], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi], 0)); }
+      if (concurrent && (pi + 4 >= parts)) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
     }
   }
   d->ev_recorded = g_profiling && d->ev_ready;
@@ -296,7 +298,7 @@ static thread_local uint8_t* g_probe_kinds = nullptr;
 static int probe_ws_alloc(size_t n, int device) {
   int rc = check_device(device);
   if (rc) return rc;
-  if (n > G16_MAX_BATCH) return set_err(BN254_E_BAD_ARG, "probe batch too large");
+  if (n > G16_MAX_LAUNCH) return set_err(BN254_E_BAD_ARG, "probe batch too large");
   HIPCK(hipMalloc((void**)&g_probe_ws, (n ? n : 1) * (size_t)G16_WS_BYTES_PER_PROOF));
   HIPCK(hipMalloc((void**)&g_probe_kinds, n ? n : 1));  // status bytes of the probe lanes
   return BN254_OK;

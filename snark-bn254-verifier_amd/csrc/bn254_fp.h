@@ -33,6 +33,12 @@
 #else
 #define BN_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 #endif
+// out of line on the host (compile time), inline on the device: a device call passes its Fp arguments through scratch memory
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BN_HD_DEVINLINE __host__ __device__ __forceinline__
+#else
+#define BN_HD_DEVINLINE __host__ __device__ inline __attribute__((noinline))
+#endif
 #else
 #if defined(BN_TRACK_BOUNDS)
 #define BN_HD inline
@@ -40,6 +46,7 @@
 #define BN_HD inline __attribute__((always_inline))
 #endif
 #define BN_HD_NOINLINE inline __attribute__((noinline))
+#define BN_HD_DEVINLINE inline __attribute__((noinline))
 #endif
 
 // scheduling fence: stops the machine scheduler from interleaving independent field multiplications (which
@@ -421,8 +428,8 @@ BN_HD void words_to_be(uint8_t* be32, const uint32_t w[8]) {
 }
 
 // ---- exponentiation by a fixed public exponent (bit table from bn254_constants.h), inversion -------------------------------------
-BN_HD_NOINLINE Fp fp_mul_nl(const Fp& a, const Fp& b) { return fp_mul(a, b); }
-BN_HD_NOINLINE Fp fp_sqr_nl(const Fp& a) { return fp_sqr(a); }
+BN_HD_DEVINLINE Fp fp_mul_nl(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+BN_HD_DEVINLINE Fp fp_sqr_nl(const Fp& a) { return fp_sqr(a); }
 BN_HD Fp fp_pow_bits(const Fp& a, const uint8_t* bits, int nbits) {  // bits[0] = leading 1
   Fp acc = a;
   for (int i = 1; i < nbits; i++) {

@@ -17,14 +17,15 @@
 
 #define MSM_ENTRY_DWORDS 20    // affine G1 point, 2 x 9 limbs + 2 pad: 80-byte entries, 16-byte aligned
 #define FIXED_LINE_DWORDS 54   // one precomputed Miller step of a fixed G2 argument: m, c, xi*c (3 Fp2)
-#define G16_WS_ELEMS 106       // Fp elements per proof in the workspace (bn254_vm.h: VE_COUNT)
+#define G16_WS_ELEMS 130       // Fp elements per proof in the workspace (bn254_vm.h: VE_COUNT)
 #define G16_WS_BYTES_PER_PROOF (G16_WS_ELEMS * 36)
-#define G16_MAX_BATCH 1048576  // the workspace is addressed with 32-bit buffer offsets: 106 * 36 * n < 2^32
+#define G16_MAX_BATCH 1048576  // proofs per chunk of a larger batch (one workspace)
+#define G16_MAX_LAUNCH 786432  // proofs per kernel launch: the workspace is addressed with 32-bit buffer offsets, 130 * 36 * n < 2^32
 
 struct G16LaunchArgs {
   const uint8_t* proofs; size_t stride;
   const uint8_t* inputs; int n_public;
-  size_t n;                 // <= G16_MAX_BATCH
+  size_t n;                 // <= G16_MAX_LAUNCH
   int32_t* ws;              // G16_WS_BYTES_PER_PROOF * n bytes
   uint8_t* status;          // n bytes
   const int32_t* msm_tab;   // n_public * 32 * 255 entries of MSM_ENTRY_DWORDS
@@ -37,7 +38,7 @@ struct G16LaunchArgs {
 // kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
 enum {
   KID_PREPARE, KID_SUBGROUP, KID_VM_INIT, KID_F12_SQR, KID_G2_DBL, KID_G2_ADD, KID_MUL_LINE_VAR, KID_MUL_LINE_FIXED, KID_F12_MUL,
-  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_COUNT
+  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_F12_COPY, KID_CYCLO_SQR_N, KID_COUNT
 };
 extern const char* const bn254_kernel_kind_names[KID_COUNT];
 // optional per-launch timing: every launch whose kind is in `mask` is bracketed by two events from the pool

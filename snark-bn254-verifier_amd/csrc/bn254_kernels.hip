@@ -101,8 +101,14 @@ __global__ void __launch_bounds__(256, 2) k_g2_dbl(int32_t* ws, uint32_t n, cons
 __global__ void __launch_bounds__(256, 2) k_g2_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line, int e_b, int which) {
   VM_KERNEL_PROLOGUE(); vm_g2_add(w, e_t, e_line, e_b, which);
 }
-__global__ void __launch_bounds__(256, 2) k_f12_mul(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int b) { VM_KERNEL_PROLOGUE(); vm_f12_mul(w, d, a, b); }
+__global__ void __launch_bounds__(256, 2) k_f12_mul(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int b, int conj_b) {
+  VM_KERNEL_PROLOGUE(); vm_f12_mul(w, d, a, b, conj_b != 0);
+}
+__global__ void __launch_bounds__(256, 2) k_f12_copy(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_copy(w, d, a); }
 __global__ void __launch_bounds__(256, 2) k_f12_cyclo_sqr(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_cyclo_sqr(w, d, a); }
+__global__ void __launch_bounds__(256, 2) k_f12_cyclo_sqr_n(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int count) {
+  VM_KERNEL_PROLOGUE(); vm_f12_cyclo_sqr_n(w, d, a, __builtin_amdgcn_readfirstlane(count));
+}
 __global__ void __launch_bounds__(256, 2) k_f12_conj(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_conj(w, d, a); }
 __global__ void __launch_bounds__(256, 2) k_f12_frob(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int j) { VM_KERNEL_PROLOGUE(); vm_f12_frob(w, d, a, j); }
 __global__ void __launch_bounds__(256, 2) k_f12_inv(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_inv(w, d, a); }
@@ -218,15 +224,23 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
 #pragma unroll
         for (int k = 0; k < 8; k++) sw[k] = (uint32_t)sp[4 * k] | (uint32_t)sp[4 * k + 1] << 8 | (uint32_t)sp[4 * k + 2] << 16 | (uint32_t)sp[4 * k + 3] << 24;
       }
-      // byte j of the big-endian scalar is sw[j / 4] >> (8 (j % 4)); window w (weight 2^(8w)) is byte 31 - w
-      for (int wi = 0; wi < 32; wi++) {
-        int j = 31 - wi;
-        uint32_t dig = (sw[j >> 2] >> (8 * (j & 3))) & 0xff;
-        if (dig != 0) {
-          const int32_t* e = msm_tab + ((size_t)(s * 32 + wi) * 255 + (dig - 1)) * MSM_ENTRY_DWORDS;
-          G1Aff q;
+      // byte j of the big-endian scalar is sw[j / 4] >> (8 (j % 4)); window wi (weight 2^(8 wi)) is byte 31 - wi.  The bytes are
+      // consumed from the low end of sw[0] and the 256-bit array is shifted down by 8 each time: no dynamic register indexing.
+      for (int j = 0; j < 32; j++) {
+        const int wi = 31 - j;
+        uint32_t dig = sw[0] & 0xff;
 #pragma unroll
-          for (int l = 0; l < BN_NL; l++) { q.x.v[l] = e[l]; q.y.v[l] = e[BN_NL + l]; }
+        for (int k = 0; k < 7; k++) sw[k] = (sw[k] >> 8) | (sw[k + 1] << 24);
+        sw[7] >>= 8;
+        if (dig != 0) {
+          // 80-byte table entry (18 digits + 2 pad), 16-byte aligned: five 16-byte loads per lane
+          const int4* e = (const int4*)(msm_tab + ((size_t)(s * 32 + wi) * 255 + (dig - 1)) * MSM_ENTRY_DWORDS);
+          int4 v0 = e[0], v1 = e[1], v2 = e[2], v3 = e[3], v4 = e[4];
+          G1Aff q;
+          q.x.v[0] = v0.x; q.x.v[1] = v0.y; q.x.v[2] = v0.z; q.x.v[3] = v0.w; q.x.v[4] = v1.x; q.x.v[5] = v1.y; q.x.v[6] = v1.z; q.x.v[7] = v1.w;
+          q.x.v[8] = v2.x; q.y.v[0] = v2.y; q.y.v[1] = v2.z; q.y.v[2] = v2.w; q.y.v[3] = v3.x; q.y.v[4] = v3.y; q.y.v[5] = v3.z; q.y.v[6] = v3.w;
+          q.y.v[7] = v4.x; q.y.v[8] = v4.y;
+          BN_SETB(q.x, 1.0, 0.5); BN_SETB(q.y, 1.0, 0.5);
           L = g1_add_mixed(L, q);
         }
       }
@@ -324,7 +338,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_g2_dbl", "k_g2_add", "k_f12_mul_line_var", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -346,8 +360,10 @@ struct LaunchOps {
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
     BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, t == 0 ? 1 : 0);
   }
-  void f12_mul(int d, int a, int b) { BN_LAUNCH(KID_F12_MUL, k_f12_mul, ws, n, status, d, a, b); }
+  void f12_mul(int d, int a, int b, bool conj_b = false) { BN_LAUNCH(KID_F12_MUL, k_f12_mul, ws, n, status, d, a, b, conj_b ? 1 : 0); }
+  void f12_copy(int d, int a) { BN_LAUNCH(KID_F12_COPY, k_f12_copy, ws, n, status, d, a); }
   void f12_cyclo_sqr(int d, int a) { BN_LAUNCH(KID_CYCLO_SQR, k_f12_cyclo_sqr, ws, n, status, d, a); }
+  void f12_cyclo_sqr_n(int d, int a, int count) { BN_LAUNCH(KID_CYCLO_SQR_N, k_f12_cyclo_sqr_n, ws, n, status, d, a, count); }
   void f12_conj(int d, int a) { BN_LAUNCH(KID_F12_CONJ, k_f12_conj, ws, n, status, d, a); }
   void f12_frob(int d, int a, int j) { BN_LAUNCH(KID_F12_FROB, k_f12_frob, ws, n, status, d, a, j); }
   void f12_inv(int d, int a) { BN_LAUNCH(KID_F12_INV, k_f12_inv, ws, n, status, d, a); }

@@ -20,9 +20,11 @@ enum {
   VE_AX = 0, VE_AY = 1, VE_B = 2 /* x.c0 x.c1 y.c0 y.c1 */, VE_CX = 6, VE_CY = 7, VE_LX = 8, VE_LY = 9,
   VE_F = 10,                 // Miller accumulator, then m = easy part of the final exponentiation
   VE_T = 22, VE_LINE = 28,   // Miller loop: running G2 point (X, Y, Z) and the current line (r0, r1, r2)
-  VE_S0 = 22, VE_S1 = 34, VE_S2 = 46, VE_S3 = 58, VE_S4 = 70, VE_XC = 82,  // final exponentiation slots (S0 aliases T + LINE)
+  VE_S0 = 22, VE_S1 = 34, VE_S2 = 46, VE_S3 = 58, VE_S4 = 70,  // final exponentiation slots (S0 aliases T + LINE)
+  VE_P3 = 82,                   // x^3 of the windowed exp-by-u
   VE_TMPA = 94, VE_TMPB = 100,  // two Fp6 temporaries of the general Fp12 product
-  VE_COUNT = 106
+  VE_P5 = 106, VE_P7 = 118,     // x^5, x^7
+  VE_COUNT = 130
 };
 
 template <class W> BN_HD Fp2 vld2(W& w, int e) { Fp2 r; r.c0 = w.ld(e); r.c1 = w.ld(e + 1); return r; }
@@ -116,14 +118,16 @@ BN_HD bool vm_g2_ate_check(W& w, int e_t, int e_b) {
 // tower halves in k-order storage: c0 = (k0, k2, k4), c1 = (k1, k3, k5)
 template <class W> BN_HD Fp6 vld_half(W& w, int e, int h) { Fp6 r; r.c0 = vld2(w, e + 2 * h); r.c1 = vld2(w, e + 4 + 2 * h); r.c2 = vld2(w, e + 8 + 2 * h); return r; }
 template <class W> BN_HD void vst_half(W& w, int e, int h, const Fp6& a) { vst2(w, e + 2 * h, a.c0); vst2(w, e + 4 + 2 * h, a.c1); vst2(w, e + 8 + 2 * h, a.c2); }
+// conj_b: multiply by conj(b) = b^(p^6) (the inverse of b on the cyclotomic subgroup): the odd half of b is negated on load
 template <class W>
-BN_HD void vm_f12_mul(W& w, int e_dst, int e_a, int e_b) {
+BN_HD void vm_f12_mul(W& w, int e_dst, int e_a, int e_b, bool conj_b = false) {
   { Fp6 v0 = fp6_mul(vld_half(w, e_a, 0), vld_half(w, e_b, 0)); vst6(w, VE_TMPA, v0); }
-  { Fp6 v1 = fp6_mul(vld_half(w, e_a, 1), vld_half(w, e_b, 1)); vst6(w, VE_TMPB, v1); }
+  { Fp6 b1 = vld_half(w, e_b, 1); if (conj_b) b1 = fp6_neg(b1); Fp6 v1 = fp6_mul(vld_half(w, e_a, 1), b1); vst6(w, VE_TMPB, v1); }
   Fp6 s;
   {
     Fp6 sa = fp6_add(vld_half(w, e_a, 0), vld_half(w, e_a, 1));
-    Fp6 sb = fp6_add(vld_half(w, e_b, 0), vld_half(w, e_b, 1));
+    Fp6 b1 = vld_half(w, e_b, 1); if (conj_b) b1 = fp6_neg(b1);
+    Fp6 sb = fp6_add(vld_half(w, e_b, 0), b1);
     s = fp6_mul(sa, sb);
   }
   Fp6 v0 = vld6(w, VE_TMPA), v1 = vld6(w, VE_TMPB);
@@ -152,7 +156,24 @@ BN_HD void vm_f12_cyclo_sqr(W& w, int e_dst, int e_src) {
     vst2(w, e_dst + 4, z2); vst2(w, e_dst + 10, z5); vst2(w, e_dst + 8, z4); vst2(w, e_dst + 2, z1);
   }
 }
+// ---- dst <- src^(2^count): a run of Granger-Scott squarings with all six coefficients resident in registers -------------------------
+// (one load and one store of the element per run instead of per squaring; exp-by-u has runs of 4 to 7 squarings between products)
+template <class W>
+BN_HD void vm_f12_cyclo_sqr_n(W& w, int e_dst, int e_src, int count) {
+  Fp2 k0 = vld2(w, e_src), k1 = vld2(w, e_src + 2), k2 = vld2(w, e_src + 4), k3 = vld2(w, e_src + 6), k4 = vld2(w, e_src + 8), k5 = vld2(w, e_src + 10);
+  for (int it = 0; it < count; it++) {
+    Fp2 n0, n3, n2, n5, n4, n1;
+    gs_pair(n0, n3, k0, k3, k0, k3, false);
+    k0 = n0; k3 = n3;
+    gs_pair(n2, n5, k1, k4, k2, k5, false);
+    gs_pair(n4, n1, k2, k5, k4, k1, true);
+    k1 = n1; k2 = n2; k4 = n4; k5 = n5;
+  }
+  vst2(w, e_dst, k0); vst2(w, e_dst + 2, k1); vst2(w, e_dst + 4, k2); vst2(w, e_dst + 6, k3); vst2(w, e_dst + 8, k4); vst2(w, e_dst + 10, k5);
+}
 // ---- cheap unary operations ------------------------------------------------------------------------------------------------------------
+template <class W>
+BN_HD void vm_f12_copy(W& w, int e_dst, int e_src) { for (int k = 0; k < 12; k++) w.st(e_dst + k, w.ld(e_src + k)); }
 template <class W>
 BN_HD void vm_f12_conj(W& w, int e_dst, int e_src) {  // negate the odd coefficients
   for (int k = 0; k < 6; k++) { Fp2 x = vld2(w, e_src + 2 * k); vst2(w, e_dst + 2 * k, (k & 1) ? fp2_neg(x) : x); }
@@ -224,16 +245,29 @@ BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS
     }
   }
 }
-// x^u on the cyclotomic subgroup over NAF(u): dst <- src^u; e_xc receives conj(src); dst != src
+// x^u on the cyclotomic subgroup: dst <- src^u (dst != src), width-4 signed windows of u (BN_U_W4: digits +-1, +-3, +-5, +-7).
+// x^3, x^5, x^7 go to VE_P3/P5/P7; a negative digit multiplies by the conjugate (= inverse) of the table entry.
+// 63 cyclotomic squarings + 16 products (NAF(u): 62 + 23 and two conjugations).
 template <class OPS>
-BN_HD void vm_exp_u(OPS& ops, int e_dst, int e_src, int e_xc) {
-  ops.f12_conj(e_xc, e_src);
-  ops.f12_conj(e_dst, e_xc);  // dst = src (conj twice: a copy)
-  for (int i = 1; i < BN_U_NAF_LEN; i++) {
-    ops.f12_cyclo_sqr(e_dst, e_dst);
-    int d = BN_U_NAF[i];
-    if (d != 0) ops.f12_mul(e_dst, e_dst, d > 0 ? e_src : e_xc);
+BN_HD void vm_exp_u(OPS& ops, int e_dst, int e_src) {
+  ops.f12_cyclo_sqr(e_dst, e_src);                 // x^2
+  ops.f12_mul(VE_P3, e_dst, e_src, false);
+  ops.f12_mul(VE_P5, VE_P3, e_dst, false);
+  ops.f12_mul(VE_P7, VE_P5, e_dst, false);
+  // leading digit of BN_U_W4 is +1; x^2 in e_dst is no longer needed once the table is built
+  int run = 0, first = 1;
+  for (int i = 1; i < BN_U_W4_LEN; i++) {
+    run++;
+    int d = BN_U_W4[i];
+    if (d != 0) {
+      // the first run squares src straight into dst (leading digit +1: the accumulator starts as x)
+      ops.f12_cyclo_sqr_n(e_dst, first ? e_src : e_dst, run);
+      run = 0; first = 0;
+      int a = d < 0 ? -d : d;
+      ops.f12_mul(e_dst, e_dst, a == 1 ? e_src : a == 3 ? VE_P3 : a == 5 ? VE_P5 : VE_P7, d < 0);
+    }
   }
+  // BN_U_W4 ends in a non-zero digit (u is odd): no trailing run
 }
 // final exponentiation of VE_F; the result ends in VE_S0 (same exponent as bn254_pairing.h::final_exponentiation)
 template <class OPS>
@@ -241,19 +275,19 @@ BN_HD void vm_final_exp_program(OPS& ops) {
   // easy part: m = f^((p^6-1)(p^2+1)) -> VE_F
   ops.f12_inv(VE_S0, VE_F);
   ops.f12_conj(VE_S1, VE_F);
-  ops.f12_mul(VE_S0, VE_S1, VE_S0);
+  ops.f12_mul(VE_S0, VE_S1, VE_S0, false);
   ops.f12_frob(VE_S1, VE_S0, 2);
   ops.f12_mul(VE_F, VE_S1, VE_S0);
   // hard part
-  vm_exp_u(ops, VE_S0, VE_F, VE_XC); ops.f12_conj(VE_S0, VE_S0);      // t0 = m^-u
+  vm_exp_u(ops, VE_S0, VE_F); ops.f12_conj(VE_S0, VE_S0);      // t0 = m^-u
   ops.f12_cyclo_sqr(VE_S0, VE_S0);                                     // -2u
   ops.f12_cyclo_sqr(VE_S1, VE_S0);                                     // -4u
   ops.f12_mul(VE_S1, VE_S0, VE_S1);                                    // t1 = -6u
-  vm_exp_u(ops, VE_S2, VE_S1, VE_XC); ops.f12_conj(VE_S2, VE_S2);     // t2 = 6u^2
+  vm_exp_u(ops, VE_S2, VE_S1); ops.f12_conj(VE_S2, VE_S2);     // t2 = 6u^2
   ops.f12_conj(VE_S3, VE_S1);                                          // t3 = 6u
   ops.f12_mul(VE_S1, VE_S2, VE_S3);                                    // t1 = 6u^2 + 6u
   ops.f12_cyclo_sqr(VE_S3, VE_S2);                                     // t3 = 12u^2
-  vm_exp_u(ops, VE_S4, VE_S3, VE_XC);                                  // t4 = 12u^3
+  vm_exp_u(ops, VE_S4, VE_S3);                                  // t4 = 12u^3
   ops.f12_mul(VE_S4, VE_S1, VE_S4);                                    // t4 = 12u^3 + 6u^2 + 6u
   ops.f12_mul(VE_S3, VE_S0, VE_S4);                                    // t3 = 12u^3 + 6u^2 + 4u
   ops.f12_mul(VE_S0, VE_S2, VE_S4);                                    // t0 = 12u^3 + 12u^2 + 6u
