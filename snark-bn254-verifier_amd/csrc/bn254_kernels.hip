@@ -101,6 +101,12 @@ __global__ void __launch_bounds__(256, 2) k_g2_dbl(int32_t* ws, uint32_t n, cons
 __global__ void __launch_bounds__(256, 2) k_g2_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line, int e_b, int which) {
   VM_KERNEL_PROLOGUE(); vm_g2_add(w, e_t, e_line, e_b, which);
 }
+__global__ void __launch_bounds__(256, 2) k_miller_dbl_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_px) {
+  VM_KERNEL_PROLOGUE(); vm_miller_dbl_var(w, e_t, e, e_px);
+}
+__global__ void __launch_bounds__(256, 2) k_miller_add_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_b, int which, int e, int e_px) {
+  VM_KERNEL_PROLOGUE(); vm_miller_add_var(w, e_t, e_b, which, e, e_px);
+}
 __global__ void __launch_bounds__(256, 2) k_f12_mul(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int b, int conj_b) {
   VM_KERNEL_PROLOGUE(); vm_f12_mul(w, d, a, b, conj_b != 0);
 }
@@ -338,7 +344,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_g2_dbl", "k_g2_add", "k_f12_mul_line_var", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -356,6 +362,8 @@ struct LaunchOps {
   void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
   void g2_dbl(int et, int el) { BN_LAUNCH(KID_G2_DBL, k_g2_dbl, ws, n, status, et, el); }
   void g2_add(int et, int el, int eb, int which) { BN_LAUNCH(KID_G2_ADD, k_g2_add, ws, n, status, et, el, eb, which); }
+  void miller_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_DBL_VAR, k_miller_dbl_var, ws, n, status, et, e, ep); }
+  void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
   void f12_mul_line_var(int e, int el, int ep) { BN_LAUNCH(KID_MUL_LINE_VAR, k_f12_mul_line_var, ws, n, status, e, el, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
     BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, t == 0 ? 1 : 0);

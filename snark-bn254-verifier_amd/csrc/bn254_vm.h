@@ -95,6 +95,39 @@ BN_HD void vm_g2_add(W& w, int e_t, int e_line, int e_b, int which) {
   vst2(w, e_line, l.r0); vst2(w, e_line + 2, l.r1); vst2(w, e_line + 4, l.r2);
 }
 
+// ---- fused Miller step of the variable pair: T <- 2T (or T + Q), f <- f * line(P); the line never leaves the registers -----------
+template <class W>
+BN_HD void vm_f12_mul_line_regs(W& w, int e, const G2Line& l, int e_px) {
+  Fp px = w.ld(e_px), py = w.ld(e_px + 1);
+  Fp2 d0 = fp2_mul_fp(l.r0, py), d3 = fp2_mul_fp(l.r1, px), d4 = l.r2;
+  Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
+  Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+  vst2(w, e, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3)));
+  vst2(w, e + 2, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4)));
+  vst2(w, e + 4, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5)));
+  vst2(w, e + 6, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0)));
+  vst2(w, e + 8, fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1)));
+  vst2(w, e + 10, fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2)));
+}
+template <class W>
+BN_HD void vm_miller_dbl_var(W& w, int e_t, int e, int e_px) {
+  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+  G2Line l = g2_double_step(t);
+  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  vm_f12_mul_line_regs(w, e, l, e_px);
+}
+template <class W>
+BN_HD void vm_miller_add_var(W& w, int e_t, int e_b, int which, int e, int e_px) {
+  G2Aff q; q.x = vld2(w, e_b); q.y = vld2(w, e_b + 2);
+  if (which == 1) q = g2_neg(q);
+  else if (which == 2) q = g2_psi_affine(q);
+  else if (which == 3) q = g2_neg(g2_psi2_affine(q));
+  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+  G2Line l = g2_add_step(t, q);
+  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  vm_f12_mul_line_regs(w, e, l, e_px);
+}
+
 // ---- r-torsion test of B from the point the Miller loop has already computed ----------------------------------------------------------
 // After vm_miller_program the running point is T = [6u+2]B + psi(B) - psi^2(B).  For B on the twist E'(Fp2):
 //     B in G2  <=>  T == -psi^3(B)          (T finite)
@@ -236,9 +269,8 @@ BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS
   // f = 1, T = B are set by the caller
   for (int s = 0; s < BN_ATE_STEPS; s++) {
     int kind = ops.uni(step_kinds[s]);
-    if (kind == 0) { if (s != 0) ops.f12_sqr(VE_F); ops.g2_dbl(VE_T, VE_LINE); }
-    else ops.g2_add(VE_T, VE_LINE, VE_B, kind - 1);
-    ops.f12_mul_line_var(VE_F, VE_LINE, VE_AX);
+    if (kind == 0) { if (s != 0) ops.f12_sqr(VE_F); ops.miller_dbl_var(VE_T, VE_F, VE_AX); }
+    else ops.miller_add_var(VE_T, VE_B, kind - 1, VE_F, VE_AX);
     if (with_fixed_pairs) {
       ops.f12_mul_line_fixed(VE_F, 0, s, VE_LX);  // table 0 (paired with L), step s
       ops.f12_mul_line_fixed(VE_F, 1, s, VE_CX);  // table 1 (paired with C)
