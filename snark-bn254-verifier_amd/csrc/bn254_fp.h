@@ -27,7 +27,11 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#if defined(__HIP_DEVICE_COMPILE__)
 #define BN_HD __host__ __device__ __forceinline__
+#else
+#define BN_HD __host__ __device__ inline   // host pass: let the compiler decide (forced inlining makes the host build 4x slower)
+#endif
 #if defined(BN_INLINE_ALL)
 #define BN_HD_NOINLINE __host__ __device__ __forceinline__
 #else
