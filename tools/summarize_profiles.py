@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/gpu_round.sh (gpurun_out/) into the tracked summaries under profiles/.
+usage: python tools/summarize_profiles.py r01_final"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+
+
+def short(name):
+    return name.split("(")[0].replace("bn254::", "").strip()
+
+
+# ---- kernel trace: per-kernel calls / total / average (ns) from the raw trace (the --stats file carries the same numbers)
+tr = glob.glob(os.path.join(root, "gpurun_out/prof/**/*kernel_trace.csv"), recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(tr)):
+    agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+tot = sum(sum(v) for v in agg.values())
+with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (3 batches of 2^20; 2 sub-batch streams => launches cover 2^19 proofs)\n")
+    f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        f.write("%s,%d,%.3f,%.2f,%.2f,%.2f,%.2f\n" % (k, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3, 100.0 * sum(v) / tot))
+st = glob.glob(os.path.join(root, "gpurun_out/prof/**/*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(out, tag + "_rocprof_kernel_stats_raw.csv"))
+for name in ("bench.json", "prof_bench.json"):
+    p = os.path.join(root, "gpurun_out", name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(out, tag + "_" + name))
+
+
+# ---- PMC passes (batch 2^18, one stream)
+def load(pattern):
+    path = glob.glob(os.path.join(root, pattern), recursive=True)[0]
+    rows = list(csv.DictReader(open(path)))
+    a = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    first = rows[0]["Counter_Name"]
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if not k.startswith("k_"):
+            continue
+        a[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == first:
+            cnt[k] += 1
+    return a, cnt
+
+
+sq, cnt = load("gpurun_out/pmc_SQ_WAVE_CYCLES/**/*counter_collection.csv")
+fs, _ = load("gpurun_out/pmc_FETCH_SIZE/**/*counter_collection.csv")
+ws, _ = load("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv")
+n = 1 << 18
+traffic = {"_note": "HBM bytes per proof and launch of each kernel kind from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, batch 2^18, "
+                    "one stream, bench.py --steps 1 --warmup 0); FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md prescribes for gfx950 (checked on "
+                    "k_f12_sqr, whose reads are exactly 432 B/proof), WRITE_SIZE (KB) as reported", "batch": n}
+lines = ["kernel,launches,valu_active_frac,any_active_frac,wait_any_frac,wait_inst_frac,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_read_B_per_proof(2xFETCH),hbm_write_B_per_proof"]
+for k in sorted(sq, key=lambda k: -sq[k]["SQ_WAVE_CYCLES"]):
+    c = sq[k]; wc = c["SQ_WAVE_CYCLES"] or 1
+    f_ = fs[k]["FETCH_SIZE"] / max(cnt[k], 1); w_ = ws[k]["WRITE_SIZE"] / max(cnt[k], 1)
+    rd = 2 * f_ * 1024 / n; wr = w_ * 1024 / n
+    traffic[k] = {"read_bytes_per_proof": round(rd, 1), "write_bytes_per_proof": round(wr, 1)}
+    lines.append("%s,%d,%.3f,%.3f,%.3f,%.3f,%.0f,%.0f,%.0f,%.0f" % (k, cnt[k], c["SQ_ACTIVE_INST_VALU"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc,
+                                                                   c["SQ_WAIT_ANY"] / wc, c["SQ_WAIT_INST_ANY"] / wc, f_, w_, rd, wr))
+open(os.path.join(out, tag + "_pmc_summary.csv"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
