@@ -1,20 +1,24 @@
 // bn254_kernels.hip -- the gfx950 kernels of the Groth16 batch verifier, one proof per lane.
 //
 // Pipeline per batch (DESIGN.md "Kernels"):
-//   k_g16_prepare   parse 256 proof bytes (coalesced through LDS), range / on-curve checks of A, B, C, Montgomery
-//                   conversion, L = K0 + sum x_i K_i by fixed-base 8-bit windows        (groth16/converter.rs:14-26, verify.rs:53-63)
-//   k_g16_subgroup  r-torsion test of B, status precedence                              (converter.rs:152)
-//   k_g16_miller    f = Miller(A,B) * lines_G(L) * lines_D(C), G/D tables shared by the batch (verify.rs:73-77)
-//   k_g16_finalexp  f^((p^12-1)/r) == e(alpha,beta) -> status byte                      (verify.rs:77)
+//   k_g16_prepare     parse 256 proof bytes (coalesced through LDS), range / on-curve checks of A, B, C, Montgomery
+//                     conversion, L = K0 + sum x_i K_i by fixed-base 8-bit windows      (groth16/converter.rs:14-26, verify.rs:53-63)
+//   k_vm_init, k_f12_sqr, k_miller_dbl_var, k_miller_add_var, k_f12_mul_line_fixed
+//                     the shared Miller loop f = Miller(A,B) * lines_G(L) * lines_D(C), one launch per Fp12-level
+//                     operation of bn254_vm.h::vm_miller_program; G/D line tables shared by the batch  (verify.rs:73-77)
+//   k_g16_subgroup    r-torsion test of B from the loop's final G2 point, status precedence   (converter.rs:152)
+//   k_f12_inv, k_f12_conj, k_f12_frob, k_f12_mul, k_f12_cyclo_sqr(_n), k_f12_copy
+//                     f^((p^12-1)/r), bn254_vm.h::vm_final_exp_program                          (verify.rs:77)
+//   k_g16_compare     == e(alpha, beta) -> status byte                                          (verify.rs:77)
 //
-// Workspace (bn254_vm.h element map): element e, limb group g (3 limbs), proof i at byte ((e * 3 + g) * n + i) * 12, accessed
-// through ONE buffer descriptor: the row offset (e, g) is wave-uniform and travels in an SGPR (soffset), the lane offset i * 12 is
-// one VGPR shared by every access, so no per-access address arithmetic exists and a wave-level access is a contiguous 768-byte
-// segment (buffer_load_dwordx3 / buffer_store_dwordx3).
+// Workspace (bn254_vm.h element map): element e, digit l, proof i at dword (e * 9 + l) * n + i, accessed through ONE buffer
+// descriptor: the row offset (e, l) is wave-uniform and travels in an SGPR (soffset), the lane offset i * 4 is one VGPR shared
+// by every access, so no per-access address arithmetic exists and a wave-level access is one contiguous 256-byte segment
+// (buffer_load_dword / buffer_store_dword).  Lanes past the end of the batch get an out-of-range offset: the descriptor's bounds
+// check returns 0 for their loads and drops their stores.
 //
-// The Miller loop and the final exponentiation are sequences of out-of-line Fp12-level operations on that workspace
-// (bn254_vm.h): each operation is compiled once, gets the full 256-VGPR budget of a 2-waves-per-SIMD kernel and keeps nothing
-// in registers between operations.
+// Every operation is its own kernel: it gets the full 256-VGPR budget of a 2-waves-per-SIMD launch and keeps nothing in
+// registers between operations.  The host walks the program (LaunchOps below) and enqueues ~500 launches per batch.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "bn254_vm.h"

@@ -5,7 +5,7 @@
 // live at once (~200 VGPRs).  Keeping f, the G2 point T, the current line and the caller's temporaries in registers ACROSS
 // operations is what made the first version spill 4-5 KB per lane (profiles/r01_ubench_tower_karatsuba.txt).  Here every
 // operation loads its operands, has the whole 256-VGPR budget of a 2-waves-per-SIMD kernel to itself, and stores its result:
-// ~400 KB of workspace traffic per proof (DESIGN.md "Workspace traffic"), all of it 12-byte-per-lane coalesced rows.
+// ~0.6 MB of workspace traffic per proof, all of it 4-byte-per-lane coalesced rows.
 //
 // Everything is templated on the workspace accessor W (ld/st of an Fp by element index): the kernels instantiate it with buffer
 // loads (bn254_kernels.hip: SGPR row offset + one VGPR lane offset), tests/hostsim with plain arrays, so the exact operation
