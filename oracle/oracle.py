@@ -154,6 +154,15 @@ def plonk_stage_digests(proof, vk, inputs):
     return st, {"gamma": r[0:32], "beta": r[32:64], "alpha": r[64:96], "zeta": r[96:128], "h2f": r[128:176]}
 
 
+def plonk_pairing_inputs(proof, vk, inputs):
+    """(status, [P0, P1], [Q0, Q1]): the operands of the final KZG pairing check of a PlonK proof (plonk/kzg.rs:175-187)."""
+    ib = b"".join(be32(i) for i in inputs)
+    o = _buf(384)
+    st = lib().orc_plonk_pairing_inputs(proof, C.c_size_t(len(proof)), vk, C.c_size_t(len(vk)), ib, C.c_size_t(len(inputs)), o)
+    r = _b(o)
+    return st, [r[0:64], r[64:128]], [r[128:256], r[256:384]]
+
+
 def set_threads(n):
     lib().orc_set_threads(int(n))
 

@@ -373,6 +373,7 @@ static void g1_msm(g1a* o, const g1a* pts, const fr* sc, int n) {
   g1_to_affine(o, &acc);
 }
 
+static __thread uint8_t* plonk_pair_out = NULL;  /* when set: the operands of the final pairing check (2 x 64 B G1, 2 x 128 B G2) */
 static int plonk_core(const uint8_t* proof_b, size_t proof_len, const uint8_t* vk_b, size_t vk_len, const uint8_t* inputs,
                       size_t n_inputs, const uint8_t* lambda32, uint8_t* stage_out) {
   orc_init();
@@ -529,12 +530,24 @@ static int plonk_core(const uint8_t* proof_b, size_t proof_len, const uint8_t* v
   g1_to_affine(&ps[0], &j3);
   g1_neg_affine(&ps[1], &folded_quot); if (folded_quot.inf) ps[1] = folded_quot;
   qs[0] = vk.kzg_g2[0]; qs[1] = vk.kzg_g2[1];
+  if (plonk_pair_out && !ps[0].inf && !ps[1].inf) {
+    enc_g1_uncompressed(plonk_pair_out, &ps[0]); enc_g1_uncompressed(plonk_pair_out + 64, &ps[1]);
+    enc_g2_uncompressed(plonk_pair_out + 128, &qs[0]); enc_g2_uncompressed(plonk_pair_out + 256, &qs[1]);
+  }
   fp12 e; pairing_batch(&e, ps, qs, 2);
   if (!fp12_is_one(&e)) return ORC_ERR_PAIRING_FAILED;
   return ORC_ACCEPT;
 }
 int orc_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* inputs, size_t n_inputs, const uint8_t* lambda32) {
   return plonk_core(proof, proof_len, vk, vk_len, inputs, n_inputs, lambda32, NULL);
+}
+/* the (G1, G2) operands of the KZG pairing check (plonk/kzg.rs:175-187) for a proof: tests push them through the device pairing */
+int orc_plonk_pairing_inputs(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* inputs, size_t n_inputs, uint8_t* out384) {
+  memset(out384, 0, 384);
+  plonk_pair_out = out384;
+  int st = plonk_core(proof, proof_len, vk, vk_len, inputs, n_inputs, NULL, NULL);
+  plonk_pair_out = NULL;
+  return st;
 }
 int orc_plonk_stage_digests(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* inputs, size_t n_inputs, uint8_t* out176) {
   memset(out176, 0, 176);

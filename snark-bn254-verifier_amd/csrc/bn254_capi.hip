@@ -27,6 +27,7 @@ struct DevState {
   int32_t *k0 = nullptr, *gtab = nullptr, *dtab = nullptr, *target = nullptr, *msm = nullptr;
   uint8_t* step_kinds = nullptr;
   int32_t* ws = nullptr; size_t ws_cap = 0;                         // proofs the workspace can hold
+  int32_t* msm_part = nullptr; size_t msm_part_cap = 0;             // wide keys: partial sums of the public-input MSM (proofs it holds)
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
   size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
   hipEvent_t ev[5]; bool ev_ready = false; bool ev_recorded = false;
@@ -131,7 +132,7 @@ void bn254_groth16_vk_free(bn254_g16_pvk* pvk) {
   for (auto& kv : pvk->dev) {
     DevState& d = kv.second;
     if (hipSetDevice(kv.first) != hipSuccess) continue;
-    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, (int32_t*)d.step_kinds};
+    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, d.msm_part, (int32_t*)d.step_kinds};
     for (auto q : ptrs) if (q) (void)hipFree(q);
     uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
     for (auto q : bp) if (q) (void)hipFree(q);
@@ -162,9 +163,23 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
   for (size_t off = 0; off < n; off += G16_MAX_BATCH) {
     size_t m = n - off < (size_t)G16_MAX_BATCH ? n - off : (size_t)G16_MAX_BATCH;
     // sub-batches on concurrent streams: the tail of one sub-batch's kernel overlaps the head of the other's
-    int parts = (n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
-    while ((m + parts - 1) / parts > (size_t)G16_MAX_LAUNCH) parts++;      // 32-bit workspace offsets per launch
-    const bool concurrent = n_streams > 1 && parts > 1;
+    // keys with many public inputs (config 5): the MSM runs as (proof, chunk) lanes through a partial-sum buffer that is shared
+    // by the launches of a batch, so they stay on the caller's stream and cover at most G16_WIDE_MSM_MAX_PROOFS proofs each
+    const bool wide = n_public + 1 == pvk->host.n_k && n_public > (size_t)G16_WIDE_MSM_MIN_INPUTS;
+    const size_t max_launch = wide ? (size_t)G16_WIDE_MSM_MAX_PROOFS : (size_t)G16_MAX_LAUNCH;
+    if (wide) {
+      size_t need = m < max_launch ? (m + 255) / 256 * 256 : max_launch;
+      if (need > d->msm_part_cap) {
+        if (d->msm_part) HIPCK(hipFree(d->msm_part));
+        d->msm_part = nullptr; d->msm_part_cap = 0;
+        size_t chunks = (n_public + G16_WIDE_MSM_INPUTS_PER_LANE - 1) / G16_WIDE_MSM_INPUTS_PER_LANE;
+        HIPCK(hipMalloc((void**)&d->msm_part, chunks * 27 * need * sizeof(int32_t)));
+        d->msm_part_cap = need;
+      }
+    }
+    int parts = (!wide && n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
+    while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
+    const bool concurrent = !wide && n_streams > 1 && parts > 1;
     if (concurrent && !d->aux_ready) {
       for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d->join_ev[i], hipEventDisableTiming)); }
       HIPCK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
@@ -183,6 +198,7 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
       a.ws = d->ws + lo * (size_t)(G16_WS_BYTES_PER_PROOF / 4); a.status = (uint8_t*)d_status + off + lo; a.msm_tab = d->msm; a.k0 = d->k0;
       a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
       a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
+      a.msm_part = wide ? d->msm_part : nullptr;
       // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
       const bool prof_this = g_profiling && d->ev_ready && pi == 0;
       if (prof_this) { d->prof.mask = g_prof_mask; d->prof.used = 0; d->prof_n = a.n; }

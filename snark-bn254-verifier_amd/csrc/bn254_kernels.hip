@@ -142,7 +142,7 @@ __device__ __forceinline__ bool words_lt_p(const uint32_t w[8]) { return !words_
 __global__ void __launch_bounds__(256, 2)
 k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs, int n_public, uint32_t n,
               int32_t* ws, uint8_t* __restrict__ status, const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0,
-              int inputs_match_key) {
+              int inputs_match_key, int wide_msm) {
   __shared__ uint32_t lds[4 * 64 * PREP_LDS_ROW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t first = blockIdx.x * 256u + (uint32_t)wave * 64u;
@@ -221,6 +221,11 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   w.st(VE_CX, C.x); w.st(VE_CY, C.y);
 
   // ---- L = K0 + sum_i x_i K_i, x_i taken as raw 256-bit integers (no range check, as bn::Fr::from_slice)
+  if (wide_msm) {
+    // many public inputs: L comes from k_g16_msm_partial / k_g16_msm_reduce (they also set the identity flag)
+    if (live) status[i] = err ? (uint8_t)err : (uint8_t)(BN254_ST_PENDING | err_c);
+    return;
+  }
   G1Aff K0; K0.x = uni_ld(k0); K0.y = uni_ld(k0 + BN_NL);
   G1Proj L = g1_from_affine(K0);
   if (inputs_match_key) {
@@ -263,6 +268,77 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   La.y = fp_select(l_inf, fp_one(), La.y);
   w.st(VE_LX, La.x); w.st(VE_LY, La.y);
   if (live) status[i] = err ? (uint8_t)err : (uint8_t)(BN254_ST_PENDING | (l_inf ? BN254_ST_LINF : 0) | err_c);
+}
+
+// =====================================================================================================================
+// public-input MSM for keys with many inputs (BASELINE config 5: 1024): the inputs of one proof are spread over `chunks` lanes
+// =====================================================================================================================
+// table entry -> affine point (80-byte entry, 16-byte aligned: five 16-byte loads)
+__device__ __forceinline__ G1Aff msm_entry(const int32_t* __restrict__ msm_tab, size_t idx) {
+  const int4* e = (const int4*)(msm_tab + idx * MSM_ENTRY_DWORDS);
+  int4 v0 = e[0], v1 = e[1], v2 = e[2], v3 = e[3], v4 = e[4];
+  G1Aff q;
+  q.x.v[0] = v0.x; q.x.v[1] = v0.y; q.x.v[2] = v0.z; q.x.v[3] = v0.w; q.x.v[4] = v1.x; q.x.v[5] = v1.y; q.x.v[6] = v1.z; q.x.v[7] = v1.w;
+  q.x.v[8] = v2.x; q.y.v[0] = v2.y; q.y.v[1] = v2.z; q.y.v[2] = v2.w; q.y.v[3] = v3.x; q.y.v[4] = v3.y; q.y.v[5] = v3.z; q.y.v[6] = v3.w;
+  q.y.v[7] = v4.x; q.y.v[8] = v4.y;
+  BN_SETB(q.x, 1.0, 0.5); BN_SETB(q.y, 1.0, 0.5);
+  return q;
+}
+// lane g = c * n + i: chunk c of proof i sums inputs [c * per, min((c+1) * per, n_public)); partial sums (projective, 27 dwords)
+// go to part[(c * 27 + k) * n + i]: every access of a wave is contiguous over proofs.
+__global__ void __launch_bounds__(256, 2)
+k_g16_msm_partial(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, int per, int chunks, const uint8_t* __restrict__ status,
+                  const int32_t* __restrict__ msm_tab, int32_t* __restrict__ part) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n * (uint32_t)chunks) return;
+  const uint32_t c = g / n, i = g - c * n;
+  G1Proj acc = g1_identity();
+  if (status[i] & BN254_ST_PENDING) {
+    const int s_end = (int)min((uint32_t)n_public, (c + 1) * (uint32_t)per);
+    for (int s = (int)(c * per); s < s_end; s++) {
+      const uint8_t* sp = inputs + ((size_t)i * (size_t)n_public + s) * 32;
+      uint32_t sw[8];
+      if ((((uintptr_t)inputs) & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sw[k] = ((const uint32_t*)sp)[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sw[k] = (uint32_t)sp[4 * k] | (uint32_t)sp[4 * k + 1] << 8 | (uint32_t)sp[4 * k + 2] << 16 | (uint32_t)sp[4 * k + 3] << 24;
+      }
+      for (int j = 0; j < 32; j++) {  // byte j of the big-endian scalar = window 31 - j (as in k_g16_prepare)
+        const int wi = 31 - j;
+        uint32_t dig = sw[0] & 0xff;
+#pragma unroll
+        for (int k = 0; k < 7; k++) sw[k] = (sw[k] >> 8) | (sw[k + 1] << 24);
+        sw[7] >>= 8;
+        if (dig != 0) acc = g1_add_mixed(acc, msm_entry(msm_tab, (size_t)(s * 32 + wi) * 255 + (dig - 1)));
+      }
+    }
+  }
+  int32_t* o = part + (size_t)c * 27 * n + i;
+#pragma unroll
+  for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
+}
+// L = K0 + sum of the chunk sums (complete projective additions), to affine, identity flag into the status byte
+__global__ void __launch_bounds__(256, 2)
+k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32_t* ws, uint8_t* __restrict__ status, const int32_t* __restrict__ k0) {
+  VM_KERNEL_PROLOGUE();
+  const uint32_t ii = i < n ? i : n - 1;
+  G1Aff K0; K0.x = uni_ld(k0); K0.y = uni_ld(k0 + BN_NL);
+  G1Proj L = g1_from_affine(K0);
+  for (int c = 0; c < chunks; c++) {
+    const int32_t* o = part + (size_t)c * 27 * n + ii;
+    G1Proj q;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { q.x.v[l] = o[(size_t)l * n]; q.y.v[l] = o[(size_t)(9 + l) * n]; q.z.v[l] = o[(size_t)(18 + l) * n]; }
+    BN_SETB(q.x, 3.0, 0.5); BN_SETB(q.y, 3.0, 0.5); BN_SETB(q.z, 3.0, 0.5);
+    L = g1_add(L, q);
+  }
+  bool l_inf = g1_is_identity(L);
+  G1Aff La = g1_to_affine(L);
+  La.y = fp_select(l_inf, fp_one(), La.y);
+  w.st(VE_LX, La.x); w.st(VE_LY, La.y);
+  if (i < n && (st & BN254_ST_PENDING) && l_inf) status[i] = st | BN254_ST_LINF;
 }
 
 // =====================================================================================================================
@@ -348,7 +424,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_g2_dbl", "k_g2_add", "k_f12_mul_line_var", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -391,7 +467,15 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   unsigned grid = grid_for(a.n);
   uint32_t n = (uint32_t)a.n;
   if (ev) (void)hipEventRecord(ev[0], s);
-  BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key);
+  const bool wide = a.msm_part != nullptr && a.inputs_match_key && a.n_public > G16_WIDE_MSM_MIN_INPUTS;
+  BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, wide ? 1 : 0);
+  if (wide) {
+    // inputs of one proof spread over `chunks` lanes, proofs in slices that fit the partial-sum buffer
+    const int per = G16_WIDE_MSM_INPUTS_PER_LANE, chunks = (a.n_public + per - 1) / per;
+    unsigned pg = (unsigned)(((size_t)n * chunks + 255) / 256);
+    { ProfScope ps_(prof, KID_MSM_PARTIAL, s); hipLaunchKernelGGL(k_g16_msm_partial, dim3(pg), dim3(256), 0, s, a.inputs, a.n_public, n, per, chunks, (const uint8_t*)a.status, a.msm_tab, a.msm_part); }
+    BN_LAUNCH(KID_MSM_REDUCE, k_g16_msm_reduce, (const int32_t*)a.msm_part, chunks, n, a.ws, a.status, a.k0);
+  }
   if (ev) (void)hipEventRecord(ev[1], s);
   LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab}, prof};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);

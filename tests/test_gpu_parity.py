@@ -94,6 +94,36 @@ def _twist_point(O, rng):
             return be(x[1]) + be(x[0]) + be(y[1]) + be(y[0])
 
 
+def test_device_pairing_on_reference_plonk_fixtures(L, O, fixtures):
+    """The reference's own end-to-end fixtures through the device pairing: for each of the 4 PlonK proofs of
+    examples/binaries/ the oracle derives the two (G1, G2) operands of the final KZG check (plonk/kzg.rs:175-187); the device
+    computes e(P0, Q0) and e(P1, Q1) (Miller program + final exponentiation of the product path) and their product must be 1.
+    A tampered public input must not give 1."""
+    fx, vk = fixtures
+    one = be(1) + bytes(352)
+    good = 0
+    for name, f in fx.items():
+        if f["variant"] != "plonk":
+            continue
+        proof = bytes.fromhex(f["raw_proof"])
+        pis = [int(x) for x in f["public_inputs"]]
+        for tamper in (0, 1):
+            st, ps, qs = O.plonk_pairing_inputs(proof, vk, [pis[0], pis[1] + tamper])
+            if tamper and st not in (O.ACCEPT, O.ERR_PAIRING_FAILED):
+                continue  # rejected before the pairing (opening mismatch): nothing to feed the device
+            out = (C.c_uint8 * (384 * 2))()
+            _chk(L, L.bn254_dbg_pairing(ps[0] + ps[1], qs[0] + qs[1], out, C.c_size_t(2), 0))
+            out = bytes(out)
+            assert out[:384] == O.pairing(ps[0], qs[0]) and out[384:] == O.pairing(ps[1], qs[1]), name
+            prod = O.fp12_op(0, out[:384], out[384:])
+            if tamper:
+                assert prod != one, name
+            else:
+                assert st == O.ACCEPT and prod == one, name
+                good += 1
+    assert good == 4
+
+
 def test_device_g2_subgroup(L, O):
     rng = random.Random(8)
     g2 = O.g2_gen()
@@ -147,6 +177,30 @@ def test_verify_batch_vs_oracle_all_classes(pkg, O, workload, L):
         assert st == exp
         m = 96  # oracle (reference-faithful CPU path) on a prefix that contains every class
         assert O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:64 * m], 2, m, omode) == st[:m]
+        pvk.close()
+
+
+@pytest.mark.parametrize("n_public", [17, 40, 1024])
+def test_many_public_inputs_vs_oracle(pkg, O, n_public):
+    """Keys with many public inputs (BASELINE configs[4]: 1024) take the wide MSM path: the inputs of one proof are summed by
+    n_public/16 lanes and reduced.  Every status class, both key readings, the oracle on a prefix, and a wrong input count."""
+    n = 80 if n_public == 1024 else 200
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540005 + n_public, n_public, n, invalid_every=4, agree=True, threads=8)
+    assert len(vk) == 292 + 32 * (n_public + 1) + 4 + 128 and set(exp) == {0, 1, 2, 3, 4}
+    for mode, omode in ((pkg.VK_REFERENCE, O.MODE_REFERENCE), (pkg.VK_GNARK, O.MODE_GNARK)):
+        pvk = pkg.PreparedVk(vk, mode)
+        assert pvk.n_public == n_public
+        st = pvk.verify_batch(proofs, inputs)
+        assert st == exp
+        m = 12 if n_public == 1024 else 24
+        assert O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:32 * n_public * m], n_public, m, omode) == st[:m]
+        if mode == pkg.VK_REFERENCE:
+            # one input too few: PrepareInputsFailed after every loader error (groth16/verify.rs:54-56)
+            short = b"".join(inputs[32 * n_public * i:32 * n_public * i + 32 * (n_public - 1)] for i in range(n))
+            st2 = pvk.verify_batch(proofs, short, n_public=n_public - 1)
+            assert all(b == (a if a in (2, 3, 4) else pkg.ERR_INPUT_LEN) for a, b in zip(exp, st2))
+            ref2 = O.groth16_verify_many(proofs[:256 * 8], 256, vk, short[:32 * (n_public - 1) * 8], n_public - 1, 8, omode)
+            assert st2[:8] == ref2
         pvk.close()
 
 

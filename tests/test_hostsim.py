@@ -183,3 +183,31 @@ def test_pairing_matches_oracle_bytes(hostsim, O):
     assert hs.hs_miller(o, pa, qb, 2, pf, qf) == 1
     hs.hs_final_exp(o, bytes(o))
     assert bytes(o) == O.pairing(pa + pf, qb + qf)
+
+
+def test_reference_plonk_fixtures_through_product_arithmetic(hostsim, O, fixtures):
+    """The reference's 4 PlonK fixtures pin the PRODUCT's arithmetic headers (compiled for the host): the operands of each
+    proof's final KZG pairing check (derived by the oracle, plonk/kzg.rs:175-187) go through the VM Miller program and final
+    exponentiation (hs_vm_pairing3 with the two key-side G2 points as the fixed pairs), and the result must be exactly 1."""
+    hs = hostsim
+    fx, vk = fixtures
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    one = (1).to_bytes(32, "big") + bytes(352)
+    n = 0
+    for name, f in fx.items():
+        if f["variant"] != "plonk":
+            continue
+        proof = bytes.fromhex(f["raw_proof"])
+        pis = [int(x) for x in f["public_inputs"]]
+        st, ps, qs = O.plonk_pairing_inputs(proof, vk, pis)
+        assert st == O.ACCEPT
+        o = (C.c_uint8 * 384)()
+        # e(g1, g2) * e(P0, Q0) * e(P1, Q1) with (g1, g2) as the variable pair: the fixed-line tables are built from Q0, Q1
+        assert hs.hs_vm_pairing3(o, g1, g2, ps[0], qs[0], ps[1], qs[1], 0) == 1
+        assert bytes(o) == O.pairing(g1, g2), name
+        # and directly: Miller loop of the two pairs as one variable + one fixed pair, then the final exponentiation
+        assert hs.hs_miller(o, ps[0], qs[0], 1, ps[1], qs[1]) == 1
+        hs.hs_final_exp(o, bytes(o))
+        assert bytes(o) == one, name
+        n += 1
+    assert n == 4
