@@ -93,6 +93,23 @@ int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
 
+/* ---- PlonK (gnark / SP1 format), BASELINE configs[3] --------------------------------------------------------------
+ * Replaces PlonkVerifier::verify (verifier/src/lib.rs:69-73) = load_plonk_proof_from_bytes (plonk/converter.rs:121-178) +
+ * load_plonk_verifying_key_from_bytes (plonk/converter.rs:18-119, hoisted into vk_prepare) + verify_plonk
+ * (plonk/verify.rs:46-317: Fiat-Shamir transcripts transcript.rs:15-108, BSB22 hash_to_field.rs:9-122, kzg::fold_proof and
+ * kzg::batch_verify_multi_points plonk/kzg.rs:87-190).  The transcripts and the scalar-field arithmetic run on host threads;
+ * every group operation (24 G1 scalar multiplications and the two-pair pairing check per proof) runs on the GPU.
+ * Status bytes: BN254_ACCEPT or an error code; PlonK never returns BN254_REJECT (plonk/verify.rs:316).  Each proof occupies
+ * proof_stride bytes (>= its length: 904 for the SP1 circuits); public inputs are n_public x 32 big-endian bytes per proof. */
+typedef struct bn254_plonk_pvk bn254_plonk_pvk;
+int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** out);
+void bn254_plonk_vk_free(bn254_plonk_pvk* pvk);
+size_t bn254_plonk_vk_num_public(const bn254_plonk_pvk* pvk);
+int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                             size_t n_public, size_t n, uint8_t* status, int device);
+int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
+                       size_t n_public, uint8_t* status);
+
 /* ---- measurement support ------------------------------------------------------------------------------------------
  * A batch runs as ~720 kernel launches: one per Fp12-level operation of the verification program (k_f12_sqr, k_f12_mul,
  * k_f12_mul_line_fixed, ...), each over the whole (sub-)batch.  When profiling is enabled, verify_batch_device records HIP

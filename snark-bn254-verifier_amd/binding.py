@@ -52,6 +52,12 @@ def lib():
         L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.bn254_synth_groth16.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.bn254_synth_groth16_vk_len.argtypes = [C.c_size_t]
+        L.bn254_plonk_vk_prepare.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.bn254_plonk_vk_free.argtypes = [C.c_void_p]
+        L.bn254_plonk_vk_num_public.argtypes = [C.c_void_p]
+        L.bn254_plonk_vk_num_public.restype = C.c_size_t
+        L.bn254_plonk_verify_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        L.bn254_plonk_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p]
         L.bn254_groth16_kernel_kind_name.restype = C.c_char_p
         L.bn254_groth16_kernel_kind_name.argtypes = [C.c_int]
         L.bn254_set_profile_kernels.argtypes = [C.c_uint]
@@ -78,6 +84,47 @@ def _check(rc):
 
 def _inputs_bytes(public_inputs):
     return b"".join(x if isinstance(x, (bytes, bytearray)) else int(x).to_bytes(32, "big") for x in public_inputs)
+
+
+class PreparedPlonkVk:
+    """Opaque prepared PlonK verifying key (bn254_plonk_vk_prepare)."""
+
+    def __init__(self, vk_bytes):
+        self._h = C.c_void_p()
+        _check(lib().bn254_plonk_vk_prepare(bytes(vk_bytes), len(vk_bytes), C.byref(self._h)))
+        self.n_public = lib().bn254_plonk_vk_num_public(self._h)
+
+    def verify_batch(self, proofs, public_inputs, n=None, proof_stride=904, n_public=None, device=0):
+        """proofs: n * proof_stride bytes; public_inputs: n * n_public * 32 bytes.  Returns n status bytes."""
+        n_public = self.n_public if n_public is None else n_public
+        if n is None:
+            n = len(proofs) // proof_stride
+        st = (C.c_uint8 * max(n, 1))()
+        _check(lib().bn254_plonk_verify_batch(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device))
+        return bytes(st)[:n]
+
+    def close(self):
+        if self._h:
+            lib().bn254_plonk_vk_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PlonkVerifier:
+    """Mirror of the reference's `PlonkVerifier::verify(proof, vk, public_inputs)` (verifier/src/lib.rs:69-73): returns the
+    status byte (ACCEPT or an error code; PlonK never answers REJECT)."""
+
+    @staticmethod
+    def verify(proof, vk, public_inputs):
+        st = C.c_uint8(0xEE)
+        ib = _inputs_bytes(public_inputs)
+        _check(lib().bn254_plonk_verify(bytes(proof), len(proof), bytes(vk), len(vk), ib, len(ib) // 32, C.byref(st)))
+        return st.value
 
 
 class PreparedVk:

@@ -9,6 +9,8 @@
 #include <vector>
 #include "../../include/bn254_verify.h"
 #include "bn254_host.hpp"
+#include "bn254_plonk.hpp"
+#include <thread>
 
 static_assert(BN254_REJECT == BN254_ST_REJECT && BN254_ACCEPT == BN254_ST_ACCEPT && BN254_ERR_NOT_MEMBER == BN254_ST_NOT_MEMBER &&
               BN254_ERR_NOT_ON_CURVE == BN254_ST_NOT_ON_CURVE && BN254_ERR_NOT_IN_SUBGROUP == BN254_ST_NOT_IN_SUBGROUP &&
@@ -92,6 +94,62 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
   *cap = need;
   return BN254_OK;
 }
+
+// ---------------------------------------------------------------- PlonK (BASELINE configs[3])
+struct PlonkDev {
+  bool ready = false;
+  int32_t *tab0 = nullptr, *tab1 = nullptr, *one = nullptr;
+  size_t cap = 0;                      // proofs the buffers below hold
+  int32_t *ws = nullptr, *part = nullptr;
+  MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
+};
+struct bn254_plonk_pvk {
+  PlonkKey key;
+  std::vector<int32_t> tab0, tab1, one;
+  mutable std::mutex mu;
+  mutable std::map<int, PlonkDev> dev;
+};
+#define PLONK_MAX_LAUNCH 65536
+static void plonk_dev_free(PlonkDev& d) {
+  void* ptrs[] = {d.tab0, d.tab1, d.one, d.ws, d.part, d.terms, d.flags, d.words, d.inf, d.status};
+  for (auto q : ptrs) if (q) (void)hipFree(q);
+  d = PlonkDev();
+}
+static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, size_t n, PlonkDev** out) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  PlonkDev& d = pvk->dev[device];
+  if (!d.ready) {
+    if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
+    d.ready = true;
+  }
+  size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
+  if (need > d.cap) {
+    void* ptrs[] = {d.ws, d.part, d.terms, d.flags, d.words, d.inf, d.status};
+    for (auto q : ptrs) if (q) (void)hipFree(q);
+    d.ws = d.part = nullptr; d.terms = nullptr; d.flags = nullptr; d.words = nullptr; d.inf = d.status = nullptr; d.cap = 0;
+    const size_t tmax = (size_t)plonk_stage2_terms(pvk->key) > (size_t)plonk_stage1_terms(pvk->key) ? plonk_stage2_terms(pvk->key) : plonk_stage1_terms(pvk->key);
+    HIPCK(hipMalloc((void**)&d.ws, need * (size_t)G16_WS_BYTES_PER_PROOF));
+    HIPCK(hipMalloc((void**)&d.part, need * tmax * 27 * sizeof(int32_t)));
+    HIPCK(hipMalloc((void**)&d.terms, need * tmax * sizeof(MsmTerm)));
+    HIPCK(hipMalloc((void**)&d.flags, need * tmax));
+    HIPCK(hipMalloc((void**)&d.words, need * 16 * sizeof(uint32_t)));
+    HIPCK(hipMalloc((void**)&d.inf, need));
+    HIPCK(hipMalloc((void**)&d.status, need));
+    d.cap = need;
+  }
+  *out = &d;
+  return BN254_OK;
+}
+template <class F> static void plonk_parallel(size_t n, F&& f) {
+  unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
+  if (n < 64) hw = 1;
+  if (hw == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < hw; t++) th.emplace_back([&, t]() { for (size_t i = t; i < n; i += hw) f(i); });
+  for (auto& x : th) x.join();
+}
+
 
 extern "C" {
 
@@ -284,6 +342,107 @@ int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* 
   if (rc) return rc;
   rc = bn254_groth16_verify_batch(pvk, proof, proof_len, public_inputs, n_public, 1, status, 0);
   bn254_groth16_vk_free(pvk);
+  return rc;
+}
+
+// ---------------------------------------------------------------- PlonK (BASELINE configs[3]): entry points
+int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** out) {
+  if (!vk || !out) return set_err(BN254_E_BAD_ARG, "bad argument");
+  *out = nullptr;
+  auto* p = new bn254_plonk_pvk();
+  if (parse_plonk_vk(p->key, vk, vk_len) != DEC_OK) { delete p; return set_err(BN254_E_VK, "PlonK verifying key does not parse"); }
+  // line tables of the two KZG G2 points (kzg.rs:175-187: e(P0, g2[0]) e(P1, g2[1]) == 1); target = 1 in GT
+  std::vector<FixedLine> t0(BN_ATE_STEPS), t1(BN_ATE_STEPS);
+  if (!fixed_line_table(t0.data(), p->key.kzg_g2[0]) || !fixed_line_table(t1.data(), p->key.kzg_g2[1])) { delete p; return set_err(BN254_E_VK, "degenerate KZG G2 point"); }
+  p->tab0.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS); p->tab1.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS);
+  for (int s = 0; s < BN_ATE_STEPS; s++) {
+    int32_t* a = p->tab0.data() + (size_t)s * FIXED_LINE_DWORDS; int32_t* b = p->tab1.data() + (size_t)s * FIXED_LINE_DWORDS;
+    put_fp2(a, t0[s].m); put_fp2(a + 2 * BN_NL, t0[s].c); put_fp2(a + 4 * BN_NL, t0[s].xc);
+    put_fp2(b, t1[s].m); put_fp2(b + 2 * BN_NL, t1[s].c); put_fp2(b + 4 * BN_NL, t1[s].xc);
+  }
+  p->one.resize(12 * BN_NL);
+  put_fp12(p->one.data(), fp12_one());
+  *out = p;
+  return BN254_OK;
+}
+void bn254_plonk_vk_free(bn254_plonk_pvk* pvk) {
+  if (!pvk) return;
+  for (auto& kv : pvk->dev) { if (hipSetDevice(kv.first) != hipSuccess) continue; plonk_dev_free(kv.second); }
+  delete pvk;
+}
+size_t bn254_plonk_vk_num_public(const bn254_plonk_pvk* pvk) { return pvk ? (size_t)pvk->key.nb_public : 0; }
+
+int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                             size_t n_public, size_t n, uint8_t* status, int device) {
+  if (!pvk || (n && (!proofs || !status)) || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (n == 0) return BN254_OK;
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  PlonkDev* d;
+  int rc = plonk_ensure_dev(pvk, device, n, &d);
+  if (rc) return rc;
+  const PlonkKey& key = pvk->key;
+  const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key);
+  const FrM lambda = fr_ctx().from_u64(0x9e3779b97f4a7c15ull);  // the reference draws it at random (kzg.rs:149-154); any value works
+  for (size_t off = 0; off < n; off += PLONK_MAX_LAUNCH) {
+    const size_t m = n - off < (size_t)PLONK_MAX_LAUNCH ? n - off : (size_t)PLONK_MAX_LAUNCH;
+    std::vector<PlonkWork> work(m);
+    std::vector<MsmTerm> terms(m * (size_t)(T1 > T2 ? T1 : T2));
+    std::vector<uint8_t> flags(m * (size_t)(T1 > T2 ? T1 : T2), 0), st(m), inf(m);
+    std::vector<uint32_t> words(m * 16);
+    memset(terms.data(), 0, terms.size() * sizeof(MsmTerm));
+    // ---- stage 1 on the host threads
+    plonk_parallel(m, [&](size_t i) {
+      work[i].lambda = lambda;
+      work[i].status = plonk_stage1(key, proofs + (off + i) * proof_stride, proof_stride, public_inputs + (off + i) * n_public * 32, n_public, work[i], &terms[i * T1]);
+    });
+    // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
+    HIPCK(hipMemcpy(d->terms, terms.data(), m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice));
+    HIPCK(hipMemset(d->flags, 0, m * (size_t)T1));
+    hipError_t e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, T1, d->part, d->words, d->inf, nullptr, nullptr, 0, 0, nullptr);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(words.data(), d->words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(inf.data(), d->inf, m, hipMemcpyDeviceToHost));
+    // ---- stage 2 on the host threads
+    std::vector<MsmTerm> t1(m * 2);
+    memset(t1.data(), 0, t1.size() * sizeof(MsmTerm));
+    memset(terms.data(), 0, terms.size() * sizeof(MsmTerm));
+    plonk_parallel(m, [&](size_t i) {
+      if (work[i].status == PL_OK) {
+        work[i].pr.raw = proofs + (off + i) * proof_stride;
+        plonk_stage2(key, proofs + (off + i) * proof_stride, work[i], &words[i * 16], inf[i] != 0, &terms[i * T2], &flags[i * T2], &t1[i * 2]);
+        st[i] = BN254_ST_PENDING;
+      } else {
+        st[i] = (uint8_t)work[i].status;
+      }
+    });
+    // ---- P0, P1 and the pairing check on the GPU
+    HIPCK(hipMemcpy(d->status, st.data(), m, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(d->terms, terms.data(), m * T2 * sizeof(MsmTerm), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(d->flags, flags.data(), m * (size_t)T2, hipMemcpyHostToDevice));
+    e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, T2, d->part, nullptr, nullptr, d->ws, d->status, VE_LX_ELEM, BN254_ST_LINF, nullptr);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+    HIPCK(hipDeviceSynchronize());   // d->terms is reused below
+    HIPCK(hipMemcpy(d->terms, t1.data(), m * 2 * sizeof(MsmTerm), hipMemcpyHostToDevice));
+    HIPCK(hipMemset(d->flags, 0, m * 2));
+    e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, 2, d->part, nullptr, nullptr, d->ws, d->status, VE_CX_ELEM, BN254_ST_LINF2, nullptr);
+    if (e == hipSuccess) e = bn254_launch_pairing2_fixed(d->ws, d->status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, nullptr);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(status + off, d->status, m, hipMemcpyDeviceToHost));
+  }
+  return BN254_OK;
+}
+
+int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
+                       size_t n_public, uint8_t* status) {
+  if (!proof || !vk || !status) return set_err(BN254_E_BAD_ARG, "bad argument");
+  bn254_plonk_pvk* pvk = nullptr;
+  int rc = bn254_plonk_vk_prepare(vk, vk_len, &pvk);
+  if (rc == BN254_E_VK) { *status = BN254_ERR_MALFORMED; return BN254_OK; }
+  if (rc) return rc;
+  rc = bn254_plonk_verify_batch(pvk, proof, proof_len, public_inputs, n_public, 1, status, 0);
+  bn254_plonk_vk_free(pvk);
   return rc;
 }
 

@@ -14,6 +14,7 @@
 #define BN254_ST_MALFORMED 6
 #define BN254_ST_PENDING 0x80  // internal: no error so far (low 6 bits: deferred error of point C)
 #define BN254_ST_LINF 0x40     // internal: the public-input point L is the identity
+#define BN254_ST_LINF2 0x20    // internal (PlonK pairing check): the G1 point of the second fixed pair is the identity
 
 #define MSM_ENTRY_DWORDS 20    // affine G1 point, 2 x 9 limbs + 2 pad: 80-byte entries, 16-byte aligned
 #define FIXED_LINE_DWORDS 54   // one precomputed Miller step of a fixed G2 argument: m, c, xi*c (3 Fp2)
@@ -22,6 +23,9 @@
 #define G16_MAX_BATCH 1048576  // proofs per chunk of a larger batch (one workspace)
 #define G16_MAX_LAUNCH 786432  // proofs per kernel launch: the workspace is addressed with 32-bit buffer offsets, 130 * 36 * n < 2^32
 
+// workspace elements the PlonK path writes its two G1 points to (bn254_vm.h: VE_LX, VE_CX)
+#define VE_LX_ELEM 8
+#define VE_CX_ELEM 6
 struct G16LaunchArgs {
   const uint8_t* proofs; size_t stride;
   const uint8_t* inputs; int n_public;
@@ -53,6 +57,10 @@ struct G16Prof {
   int cap, used;
 };
 hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev, G16Prof* prof);
+hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
+                               uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
+hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
+                                       int reject_code, hipStream_t s);
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

@@ -96,10 +96,10 @@ __global__ void __launch_bounds__(256, 2) k_f12_sqr(int32_t* ws, uint32_t n, con
 __global__ void __launch_bounds__(256, 2) k_f12_mul_line_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, int e_line, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_f12_mul_line_var(w, e, e_line, e_px);
 }
-__global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, const int32_t* __restrict__ entry, int e_px, int use_inf) {
+__global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, const int32_t* __restrict__ entry, int e_px, int inf_mask) {
   VM_KERNEL_PROLOGUE();
   FixedLine l; l.m = uni_ld2(entry); l.c = uni_ld2(entry + 2 * BN_NL); l.xc = uni_ld2(entry + 4 * BN_NL);
-  vm_f12_mul_line_fixed(w, e, l, e_px, use_inf && (st & BN254_ST_LINF));
+  vm_f12_mul_line_fixed(w, e, l, e_px, (st & inf_mask) != 0);  // inf_mask: the status bit that marks this pair's G1 point as the identity
 }
 __global__ void __launch_bounds__(256, 2) k_g2_dbl(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line) { VM_KERNEL_PROLOGUE(); vm_g2_dbl(w, e_t, e_line); }
 __global__ void __launch_bounds__(256, 2) k_g2_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line, int e_b, int which) {
@@ -122,10 +122,10 @@ __global__ void __launch_bounds__(256, 2) k_f12_cyclo_sqr_n(int32_t* ws, uint32_
 __global__ void __launch_bounds__(256, 2) k_f12_conj(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_conj(w, d, a); }
 __global__ void __launch_bounds__(256, 2) k_f12_frob(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int j) { VM_KERNEL_PROLOGUE(); vm_f12_frob(w, d, a, j); }
 __global__ void __launch_bounds__(256, 2) k_f12_inv(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_inv(w, d, a); }
-__global__ void __launch_bounds__(256, 2) k_g16_compare(int32_t* ws, uint32_t n, uint8_t* __restrict__ status, const int32_t* __restrict__ target) {
+__global__ void __launch_bounds__(256, 2) k_g16_compare(int32_t* ws, uint32_t n, uint8_t* __restrict__ status, const int32_t* __restrict__ target, int reject_code) {
   VM_KERNEL_PROLOGUE();
   bool acc = vm_f12_eq_const(w, VE_S0, target);
-  if (i < n && (st & BN254_ST_PENDING)) status[i] = acc ? BN254_ST_ACCEPT : BN254_ST_REJECT;
+  if (i < n && (st & BN254_ST_PENDING)) status[i] = acc ? BN254_ST_ACCEPT : (uint8_t)reject_code;
 }
 
 // big-endian 32-byte field (8 dwords as loaded little-endian from memory) -> little-endian words
@@ -342,6 +342,78 @@ k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32
 }
 
 // =====================================================================================================================
+// variable-base G1 multi-scalar multiplication (PlonK: linearised-polynomial digest, folded digests and quotients)
+// =====================================================================================================================
+// lane g = t * n + i: term t of item i.  terms[g * 26]: 18 digits of the affine point, 8 little-endian words of the scalar
+// (canonical, < r).  Double-and-always-add with the complete formulas: data-independent control, no special cases.
+// flags[g] != 0: the point is the identity (the term contributes nothing).  Partial results: part[(t * 27 + k) * n + i].
+__global__ void __launch_bounds__(256, 2)
+k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n * (uint32_t)n_terms) return;
+  const uint32_t t = g / n, i = g - t * n;
+  const int32_t* e = terms + ((size_t)i * n_terms + t) * 26;
+  G1Aff P;
+#pragma unroll
+  for (int l = 0; l < BN_NL; l++) { P.x.v[l] = e[l]; P.y.v[l] = e[BN_NL + l]; }
+  BN_SETB(P.x, 1.0, 0.5); BN_SETB(P.y, 1.0, 0.5);
+  uint32_t sw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) sw[k] = (uint32_t)e[18 + k];
+  if (flags[(size_t)i * n_terms + t]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) sw[k] = 0;
+  }
+  G1Proj acc = g1_identity();
+  for (int b = 0; b < 256; b++) {  // most significant bit first; the 256-bit array is shifted up by one each time
+    const bool bit = (sw[7] >> 31) != 0;
+#pragma unroll
+    for (int k = 7; k > 0; k--) sw[k] = (sw[k] << 1) | (sw[k - 1] >> 31);
+    sw[0] <<= 1;
+    acc = g1_dbl(acc);
+    G1Proj c = g1_add_mixed(acc, P);
+    acc.x = fp_select(bit, c.x, acc.x); acc.y = fp_select(bit, c.y, acc.y); acc.z = fp_select(bit, c.z, acc.z);
+  }
+  int32_t* o = part + (size_t)t * 27 * n + i;
+#pragma unroll
+  for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
+}
+// per item: the sum of its n_terms partial results, to affine.  out_words != nullptr: 16 little-endian words (x | y, canonical) and a
+// flag byte (1 = identity) per item, for the host.  Otherwise the point goes to workspace elements (e_x, e_x + 1) as (x, y) or
+// (0, 1) for the identity, whose flag bit `inf_bit` is OR-ed into the (pending) status byte.
+__global__ void __launch_bounds__(256, 2)
+k_g1_sum_affine(const int32_t* __restrict__ part, int n_terms, uint32_t n, uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf,
+                int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t ii = i < n ? i : n - 1;
+  G1Proj L = g1_identity();
+  for (int c = 0; c < n_terms; c++) {
+    const int32_t* o = part + (size_t)c * 27 * n + ii;
+    G1Proj q;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { q.x.v[l] = o[(size_t)l * n]; q.y.v[l] = o[(size_t)(9 + l) * n]; q.z.v[l] = o[(size_t)(18 + l) * n]; }
+    BN_SETB(q.x, 3.0, 0.5); BN_SETB(q.y, 3.0, 0.5); BN_SETB(q.z, 3.0, 0.5);
+    L = g1_add(L, q);
+  }
+  bool l_inf = g1_is_identity(L);
+  G1Aff La = g1_to_affine(L);
+  if (out_words) {
+    if (i < n) {
+      uint32_t wx[8], wy[8];
+      fp_to_words(wx, La.x); fp_to_words(wy, La.y);
+#pragma unroll
+      for (int k = 0; k < 8; k++) { out_words[(size_t)i * 16 + k] = wx[k]; out_words[(size_t)i * 16 + 8 + k] = wy[k]; }
+      out_inf[i] = l_inf ? 1 : 0;
+    }
+  } else {
+    DevWs w(ws, n, i < n ? i : DEAD_LANE);
+    La.y = fp_select(l_inf, fp_one(), La.y);
+    w.st(e_x, La.x); w.st(e_x + 1, La.y);
+    if (i < n && l_inf) { uint8_t st = status[i]; if (st & BN254_ST_PENDING) status[i] = st | (uint8_t)inf_bit; }
+  }
+}
+
+// =====================================================================================================================
 // k_g16_subgroup
 // =====================================================================================================================
 __global__ void __launch_bounds__(256, 2)
@@ -438,6 +510,7 @@ struct LaunchOps {
   int32_t* ws; uint32_t n; const uint8_t* status; unsigned grid; hipStream_t s;
   const int32_t* tab[2];
   G16Prof* prof;
+  int inf_mask[2] = {BN254_ST_LINF, 0};   // status bits marking the G1 point of fixed pair 0 / 1 as the identity
   int uni(int x) { return x; }
   void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
   void g2_dbl(int et, int el) { BN_LAUNCH(KID_G2_DBL, k_g2_dbl, ws, n, status, et, el); }
@@ -446,7 +519,7 @@ struct LaunchOps {
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
   void f12_mul_line_var(int e, int el, int ep) { BN_LAUNCH(KID_MUL_LINE_VAR, k_f12_mul_line_var, ws, n, status, e, el, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
-    BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, t == 0 ? 1 : 0);
+    BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, inf_mask[t]);
   }
   void f12_mul(int d, int a, int b, bool conj_b = false) { BN_LAUNCH(KID_F12_MUL, k_f12_mul, ws, n, status, d, a, b, conj_b ? 1 : 0); }
   void f12_copy(int d, int a) { BN_LAUNCH(KID_F12_COPY, k_f12_copy, ws, n, status, d, a); }
@@ -485,7 +558,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
   if (ev) (void)hipEventRecord(ev[3], s);
   vm_final_exp_program(ops);
-  BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, a.status, a.target);
+  BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, a.status, a.target, BN254_ST_REJECT);
   if (ev) (void)hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
@@ -535,5 +608,33 @@ hipError_t bn254_launch_dbg_g2_ate(const uint8_t* g1, const uint8_t* g2, uint8_t
 }
 hipError_t bn254_launch_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_dbg_g2_subgroup, dim3(grid_for(n)), dim3(256), 0, s, g2, o, n);
+  return hipGetLastError();
+}
+
+// ---- PlonK: G1 MSM stages and the two-fixed-pair pairing check -----------------------------------------------------------------------
+hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
+                               uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
+  unsigned g1 = (unsigned)((n * (size_t)n_terms + 255) / 256);
+  hipLaunchKernelGGL(k_g1_scalar_mul, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, n_terms, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
+  return hipGetLastError();
+}
+// prod_t e(P_t, Q_t) == 1 for two key-side G2 points (line tables tab0, tab1) and per-item G1 points already in the workspace
+// (P_0 at VE_LX, P_1 at VE_CX; identity flags BN254_ST_LINF / BN254_ST_LINF2 in the status byte): ACCEPT or reject_code
+hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
+                                       int reject_code, hipStream_t s) {
+  unsigned grid = grid_for(n);
+  uint32_t nn = (uint32_t)n;
+  G16Prof* prof = nullptr;
+  LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1}, nullptr};
+  ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
+  BN_LAUNCH(KID_VM_INIT, k_vm_init, ws, nn, (const uint8_t*)status);
+  for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+    if (step_kinds_host()[st_] == 0 && st_ != 0) ops.f12_sqr(VE_F);
+    ops.f12_mul_line_fixed(VE_F, 0, st_, VE_LX);
+    ops.f12_mul_line_fixed(VE_F, 1, st_, VE_CX);
+  }
+  vm_final_exp_program(ops);
+  BN_LAUNCH(KID_COMPARE, k_g16_compare, ws, nn, status, target_one, reject_code);
   return hipGetLastError();
 }

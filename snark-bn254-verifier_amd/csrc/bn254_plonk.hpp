@@ -1,0 +1,402 @@
+// bn254_plonk.hpp -- host side of the PlonK batch verifier (BASELINE configs[3]; reference verifier/src/plonk/{verify,kzg,
+// converter,proof}.rs, transcript.rs, hash_to_field.rs).
+//
+// Split of the work per proof:
+//   host   parsing, the Fiat-Shamir transcripts (5 SHA-256 chains of ~1 KB), BSB22 hash-to-field, the Fr arithmetic of the
+//          linearisation (3 pow, 4 inversions, ~100 products): control-heavy, a few hundred microseconds in total per proof
+//   GPU    every group operation: the 11-term G1 MSM of the linearised polynomial digest, the folding MSMs of the KZG batch
+//          opening (13 more scalar multiplications) and the two-pair pairing check (bn254_kernels.hip)
+// The second transcript hashes the first MSM's result, so a batch makes one round trip: stage1 (host) -> MSM -> stage2 (host)
+// -> MSMs + pairing.  Nothing here is shared with oracle/: this is product code.
+#pragma once
+#include <cstring>
+#include <string>
+#include <vector>
+#include "bn254_host.hpp"
+
+namespace bn254host {
+
+// ---------------------------------------------------------------- SHA-256 (FIPS 180-4), transcript.rs / hash_to_field.rs use sha2
+struct Sha256 {
+  uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill;
+  Sha256() { reset(); }
+  void reset() {
+    static const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    memcpy(h, iv, sizeof h); len = 0; fill = 0;
+  }
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+      0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+      0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+      0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+      0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+      0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const void* data, size_t n) {
+    const uint8_t* p = (const uint8_t*)data; len += n;
+    while (n) {
+      size_t k = 64 - fill < n ? 64 - fill : n;
+      memcpy(buf + fill, p, k); fill += k; p += k; n -= k;
+      if (fill == 64) { block(buf); fill = 0; }
+    }
+  }
+  void finish(uint8_t out[32]) {
+    uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1); uint8_t z = 0;
+    while (fill != 56) update(&z, 1);
+    uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+  }
+};
+
+// ---------------------------------------------------------------- Fr in Montgomery form (4 x 64), host only
+struct FrM { uint64_t l[4]; };
+struct FrCtx {
+  uint64_t m[4], inv; FrM one, r2;
+  FrCtx() {
+    for (int i = 0; i < 4; i++) m[i] = (uint64_t)BN_R_WORDS[2 * i] | ((uint64_t)BN_R_WORDS[2 * i + 1] << 32);
+    uint64_t x = 1; for (int i = 0; i < 6; i++) x *= 2 - m[0] * x;   // m[0]^-1 mod 2^64 (Newton)
+    inv = ~x + 1;                                                    // -m^-1
+    FrM t = {{1, 0, 0, 0}};
+    for (int i = 0; i < 256; i++) t = dbl_mod(t);
+    one = t;                                                         // 2^256 mod r
+    for (int i = 0; i < 256; i++) t = dbl_mod(t);
+    r2 = t;                                                          // 2^512 mod r
+  }
+  bool geq_m(const FrM& a) const { for (int i = 3; i >= 0; i--) { if (a.l[i] > m[i]) return true; if (a.l[i] < m[i]) return false; } return true; }
+  FrM sub_m(const FrM& a) const { FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)a.l[i] - m[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r; }
+  FrM dbl_mod(const FrM& a) const {
+    FrM r; uint64_t c = 0;
+    for (int i = 0; i < 4; i++) { uint64_t v = a.l[i]; r.l[i] = (v << 1) | c; c = v >> 63; }
+    if (c || geq_m(r)) r = sub_m(r);
+    return r;
+  }
+  FrM add(const FrM& a, const FrM& b) const {
+    FrM r; unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (unsigned __int128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    if (c || geq_m(r)) r = sub_m(r);
+    return r;
+  }
+  FrM neg(const FrM& a) const {
+    if (!(a.l[0] | a.l[1] | a.l[2] | a.l[3])) return a;
+    FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)m[i] - a.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r;
+  }
+  FrM sub(const FrM& a, const FrM& b) const { return add(a, neg(b)); }
+  FrM mul(const FrM& a, const FrM& b) const {  // CIOS Montgomery product
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; j++) { c += (unsigned __int128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+      c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+      uint64_t q = t[0] * inv;
+      c = (unsigned __int128)q * m[0] + t[0]; c >>= 64;
+      for (int j = 1; j < 4; j++) { c += (unsigned __int128)q * m[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+      c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    FrM r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_m(r)) r = sub_m(r);
+    return r;
+  }
+  FrM from_u64(uint64_t v) const { FrM t = {{v, 0, 0, 0}}; return mul(t, r2); }
+  FrM from_canon(const FrM& a) const { return mul(a, r2); }          // a < r
+  FrM to_canon(const FrM& a) const { FrM o = {{1, 0, 0, 0}}; return mul(a, o); }
+  bool is_zero(const FrM& a) const { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
+  bool eq(const FrM& a, const FrM& b) const { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+  FrM pow_u64(const FrM& a, uint64_t e) const {
+    FrM r = one, b = a;
+    while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; }
+    return r;
+  }
+  FrM inverse(const FrM& a) const {  // a^(r-2); 0 -> 0
+    uint64_t e[4] = {m[0] - 2, m[1], m[2], m[3]};
+    FrM r = one;
+    for (int i = 255; i >= 0; i--) { r = mul(r, r); if ((e[i / 64] >> (i % 64)) & 1) r = mul(r, a); }
+    return r;
+  }
+  // big-endian bytes of any length, reduced mod r (Fr::from_slice stores the raw value and every later operation is mod r; the
+  // challenges and hash_to_field reduce explicitly): Horner over the bytes
+  FrM from_be_reduce(const uint8_t* b, size_t n) const {
+    FrM acc = {{0, 0, 0, 0}}, c256 = from_u64(256);
+    for (size_t i = 0; i < n; i++) acc = add(mul(acc, c256), from_u64(b[i]));
+    return acc;
+  }
+  void to_be(uint8_t out[32], const FrM& a) const {
+    FrM c = to_canon(a);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[(3 - i) * 8 + j] = (uint8_t)(c.l[i] >> (56 - 8 * j));
+  }
+  void to_words(uint32_t w[8], const FrM& a) const { FrM c = to_canon(a); for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)c.l[i]; w[2 * i + 1] = (uint32_t)(c.l[i] >> 32); } }
+};
+inline const FrCtx& fr_ctx() { static const FrCtx c; return c; }
+
+// ---------------------------------------------------------------- key and proof (plonk/converter.rs:18-178, proof.rs)
+enum { PLONK_MAX_QCP = 8, PLONK_MAX_CLAIMED = 16 };
+struct PlonkKey {
+  uint64_t size, nb_public; FrM size_inv, generator, coset_shift;
+  G1Aff s[3], ql, qr, qm, qo, qk, qcp[PLONK_MAX_QCP]; uint32_t n_qcp;
+  G1Aff kzg_g1; G2Aff kzg_g2[2];
+  uint64_t cci[PLONK_MAX_QCP]; uint64_t n_cci;
+  uint8_t enc[8 + PLONK_MAX_QCP][64];  // uncompressed encodings of s1..3, ql, qr, qm, qo, qk, qcp[]: what the transcript binds
+};
+inline uint64_t be64(const uint8_t* b) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = v << 8 | b[i]; return v; }
+// plonk/converter.rs:18-119.  G1 points: unchecked decompression (converter.rs:62-76); G2: converter.rs:113-133 in the reference's
+// reading of the root order; 33 788 bytes of precomputed lines are skipped (converter.rs:58).
+inline int parse_plonk_vk(PlonkKey& vk, const uint8_t* b, size_t n) {
+  const FrCtx& F = fr_ctx();
+  if (n < 372) return DEC_MALFORMED;
+  vk.size = be64(b);
+  vk.size_inv = F.from_be_reduce(b + 8, 32);
+  vk.generator = F.from_be_reduce(b + 40, 32);
+  vk.nb_public = be64(b + 72);
+  vk.coset_shift = F.from_be_reduce(b + 80, 32);
+  G1Aff* pts[8] = {&vk.s[0], &vk.s[1], &vk.s[2], &vk.ql, &vk.qr, &vk.qm, &vk.qo, &vk.qk};
+  for (int i = 0; i < 8; i++) { if (dec_g1_compressed(*pts[i], b + 112 + 32 * i) != DEC_OK) return DEC_MALFORMED; enc_g1_uncompressed(vk.enc[i], *pts[i]); }
+  vk.n_qcp = be32(b + 368);
+  if (vk.n_qcp > PLONK_MAX_QCP) return DEC_MALFORMED;
+  size_t off = 372;
+  if (n < off + 32 * (size_t)vk.n_qcp + 160 + 33788 + 8) return DEC_MALFORMED;
+  for (uint32_t i = 0; i < vk.n_qcp; i++, off += 32) { if (dec_g1_compressed(vk.qcp[i], b + off) != DEC_OK) return DEC_MALFORMED; enc_g1_uncompressed(vk.enc[8 + i], vk.qcp[i]); }
+  if (dec_g1_compressed(vk.kzg_g1, b + off) != DEC_OK) return DEC_MALFORMED;
+  if (dec_g2_compressed(vk.kzg_g2[0], b + off + 32, 0) != DEC_OK) return DEC_MALFORMED;
+  if (dec_g2_compressed(vk.kzg_g2[1], b + off + 96, 0) != DEC_OK) return DEC_MALFORMED;
+  off += 160 + 33788;
+  vk.n_cci = be64(b + off); off += 8;
+  if (vk.n_cci > PLONK_MAX_QCP || n < off + 8 * vk.n_cci) return DEC_MALFORMED;
+  for (uint64_t i = 0; i < vk.n_cci; i++, off += 8) vk.cci[i] = be64(b + off);
+  return DEC_OK;
+}
+struct PlonkProof {
+  G1Aff lro[3], z, h[3], batch_h, zs_h, bsb[PLONK_MAX_QCP];
+  const uint8_t* raw;                       // the proof bytes (the transcript binds the encodings as they came)
+  size_t off_claimed, off_zs_h, off_bsb;
+  FrM claimed[PLONK_MAX_CLAIMED], zs_value; uint32_t n_claimed, n_bsb;
+};
+// status codes as in include/bn254_verify.h
+enum { PL_OK = 1, PL_NOT_MEMBER = 2, PL_NOT_ON_CURVE = 3, PL_INPUT_LEN = 5, PL_MALFORMED = 6, PL_OPENING = 7, PL_PAIRING = 8, PL_BSB22 = 9, PL_INVERSE = 10 };
+// converter.rs:78-88: two field members (>= p rejected), then the curve equation
+inline int dec_g1_uncompressed_checked(G1Aff& o, const uint8_t* b) {
+  if (!be_lt_p(b) || !be_lt_p(b + 32)) return PL_NOT_MEMBER;
+  o.x = fp_from_be(b); o.y = fp_from_be(b + 32);
+  return g1_on_curve(o) ? PL_OK : PL_NOT_ON_CURVE;
+}
+// plonk/converter.rs:121-178
+inline int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
+  const FrCtx& F = fr_ctx();
+  int st;
+  if (n < 516) return PL_MALFORMED;
+  p.raw = b;
+  G1Aff* pts[8] = {&p.lro[0], &p.lro[1], &p.lro[2], &p.z, &p.h[0], &p.h[1], &p.h[2], &p.batch_h};
+  for (int i = 0; i < 8; i++) if ((st = dec_g1_uncompressed_checked(*pts[i], b + 64 * i)) != PL_OK) return st;
+  p.n_claimed = be32(b + 512);
+  if (p.n_claimed > PLONK_MAX_CLAIMED) return PL_MALFORMED;
+  size_t off = 516;
+  if (n < off + 32 * (size_t)p.n_claimed + 100) return PL_MALFORMED;
+  p.off_claimed = off;
+  for (uint32_t i = 0; i < p.n_claimed; i++, off += 32) p.claimed[i] = F.from_be_reduce(b + off, 32);
+  p.off_zs_h = off;
+  if ((st = dec_g1_uncompressed_checked(p.zs_h, b + off)) != PL_OK) return st;
+  p.zs_value = F.from_be_reduce(b + off + 64, 32);
+  p.n_bsb = be32(b + off + 96);
+  if (p.n_bsb > PLONK_MAX_QCP) return PL_MALFORMED;
+  off += 100;
+  if (n < off + 64 * (size_t)p.n_bsb) return PL_MALFORMED;
+  p.off_bsb = off;
+  for (uint32_t i = 0; i < p.n_bsb; i++, off += 64) if ((st = dec_g1_uncompressed_checked(p.bsb[i], b + off)) != PL_OK) return st;
+  return PL_OK;
+}
+
+// transcript.rs:15-108: challenge = SHA-256(name | digest of the previous challenge (position > 0) | bindings in order)
+struct Challenge {
+  Sha256 h;
+  Challenge(const char* name, const uint8_t* prev) { h.update(name, strlen(name)); if (prev) h.update(prev, 32); }
+  void bind(const void* d, size_t n) { h.update(d, n); }
+  FrM finish(uint8_t digest[32]) { h.finish(digest); return fr_ctx().from_be_reduce(digest, 32); }
+};
+// hash_to_field.rs:45-97: RFC 9380 expand_message_xmd(SHA-256), 48 bytes, DST "BSB22-Plonk", reduced mod r
+inline FrM bsb22_hash_to_field(const uint8_t g1_uncompressed[64]) {
+  static const char dst[] = "BSB22-Plonk";
+  const uint8_t dl = 11;
+  uint8_t b0[32], b1[32], b2[32], z[64] = {0}, lib[3] = {0, 48, 0}, idx = 1, out[48], sx[32];
+  Sha256 h; h.update(z, 64); h.update(g1_uncompressed, 64); h.update(lib, 3); h.update(dst, dl); h.update(&dl, 1); h.finish(b0);
+  h.reset(); h.update(b0, 32); h.update(&idx, 1); h.update(dst, dl); h.update(&dl, 1); h.finish(b1);
+  for (int j = 0; j < 32; j++) sx[j] = b0[j] ^ b1[j];
+  idx = 2;
+  h.reset(); h.update(sx, 32); h.update(&idx, 1); h.update(dst, dl); h.update(&dl, 1); h.finish(b2);
+  memcpy(out, b1, 32); memcpy(out + 32, b2, 16);
+  return fr_ctx().from_be_reduce(out, 48);
+}
+
+// ---------------------------------------------------------------- per-proof state carried between the two host stages
+struct MsmTerm { int32_t pt[18]; uint32_t k[8]; };   // affine point (Montgomery digits) and canonical scalar: what k_g1_scalar_mul reads
+static_assert(sizeof(MsmTerm) == 104, "term layout");
+inline void put_term(MsmTerm& t, const G1Aff& p, const FrM& k) {
+  fp_to_limbs(t.pt, p.x); fp_to_limbs(t.pt + BN_NL, p.y); fr_ctx().to_words(t.k, k);
+}
+struct PlonkWork {
+  int status;                 // PL_OK while the proof is still alive, else the final status
+  PlonkProof pr;
+  FrM zeta, zu_coeff_dummy;   // (second member unused; keeps the struct trivially copyable)
+  FrM lambda;
+};
+enum { PLONK_STAGE1_TERMS_BASE = 10 };  // + n_bsb
+inline int plonk_stage1_terms(const PlonkKey& vk) { return PLONK_STAGE1_TERMS_BASE + (int)vk.n_qcp; }
+inline int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }   // lin_digest, lro x3, s1, s2, qcp.., z, kzg_g1, batch_h, zs_h
+
+// Stage 1 (plonk/verify.rs:46-284): everything up to the scalars of the linearised polynomial digest.  On a failed check the
+// proof's final status is returned and its terms are left zeroed.
+inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
+                        PlonkWork& wk, MsmTerm* terms /* plonk_stage1_terms(vk) */) {
+  const FrCtx& F = fr_ctx();
+  PlonkProof& pr = wk.pr;
+  int st = parse_plonk_proof(pr, proof, proof_len);                       // lib.rs:70
+  if (st != PL_OK) return st;
+  if (pr.n_bsb != vk.n_qcp) return PL_BSB22;                              // verify.rs:52-54
+  if (n_inputs != vk.nb_public) return PL_INPUT_LEN;                      // verify.rs:57-59 (InvalidWitness)
+  if (pr.n_claimed != 6 + vk.n_qcp || vk.n_cci != vk.n_qcp) return PL_MALFORMED;  // index panics in the reference
+  const FrM one = F.one;
+  // Fiat-Shamir (verify.rs:62-95, 319-362)
+  uint8_t dg[32], db[32], da[32], dz[32];
+  Challenge cg("gamma", nullptr);
+  for (uint32_t i = 0; i < 8 + vk.n_qcp; i++) cg.bind(vk.enc[i], 64);
+  cg.bind(inputs, 32 * n_inputs);                                         // the public inputs as stored (raw big-endian)
+  cg.bind(proof, 192);                                                    // l, r, o
+  FrM gamma = cg.finish(dg);
+  Challenge cb("beta", dg); FrM beta = cb.finish(db);
+  Challenge ca("alpha", db);
+  ca.bind(proof + pr.off_bsb, 64 * (size_t)pr.n_bsb);
+  ca.bind(proof + 192, 64);                                               // z
+  FrM alpha = ca.finish(da);
+  Challenge cz("zeta", da);
+  cz.bind(proof + 256, 192);                                              // h0, h1, h2
+  FrM zeta = cz.finish(dz);
+  wk.zeta = zeta;
+  // verify.rs:97-107
+  FrM zeta_n = F.pow_u64(zeta, vk.size);
+  FrM zh_zeta = F.sub(zeta_n, one);
+  FrM zm1 = F.sub(zeta, one);
+  if (F.is_zero(zm1)) return PL_INVERSE;
+  FrM lagrange_one = F.mul(F.mul(F.inverse(zm1), zh_zeta), vk.size_inv);
+  // verify.rs:109-137: PI = sum_i L_i(zeta) w_i (batch_invert leaves zeros alone)
+  FrM pi = {{0, 0, 0, 0}}, accw = one;
+  for (size_t i = 0; i < n_inputs; i++) {
+    FrM den = F.sub(zeta, accw);
+    FrM inv = F.is_zero(den) ? den : F.inverse(den);
+    FrM x = F.mul(F.mul(F.mul(zh_zeta, inv), vk.size_inv), accw);
+    x = F.mul(x, F.from_be_reduce(inputs + 32 * i, 32));
+    accw = F.mul(accw, vk.generator);
+    pi = F.add(pi, x);
+  }
+  // verify.rs:139-163: BSB22 commitments enter the public-input polynomial through hash_to_field
+  for (uint64_t i = 0; i < vk.n_cci; i++) {
+    FrM hashed = bsb22_hash_to_field(proof + pr.off_bsb + 64 * i);
+    FrM wpow = F.pow_u64(vk.generator, vk.nb_public + vk.cci[i]);
+    FrM den = F.sub(zeta, wpow);
+    FrM lag = F.mul(F.mul(F.mul(F.mul(zh_zeta, wpow), F.inverse(den)), vk.size_inv), hashed);
+    pi = F.add(pi, lag);
+  }
+  // verify.rs:165-214: the constant term of the linearised polynomial must equal the claimed opening
+  const FrM &l = pr.claimed[1], &r = pr.claimed[2], &o = pr.claimed[3], &s1 = pr.claimed[4], &s2 = pr.claimed[5], &zu = pr.zs_value;
+  FrM a2l1 = F.mul(F.mul(lagrange_one, alpha), alpha);
+  FrM cl = F.add(F.add(F.mul(beta, s1), gamma), l);
+  cl = F.mul(cl, F.add(F.add(F.mul(beta, s2), gamma), r));
+  cl = F.mul(cl, F.add(o, gamma));
+  cl = F.mul(F.mul(cl, alpha), zu);
+  cl = F.neg(F.add(F.sub(cl, a2l1), pi));
+  {
+    // Fr == compares stored words: a claimed value that is not reduced (>= r) can never equal the reduced left-hand side
+    FrM raw;
+    const uint8_t* cb0 = proof + pr.off_claimed;
+    for (int i = 0; i < 4; i++) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = v << 8 | cb0[(3 - i) * 8 + j]; raw.l[i] = v; }
+    if (F.geq_m(raw) || !F.eq(cl, pr.claimed[0])) return PL_OPENING;
+  }
+  // verify.rs:216-250
+  FrM t1;
+  FrM _s1 = F.add(F.add(F.mul(beta, s1), l), gamma);
+  t1 = F.add(F.add(F.mul(beta, s2), r), gamma);
+  _s1 = F.mul(F.mul(F.mul(F.mul(_s1, t1), beta), alpha), zu);
+  FrM _s2 = F.add(F.add(F.mul(beta, zeta), gamma), l);
+  FrM u = F.mul(beta, vk.coset_shift);
+  _s2 = F.mul(_s2, F.add(F.add(F.mul(u, zeta), gamma), r));
+  FrM u2 = F.mul(u, vk.coset_shift);
+  _s2 = F.mul(_s2, F.add(F.add(F.mul(u2, zeta), gamma), o));
+  _s2 = F.neg(F.mul(_s2, alpha));
+  FrM coeff_z = F.add(a2l1, _s2);
+  FrM rl = F.mul(l, r);
+  FrM zn2 = F.pow_u64(zeta, vk.size + 2);
+  FrM zn2sq = F.mul(zn2, zn2);
+  zn2 = F.neg(F.mul(zn2, zh_zeta));
+  zn2sq = F.neg(F.mul(zn2sq, zh_zeta));
+  FrM zh = F.neg(zh_zeta);
+  // verify.rs:252-284: the MSM of the linearised polynomial digest
+  int np = 0;
+  for (uint32_t i = 0; i < pr.n_bsb; i++) put_term(terms[np++], pr.bsb[i], pr.claimed[6 + i]);
+  put_term(terms[np++], vk.ql, l); put_term(terms[np++], vk.qr, r); put_term(terms[np++], vk.qm, rl); put_term(terms[np++], vk.qo, o);
+  put_term(terms[np++], vk.qk, one); put_term(terms[np++], vk.s[2], _s1); put_term(terms[np++], pr.z, coeff_z);
+  put_term(terms[np++], pr.h[0], zh); put_term(terms[np++], pr.h[1], zn2); put_term(terms[np++], pr.h[2], zn2sq);
+  return PL_OK;
+}
+
+// Stage 2 (plonk/verify.rs:286-303, kzg.rs:46-190): fold the opening proofs at zeta and at zeta * omega.  lin_digest: the stage-1
+// MSM result as 16 little-endian words (x | y) and its identity flag.  Writes the terms of
+//   P0 = sum_i gamma^i D_i + lambda Z - fe G_kzg + zeta H_batch + lambda zeta omega H_zs      (plonk_stage2_terms(vk) terms)
+//   P1 = -(H_batch + lambda H_zs)                                                              (2 terms)
+// for the check e(P0, g2[0]) e(P1, g2[1]) == 1 (kzg.rs:175-187).
+inline void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWork& wk, const uint32_t lin_words[16], bool lin_inf,
+                         MsmTerm* t0, uint8_t* t0_inf, MsmTerm* t1) {
+  const FrCtx& F = fr_ctx();
+  const PlonkProof& pr = wk.pr;
+  const int nd = 6 + (int)vk.n_qcp;
+  // the digests in folding order: linearised polynomial, l, r, o, s1, s2, qcp...
+  uint8_t lin_enc[64];
+  G1Aff lin;
+  if (lin_inf) { memset(lin_enc, 0, 64); lin.x = fp_zero(); lin.y = fp_zero(); }
+  else { lin.x = fp_from_words(lin_words); lin.y = fp_from_words(lin_words + 8); enc_g1_uncompressed(lin_enc, lin); }
+  // kzg.rs:46-72: a fresh transcript for the folding challenge
+  uint8_t b32[32], dgam[32];
+  Challenge cg("gamma", nullptr);
+  F.to_be(b32, wk.zeta); cg.bind(b32, 32);
+  cg.bind(lin_enc, 64);
+  cg.bind(proof, 192);                                      // l, r, o
+  cg.bind(vk.enc[0], 64); cg.bind(vk.enc[1], 64);           // s1, s2
+  for (uint32_t i = 0; i < vk.n_qcp; i++) cg.bind(vk.enc[8 + i], 64);
+  cg.bind(proof + pr.off_claimed, 32 * (size_t)nd);         // the claimed values as stored
+  cg.bind(proof + pr.off_zs_h + 64, 32);                    // z(zeta omega) as stored
+  FrM kgamma = cg.finish(dgam);
+  FrM gi[PLONK_MAX_QCP + 6];
+  gi[0] = F.one;
+  for (int i = 1; i < nd; i++) gi[i] = F.mul(gi[i - 1], kgamma);
+  FrM folded_eval = {{0, 0, 0, 0}};
+  for (int i = 0; i < nd; i++) folded_eval = F.add(folded_eval, F.mul(pr.claimed[i], gi[i]));
+  // kzg.rs:128-190: batch the two opening points with lambda
+  const FrM lam = wk.lambda;
+  FrM fe = F.add(folded_eval, F.mul(pr.zs_value, lam));
+  FrM shifted = F.mul(wk.zeta, vk.generator);
+  int np = 0;
+  memset(t0_inf, 0, (size_t)plonk_stage2_terms(vk));
+  t0_inf[np] = lin_inf ? 1 : 0; put_term(t0[np++], lin, gi[0]);
+  put_term(t0[np++], pr.lro[0], gi[1]); put_term(t0[np++], pr.lro[1], gi[2]); put_term(t0[np++], pr.lro[2], gi[3]);
+  put_term(t0[np++], vk.s[0], gi[4]); put_term(t0[np++], vk.s[1], gi[5]);
+  for (uint32_t i = 0; i < vk.n_qcp; i++) put_term(t0[np++], vk.qcp[i], gi[6 + i]);
+  put_term(t0[np++], pr.z, lam);
+  put_term(t0[np++], vk.kzg_g1, F.neg(fe));
+  put_term(t0[np++], pr.batch_h, wk.zeta);
+  put_term(t0[np++], pr.zs_h, F.mul(lam, shifted));
+  put_term(t1[0], pr.batch_h, F.neg(F.one));
+  put_term(t1[1], pr.zs_h, F.neg(lam));
+}
+
+}  // namespace bn254host

@@ -180,6 +180,62 @@ def test_verify_batch_vs_oracle_all_classes(pkg, O, workload, L):
         pvk.close()
 
 
+def _plonk_cases(O, fixtures, rng, per_fixture):
+    """(proof, inputs) pairs built from the reference's 4 PlonK fixtures: the originals and single-byte / single-bit mutations of
+    the proof and the public inputs that exercise every status the PlonK path can return."""
+    fx, vk = fixtures
+    cases = []
+    for name, f in fx.items():
+        if f["variant"] != "plonk":
+            continue
+        proof = bytes.fromhex(f["raw_proof"])
+        pis = b"".join(be(int(x)) for x in f["public_inputs"])
+        cases.append((proof, pis))
+        for _ in range(per_fixture):
+            p, q = bytearray(proof), bytearray(pis)
+            kind = rng.randrange(8)
+            if kind == 0: q[rng.randrange(64)] ^= 1 << rng.randrange(8)                 # public input
+            elif kind == 1: p[516 + rng.randrange(32 * 7)] ^= 1 << rng.randrange(8)     # a claimed value
+            elif kind == 2: p[rng.randrange(512)] ^= 1 << rng.randrange(8)              # a commitment coordinate
+            elif kind == 3: p[0:32] = bytes([0xff]) * 32                                # coordinate >= p
+            elif kind == 4: p[515] ^= 1                                                 # number of claimed values
+            elif kind == 5: p[516 + 32 * 7 + 64 + rng.randrange(32)] ^= 1               # z(zeta omega)
+            elif kind == 6: p[448 + rng.randrange(64)] ^= 1 << rng.randrange(8)         # batched opening proof
+            else: p[516 + 32 * 7 + 64 + 32 + 3] ^= 1                                    # number of BSB22 commitments
+            cases.append((bytes(p), bytes(q)))
+    return cases, vk
+
+
+def test_plonk_reference_fixtures_and_mutations_vs_oracle(pkg, O, fixtures):
+    """BASELINE configs[3]: the reference's PlonK fixtures (examples/binaries/*_plonk_proof.bin, vk from the guest ELF) must be
+    accepted by the GPU path, and every mutated proof must get the oracle's status byte."""
+    rng = random.Random(31)
+    cases, vk = _plonk_cases(O, fixtures, rng, 30)
+    pvk = pkg.PreparedPlonkVk(vk)
+    assert pvk.n_public == 2
+    proofs = b"".join(c[0] for c in cases); inputs = b"".join(c[1] for c in cases)
+    st = pvk.verify_batch(proofs, inputs, proof_stride=904)
+    exp = bytes(O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) for c in cases)
+    assert st == exp
+    assert st[0] == pkg.ACCEPT and st.count(bytes([pkg.ACCEPT])) >= 4 and len(set(st)) >= 4, sorted(set(st))
+    # single-proof entry point (PlonkVerifier::verify), wrong number of public inputs
+    assert pkg.PlonkVerifier.verify(cases[0][0], vk, [cases[0][1][:32], cases[0][1][32:]]) == pkg.ACCEPT
+    assert pkg.PlonkVerifier.verify(cases[0][0], vk, [cases[0][1][:32]]) == O.plonk_verify(cases[0][0], vk, [int.from_bytes(cases[0][1][:32], "big")])
+    pvk.close()
+
+
+def test_plonk_batch_4096(pkg, O, fixtures):
+    """Batch of 4096 (the size BASELINE quotes): fixtures and mutations repeated; statuses must be those of the small run."""
+    rng = random.Random(32)
+    cases, vk = _plonk_cases(O, fixtures, rng, 7)
+    pvk = pkg.PreparedPlonkVk(vk)
+    small = pvk.verify_batch(b"".join(c[0] for c in cases), b"".join(c[1] for c in cases))
+    reps = 4096 // len(cases)
+    big = pvk.verify_batch(b"".join(c[0] for c in cases) * reps, b"".join(c[1] for c in cases) * reps)
+    assert big == small * reps
+    pvk.close()
+
+
 @pytest.mark.parametrize("n_public", [17, 40, 1024])
 def test_many_public_inputs_vs_oracle(pkg, O, n_public):
     """Keys with many public inputs (BASELINE configs[4]: 1024) take the wide MSM path: the inputs of one proof are summed by
