@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""PlonK batch verification rate (BASELINE configs[3]: batch 4096, SP1 circuit, 2 public inputs) on one MI355X.
+The workload is the reference's 4 PlonK fixtures plus mutated copies (every 8th proof invalid), host buffers in, status bytes out:
+the host stages (transcripts, scalar-field arithmetic) are part of the path, so the rate is PCIe- and host-inclusive.
+Prints one JSON line; cpu_baseline = the oracle's reference-faithful PlonK verifier on one core."""
+import argparse, importlib, json, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=64)
+    args = ap.parse_args()
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    from oracle import oracle as O
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    vk = open(os.path.join(ROOT, "tests", "golden", "plonk_vk.bin"), "rb").read()
+    base = [(bytes.fromhex(f["raw_proof"]), b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"])) for f in fx.values() if f["variant"] == "plonk"]
+    rng = random.Random(4)
+    proofs, inputs = [], []
+    for i in range(args.batch):
+        p, q = base[i % len(base)]
+        if i % 8 == 7:
+            q = bytearray(q); q[rng.randrange(64)] ^= 1 << rng.randrange(8); q = bytes(q)
+        proofs.append(p); inputs.append(q)
+    pb, ib = b"".join(proofs), b"".join(inputs)
+    pvk = pkg.PreparedPlonkVk(vk)
+    for _ in range(args.warmup):
+        st = pvk.verify_batch(pb, ib)
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        st = pvk.verify_batch(pb, ib)
+    dt = time.perf_counter() - t
+    m = min(args.cpu_sample, args.batch)
+    t = time.perf_counter()
+    ref = bytes(O.plonk_verify(proofs[i], vk, [int.from_bytes(inputs[i][:32], "big"), int.from_bytes(inputs[i][32:], "big")]) for i in range(m))
+    cdt = time.perf_counter() - t
+    assert st[:m] == ref, "GPU statuses differ from the oracle"
+    assert st.count(bytes([pkg.ACCEPT])) == args.batch - args.batch // 8
+    print(json.dumps({"metric": "PlonK verifies/sec at batch=%d (host buffers in, status bytes out)" % args.batch, "value": args.batch * args.steps / dt,
+                      "unit": "proofs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+                      "higher_is_better": True, "dtype": "int64", "data": "reference fixtures + mutations",
+                      "config": {"workload": "BASELINE configs[3]: PlonK batch %d, 904-byte proofs, 2 public inputs, 1/8 invalid" % args.batch},
+                      "cpu_baseline": {"value": m / cdt, "unit": "proofs/s", "cores": 1, "kind": "port", "sample": "first %d proofs, %.1f s" % (m, cdt)}}))
+
+
+if __name__ == "__main__":
+    main()
