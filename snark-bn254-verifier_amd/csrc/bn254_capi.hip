@@ -27,7 +27,6 @@ static int set_err(int code, const std::string& msg) { g_err = msg; return code;
 struct DevState {
   bool ready = false;
   int32_t *k0 = nullptr, *gtab = nullptr, *dtab = nullptr, *target = nullptr, *msm = nullptr;
-  uint8_t* step_kinds = nullptr;
   int32_t* ws = nullptr; size_t ws_cap = 0;                         // proofs the workspace can hold
   int32_t* msm_part = nullptr; size_t msm_part_cap = 0;             // wide keys: partial sums of the public-input MSM (proofs it holds)
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
@@ -190,7 +189,7 @@ void bn254_groth16_vk_free(bn254_g16_pvk* pvk) {
   for (auto& kv : pvk->dev) {
     DevState& d = kv.second;
     if (hipSetDevice(kv.first) != hipSuccess) continue;
-    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, d.msm_part, (int32_t*)d.step_kinds};
+    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, d.msm_part};
     for (auto q : ptrs) if (q) (void)hipFree(q);
     uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
     for (auto q : bp) if (q) (void)hipFree(q);

@@ -45,7 +45,7 @@ struct G16LaunchArgs {
 #define G16_WIDE_MSM_MAX_PROOFS 65536   // proofs per launch on the wide path (bounds the partial-sum buffer: 442 MB at 1024 inputs)
 // kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
 enum {
-  KID_PREPARE, KID_SUBGROUP, KID_VM_INIT, KID_F12_SQR, KID_G2_DBL, KID_G2_ADD, KID_MUL_LINE_VAR, KID_MUL_LINE_FIXED, KID_F12_MUL,
+  KID_PREPARE, KID_SUBGROUP, KID_VM_INIT, KID_F12_SQR, KID_MUL_LINE_FIXED, KID_F12_MUL,
   KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_F12_COPY, KID_CYCLO_SQR_N, KID_MILLER_DBL_VAR, KID_MILLER_ADD_VAR, KID_MSM_PARTIAL, KID_MSM_REDUCE, KID_COUNT
 };
 extern const char* const bn254_kernel_kind_names[KID_COUNT];

@@ -26,7 +26,6 @@
 
 namespace bn254 {
 
-typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
 
 // ---- workspace accessor ----------------------------------------------------------------------------------------------------------
 struct DevWs {
@@ -93,17 +92,10 @@ __global__ void __launch_bounds__(256, 2) k_vm_init(int32_t* ws, uint32_t n, con
   w.st(VE_T + 4, fp_one()); w.st(VE_T + 5, fp_zero());
 }
 __global__ void __launch_bounds__(256, 2) k_f12_sqr(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e) { VM_KERNEL_PROLOGUE(); vm_f12_sqr(w, e); }
-__global__ void __launch_bounds__(256, 2) k_f12_mul_line_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, int e_line, int e_px) {
-  VM_KERNEL_PROLOGUE(); vm_f12_mul_line_var(w, e, e_line, e_px);
-}
 __global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, const int32_t* __restrict__ entry, int e_px, int inf_mask) {
   VM_KERNEL_PROLOGUE();
   FixedLine l; l.m = uni_ld2(entry); l.c = uni_ld2(entry + 2 * BN_NL); l.xc = uni_ld2(entry + 4 * BN_NL);
   vm_f12_mul_line_fixed(w, e, l, e_px, (st & inf_mask) != 0);  // inf_mask: the status bit that marks this pair's G1 point as the identity
-}
-__global__ void __launch_bounds__(256, 2) k_g2_dbl(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line) { VM_KERNEL_PROLOGUE(); vm_g2_dbl(w, e_t, e_line); }
-__global__ void __launch_bounds__(256, 2) k_g2_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_line, int e_b, int which) {
-  VM_KERNEL_PROLOGUE(); vm_g2_add(w, e_t, e_line, e_b, which);
 }
 __global__ void __launch_bounds__(256, 2) k_miller_dbl_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_miller_dbl_var(w, e_t, e, e_px);
@@ -495,7 +487,7 @@ using namespace bn254;
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
-  "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_g2_dbl", "k_g2_add", "k_f12_mul_line_var", "k_f12_mul_line_fixed",
+  "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_f12_mul_line_fixed",
   "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
@@ -513,11 +505,8 @@ struct LaunchOps {
   int inf_mask[2] = {BN254_ST_LINF, 0};   // status bits marking the G1 point of fixed pair 0 / 1 as the identity
   int uni(int x) { return x; }
   void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
-  void g2_dbl(int et, int el) { BN_LAUNCH(KID_G2_DBL, k_g2_dbl, ws, n, status, et, el); }
-  void g2_add(int et, int el, int eb, int which) { BN_LAUNCH(KID_G2_ADD, k_g2_add, ws, n, status, et, el, eb, which); }
   void miller_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_DBL_VAR, k_miller_dbl_var, ws, n, status, et, e, ep); }
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
-  void f12_mul_line_var(int e, int el, int ep) { BN_LAUNCH(KID_MUL_LINE_VAR, k_f12_mul_line_var, ws, n, status, e, el, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
     BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, inf_mask[t]);
   }

@@ -19,8 +19,8 @@ namespace bn254 {
 enum {
   VE_AX = 0, VE_AY = 1, VE_B = 2 /* x.c0 x.c1 y.c0 y.c1 */, VE_CX = 6, VE_CY = 7, VE_LX = 8, VE_LY = 9,
   VE_F = 10,                 // Miller accumulator, then m = easy part of the final exponentiation
-  VE_T = 22, VE_LINE = 28,   // Miller loop: running G2 point (X, Y, Z) and the current line (r0, r1, r2)
-  VE_S0 = 22, VE_S1 = 34, VE_S2 = 46, VE_S3 = 58, VE_S4 = 70,  // final exponentiation slots (S0 aliases T + LINE)
+  VE_T = 22,                 // Miller loop: running G2 point (X, Y, Z)
+  VE_S0 = 22, VE_S1 = 34, VE_S2 = 46, VE_S3 = 58, VE_S4 = 70,  // final exponentiation slots (S0 aliases T)
   VE_P3 = 82,                   // x^3 of the windowed exp-by-u
   VE_TMPA = 94, VE_TMPB = 100,  // two Fp6 temporaries of the general Fp12 product
   VE_P5 = 106, VE_P7 = 118,     // x^5, x^7
@@ -44,20 +44,6 @@ BN_HD void vm_f12_sqr(W& w, int e) {
   vst2(w, e + 8, fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5)));
   vst2(w, e + 10, fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3)));
 }
-// ---- f <- f * (d0 + d3 w + d4 w^3), all coefficients in Fp2 (variable-Q line): d0 = r0 yP, d3 = r1 xP, d4 = r2 ----------------------
-template <class W>
-BN_HD void vm_f12_mul_line_var(W& w, int e, int e_line, int e_px) {
-  Fp px = w.ld(e_px), py = w.ld(e_px + 1);
-  Fp2 d0 = fp2_mul_fp(vld2(w, e_line), py), d3 = fp2_mul_fp(vld2(w, e_line + 2), px), d4 = vld2(w, e_line + 4);
-  Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
-  Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
-  vst2(w, e, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3)));
-  vst2(w, e + 2, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4)));
-  vst2(w, e + 4, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5)));
-  vst2(w, e + 6, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0)));
-  vst2(w, e + 8, fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1)));
-  vst2(w, e + 10, fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2)));
-}
 // ---- f <- f * (yP + (m xP) w + c w^3): precomputed affine line of a fixed G2 argument; inf: the G1 point is the identity -----------
 template <class W>
 BN_HD void vm_f12_mul_line_fixed(W& w, int e, const FixedLine& l, int e_px, bool inf) {
@@ -74,27 +60,6 @@ BN_HD void vm_f12_mul_line_fixed(W& w, int e, const FixedLine& l, int e_px, bool
   vst2(w, e + 8, fp2_dot_line(d0, k4, d3, k3, d4, k1));
   vst2(w, e + 10, fp2_dot_line(d0, k5, d3, k4, d4, k2));
 }
-// ---- G2 steps on the workspace: T <- 2T / T <- T + Q, line written to e_line -----------------------------------------------------
-template <class W>
-BN_HD void vm_g2_dbl(W& w, int e_t, int e_line) {
-  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
-  G2Line l = g2_double_step(t);
-  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
-  vst2(w, e_line, l.r0); vst2(w, e_line + 2, l.r1); vst2(w, e_line + 4, l.r2);
-}
-// which: 0 = +B, 1 = -B, 2 = pi(B), 3 = -pi^2(B)
-template <class W>
-BN_HD void vm_g2_add(W& w, int e_t, int e_line, int e_b, int which) {
-  G2Aff q; q.x = vld2(w, e_b); q.y = vld2(w, e_b + 2);
-  if (which == 1) q = g2_neg(q);
-  else if (which == 2) q = g2_psi_affine(q);
-  else if (which == 3) q = g2_neg(g2_psi2_affine(q));
-  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
-  G2Line l = g2_add_step(t, q);
-  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
-  vst2(w, e_line, l.r0); vst2(w, e_line + 2, l.r1); vst2(w, e_line + 4, l.r2);
-}
-
 // ---- fused Miller step of the variable pair: T <- 2T (or T + Q), f <- f * line(P); the line never leaves the registers -----------
 template <class W>
 BN_HD void vm_f12_mul_line_regs(W& w, int e, const G2Line& l, int e_px) {

@@ -51,7 +51,7 @@ void hs_fp_op(int op, uint8_t* o, const uint8_t* a, const uint8_t* b, int inflat
   }
   fp_out(o, r);
 }
-// op: 0 add 1 sub 2 mul 3 inv 5 sqr 6 mul_xi
+// op: 0 add 1 sub 2 mul 3 inv 5 sqr 6 mul_xi; Karatsuba dot (fp2_dotk): 10 x*y, 11 x^2, 12 2xy - yx + x^2 (= xy + x^2), 13 -2 x*y + x*(y.c0)
 void hs_fp2_op(int op, uint8_t* o, const uint8_t* a, const uint8_t* b, int inflate) {
   Fp2 x = fp2_in(a, inflate), y = fp2_in(b, inflate), r = fp2_zero();
   switch (op) {
@@ -61,6 +61,10 @@ void hs_fp2_op(int op, uint8_t* o, const uint8_t* a, const uint8_t* b, int infla
     case 3: r = fp2_inv(x); break;
     case 5: r = fp2_sqr(x); break;
     case 6: r = fp2_mul_xi(x); break;
+    case 10: r = fp2_dotk(kp(x, y)); break;
+    case 11: r = fp2_dotk(ksq(x)); break;
+    case 12: r = fp2_dotk(kp2(x, y), km(y, x), ksq(x)); break;
+    case 13: r = fp2_dotk(km2(x, y), kfp(x, y.c0)); break;
   }
   fp2_out(o, r);
 }

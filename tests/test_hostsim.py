@@ -56,6 +56,12 @@ def test_fp2_fp12(hostsim, O):
                 assert fp2(op, a, b, inf) == O.fp2_op(op, a, b)
             assert fp2(5, a, b, inf) == O.fp2_op(5, a)
             assert fp2(6, a, b, inf) == O.fp2_op(2, a, (9, 1))
+            if inf == 0:  # the Karatsuba form of the Fp2 dot product (operand sums need normalised digits)
+                ab, aa = O.fp2_op(2, a, b), O.fp2_op(5, a)
+                assert fp2(10, a, b) == ab and fp2(11, a, b) == aa
+                assert fp2(12, a, b) == O.fp2_op(0, ab, aa)
+                m2 = O.fp2_op(1, (0, 0), O.fp2_op(0, ab, ab))
+                assert fp2(13, a, b) == O.fp2_op(0, m2, O.fp2_op(2, a, (b[0], 0)))
     for _ in range(5):
         a = rnd2(); assert fp2(3, a) == O.fp2_op(3, a)
     r12 = lambda: b"".join(be(random.randrange(P)) for _ in range(12))
