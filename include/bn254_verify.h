@@ -110,6 +110,23 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                        size_t n_public, uint8_t* status);
 
+/* ---- gnark / SP1 formats, both directions (host only) ------------------------------------------------------------------
+ * Point codecs of verifier/src/converter.rs:23-153.  compress: uncompressed big-endian coordinates (G1: x | y; G2: x.c1 | x.c0 |
+ * y.c1 | y.c0) -> gnark compressed form (flag 0b10 / 0b11 = lexicographically smallest / largest y in the top two bits).
+ * decompress: the inverse; `checked` selects compressed_x_to_g{1,2}_point (converter.rs:46,91: curve and, for G2, r-torsion
+ * checks) over the unchecked variants (converter.rs:62,113) the key loaders use; mode = BN254_VK_REFERENCE / BN254_VK_GNARK
+ * picks the reading of the G2 root order.  *status: BN254_ACCEPT, BN254_ERR_MALFORMED (flag 0b00, no square root),
+ * BN254_ERR_NOT_ON_CURVE, BN254_ERR_NOT_IN_SUBGROUP.
+ * bn254_sp1_fixture_parse: the SP1 v2.0.0 SP1ProofWithPublicValues files of examples/binaries/ (bincode) -> variant (2 PlonK,
+ * 3 Groth16), raw gnark proof bytes, the two public inputs as 32-byte big-endian values, and the vkey hash: exactly what
+ * examples/script/src/main.rs:115-138 feeds to the verifiers. */
+int bn254_g1_compress(const uint8_t xy[64], uint8_t out[32]);
+int bn254_g2_compress(const uint8_t xy[128], uint8_t out[64]);
+int bn254_g1_decompress(const uint8_t in[32], uint8_t out[64], int checked, uint8_t* status);
+int bn254_g2_decompress(const uint8_t in[64], uint8_t out[128], unsigned mode, int checked, uint8_t* status);
+int bn254_sp1_fixture_parse(const uint8_t* buf, size_t len, int* variant, uint8_t* raw_proof, size_t raw_cap, size_t* raw_len,
+                            uint8_t public_inputs[64], uint8_t vkey_hash[32]);
+
 /* ---- measurement support ------------------------------------------------------------------------------------------
  * A batch runs as ~720 kernel launches: one per Fp12-level operation of the verification program (k_f12_sqr, k_f12_mul,
  * k_f12_mul_line_fixed, ...), each over the whole (sub-)batch.  When profiling is enabled, verify_batch_device records HIP

@@ -445,6 +445,91 @@ int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk
   return rc;
 }
 
+// ---------------------------------------------------------------- gnark / SP1 formats (host only: byte shuffling and one square root)
+int bn254_g1_compress(const uint8_t xy[64], uint8_t out[32]) {
+  if (!xy || !out) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (!be_lt_p(xy) || !be_lt_p(xy + 32)) return set_err(BN254_E_BAD_ARG, "coordinate not reduced");
+  G1Aff p; p.x = fp_from_be(xy); p.y = fp_from_be(xy + 32);
+  enc_g1_compressed(out, p);
+  return BN254_OK;
+}
+int bn254_g2_compress(const uint8_t xy[128], uint8_t out[64]) {
+  if (!xy || !out) return set_err(BN254_E_BAD_ARG, "bad argument");
+  for (int i = 0; i < 4; i++) if (!be_lt_p(xy + 32 * i)) return set_err(BN254_E_BAD_ARG, "coordinate not reduced");
+  G2Aff p; p.x.c1 = fp_from_be(xy); p.x.c0 = fp_from_be(xy + 32); p.y.c1 = fp_from_be(xy + 64); p.y.c0 = fp_from_be(xy + 96);
+  enc_g2_compressed(out, p);
+  return BN254_OK;
+}
+int bn254_g1_decompress(const uint8_t in[32], uint8_t out[64], int checked, uint8_t* status) {
+  if (!in || !out || !status) return set_err(BN254_E_BAD_ARG, "bad argument");
+  G1Aff p;
+  if (dec_g1_compressed(p, in) != DEC_OK) { *status = BN254_ERR_MALFORMED; return BN254_OK; }
+  // checked (converter.rs:46-60): AffineG1::new = curve equation; G1 has cofactor 1, so there is nothing else to test
+  if (checked && !g1_on_curve(p)) { *status = BN254_ERR_NOT_ON_CURVE; return BN254_OK; }
+  enc_g1_uncompressed(out, p);
+  *status = BN254_ACCEPT;
+  return BN254_OK;
+}
+int bn254_g2_decompress(const uint8_t in[64], uint8_t out[128], unsigned mode, int checked, uint8_t* status) {
+  if (!in || !out || !status || mode > 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  G2Aff p;
+  if (dec_g2_compressed(p, in, (int)mode) != DEC_OK) { *status = BN254_ERR_MALFORMED; return BN254_OK; }
+  if (checked) {  // converter.rs:91-111: AffineG2::new = curve equation, then the r-torsion test
+    if (!g2_on_curve(p)) { *status = BN254_ERR_NOT_ON_CURVE; return BN254_OK; }
+    if (!g2_in_subgroup(p)) { *status = BN254_ERR_NOT_IN_SUBGROUP; return BN254_OK; }
+  }
+  enc_g2_uncompressed(out, p);
+  *status = BN254_ACCEPT;
+  return BN254_OK;
+}
+// SP1 v2.0.0 `SP1ProofWithPublicValues` as written by bincode (little-endian, u64 lengths): u32 variant (2 PlonK, 3 Groth16),
+// String public_inputs[0], String public_inputs[1] (decimal), String encoded_proof (hex), String raw_proof (hex), [u8; 32]
+// vkey hash, ...  (examples/script/src/main.rs:115-138 reads the same fields)
+static bool sp1_string(const uint8_t* b, size_t len, size_t& off, const uint8_t** s, size_t* n) {
+  if (off + 8 > len) return false;
+  uint64_t k = 0; for (int i = 7; i >= 0; i--) k = k << 8 | b[off + i];
+  off += 8;
+  if (k > len - off) return false;
+  *s = b + off; *n = (size_t)k; off += (size_t)k;
+  return true;
+}
+static bool dec_to_be32(const uint8_t* s, size_t n, uint8_t out[32]) {
+  memset(out, 0, 32);
+  if (n == 0) return false;
+  for (size_t i = 0; i < n; i++) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    unsigned carry = s[i] - '0';
+    for (int j = 31; j >= 0; j--) { unsigned v = out[j] * 10u + carry; out[j] = (uint8_t)v; carry = v >> 8; }
+    if (carry) return false;  // more than 256 bits
+  }
+  return true;
+}
+int bn254_sp1_fixture_parse(const uint8_t* buf, size_t len, int* variant, uint8_t* raw_proof, size_t raw_cap, size_t* raw_len,
+                            uint8_t public_inputs[64], uint8_t vkey_hash[32]) {
+  if (!buf || !variant || !raw_proof || !raw_len || !public_inputs || !vkey_hash) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (len < 4) return set_err(BN254_E_BAD_ARG, "truncated fixture");
+  *variant = (int)((uint32_t)buf[0] | (uint32_t)buf[1] << 8 | (uint32_t)buf[2] << 16 | (uint32_t)buf[3] << 24);
+  size_t off = 4, n0, n1, ne, nr; const uint8_t *s0, *s1, *se, *sr;
+  if (!sp1_string(buf, len, off, &s0, &n0) || !sp1_string(buf, len, off, &s1, &n1) || !sp1_string(buf, len, off, &se, &ne) ||
+      !sp1_string(buf, len, off, &sr, &nr) || off + 32 > len)
+    return set_err(BN254_E_BAD_ARG, "truncated fixture");
+  if (!dec_to_be32(s0, n0, public_inputs) || !dec_to_be32(s1, n1, public_inputs + 32)) return set_err(BN254_E_BAD_ARG, "public input is not a decimal number below 2^256");
+  if (nr % 2 || nr / 2 > raw_cap) return set_err(BN254_E_BAD_ARG, "raw proof does not fit");
+  for (size_t i = 0; i < nr / 2; i++) {
+    int v = 0;
+    for (int k = 0; k < 2; k++) {
+      uint8_t c = sr[2 * i + k];
+      int d = (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1;
+      if (d < 0) return set_err(BN254_E_BAD_ARG, "raw proof is not hexadecimal");
+      v = v * 16 + d;
+    }
+    raw_proof[i] = (uint8_t)v;
+  }
+  *raw_len = nr / 2;
+  memcpy(vkey_hash, buf + off, 32);
+  return BN254_OK;
+}
+
 // ---------------------------------------------------------------- device-arithmetic probes (tests)
 static int run_probe(size_t in_a, size_t in_b, size_t out_sz, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int device,
                      hipError_t (*launch)(const uint8_t*, const uint8_t*, uint8_t*, size_t)) {

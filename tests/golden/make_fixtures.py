@@ -46,6 +46,13 @@ def main():
     for fn in sorted(os.listdir(bdir)):
         if fn.endswith("_proof.bin"):
             out[fn[:-len("_proof.bin")]] = parse_fixture(os.path.join(bdir, fn))
+    # the 8 fixture files themselves (21 KB of data): input of the SP1 fixture reader test
+    import shutil
+    os.makedirs(os.path.join(HERE, "sp1"), exist_ok=True)
+    for fn in sorted(os.listdir(bdir)):
+        if fn.endswith("_proof.bin"):
+            shutil.copy(os.path.join(bdir, fn), os.path.join(HERE, "sp1", fn))
+            os.chmod(os.path.join(HERE, "sp1", fn), 0o644)
     elf = open(os.path.join(REF, "examples", "program", "elf", "plonk"), "rb").read()
     vk = elf[PLONK_VK_OFFSET:PLONK_VK_OFFSET + PLONK_VK_LEN]
     assert hashlib.sha256(vk).hexdigest() == PLONK_VK_SHA256, "plonk vk hash mismatch"

@@ -103,3 +103,46 @@ def test_product_does_not_reference_oracle():
             if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert not re.search(r'#include\s*[<"][^">]*oracle|liboracle|^\s*(from|import)\s+oracle', txt, re.M), fn
+
+
+def test_point_codecs_both_directions(pkg, O):
+    """gnark compressed <-> uncompressed through the C ABI against the oracle's codecs (converter.rs:23-153), both root-order
+    readings for G2, checked variants on points outside the subgroup, malformed flags."""
+    import ctypes as C, random
+    L = pkg.lib()
+    rng = random.Random(5)
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    st = C.c_uint8(0)
+    for _ in range(8):
+        p = O.g1_mul(g1, rng.randrange(1, R)); q = O.g2_mul(g2, rng.randrange(1, R))
+        c1 = (C.c_uint8 * 32)(); c2 = (C.c_uint8 * 64)(); u1 = (C.c_uint8 * 64)(); u2 = (C.c_uint8 * 128)()
+        assert L.bn254_g1_compress(p, c1) == 0 and bytes(c1) == O.compress_g1(p)
+        assert L.bn254_g2_compress(q, c2) == 0 and bytes(c2) == O.compress_g2(q)
+        for checked in (0, 1):
+            assert L.bn254_g1_decompress(bytes(c1), u1, checked, C.byref(st)) == 0 and st.value == pkg.ACCEPT and bytes(u1) == p
+            assert L.bn254_g2_decompress(bytes(c2), u2, pkg.VK_GNARK, checked, C.byref(st)) == 0 and st.value == pkg.ACCEPT and bytes(u2) == q
+        # the reference's reading of the root order agrees with the oracle's mode-0 decoder (it may return -q)
+        assert L.bn254_g2_decompress(bytes(c2), u2, pkg.VK_REFERENCE, 0, C.byref(st)) == 0 and st.value == pkg.ACCEPT
+        ok, ref = O.decompress_g2(bytes(c2), O.MODE_REFERENCE)
+        assert ok == O.ACCEPT and bytes(u2) == ref
+    bad = bytearray(O.compress_g1(g1)); bad[0] &= 0x3f                      # flag 0b00
+    u1 = (C.c_uint8 * 64)()
+    assert L.bn254_g1_decompress(bytes(bad), u1, 1, C.byref(st)) == 0 and st.value == pkg.ERR_MALFORMED
+
+
+def test_sp1_fixture_reader(pkg, fixtures):
+    """bn254_sp1_fixture_parse on the reference's 8 fixture files gives the fields tests/golden/fixtures.json was built from."""
+    import ctypes as C, os
+    L = pkg.lib()
+    fx, _vk = fixtures
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sp1")
+    for name, f in fx.items():
+        buf = open(os.path.join(d, name + "_proof.bin"), "rb").read()
+        variant = C.c_int(0); raw = (C.c_uint8 * 2048)(); raw_len = C.c_size_t(0); pis = (C.c_uint8 * 64)(); h = (C.c_uint8 * 32)()
+        assert L.bn254_sp1_fixture_parse(buf, C.c_size_t(len(buf)), C.byref(variant), raw, C.c_size_t(2048), C.byref(raw_len), pis, h) == 0
+        assert variant.value == (2 if f["variant"] == "plonk" else 3)
+        assert bytes(raw)[:raw_len.value] == bytes.fromhex(f["raw_proof"])
+        assert bytes(pis) == b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"])
+        assert bytes(h).hex() == f["vkey_hash"]
+    assert L.bn254_sp1_fixture_parse(b"\x03\x00", C.c_size_t(2), C.byref(variant), raw, C.c_size_t(2048), C.byref(raw_len), pis, h) != 0
