@@ -229,6 +229,19 @@ BN_HD Fp6 fp6_select(bool c, const Fp6& a, const Fp6& b) { Fp6 r; r.c0 = fp2_sel
 BN_HD Fp6 fp6_mul_v(const Fp6& a) { Fp6 r; r.c0 = fp2_mul_xi(a.c2); r.c1 = a.c0; r.c2 = a.c1; return r; }
 // (x0 + x1 v + x2 v^2)(y0 + y1 v + y2 v^2), v^3 = xi: three sums of three Fp2 products, xi folded into y1, y2 up front
 BN_HD Fp6 fp6_mul(const Fp6& x, const Fp6& y) {
+  // Karatsuba form of the Fp2 products (fp2_dotk): 27 digit products instead of 36; with 144 resident operand registers this is
+  // the one place where the operand sums still fit (237 VGPRs in k_f12_mul, no scratch, -6.6 % time:
+  // profiles/r01_kbench_memory_exposure.txt).  Operands must have normalised digits.
+  Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
+  Fp6 r;
+  r.c0 = fp2_dotk(kp(x.c0, y.c0), kp(x.c1, Y2), kp(x.c2, Y1));
+  r.c1 = fp2_dotk(kp(x.c0, y.c1), kp(x.c1, y.c0), kp(x.c2, Y2));
+  r.c2 = fp2_dotk(kp(x.c0, y.c2), kp(x.c1, y.c1), kp(x.c2, y.c0));
+  return r;
+}
+// the same product with plain Fp2 dot products (36 digit products): for callers whose other live values leave no room for the
+// operand sums (k_f12_inv)
+BN_HD Fp6 fp6_mul_plain(const Fp6& x, const Fp6& y) {
   Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
   Fp6 r;
   r.c0 = fp2_dotp(pp(x.c0, y.c0), pp(x.c1, Y2), pp(x.c2, Y1));

@@ -196,7 +196,7 @@ BN_HD void vm_f12_inv(W& w, int e_dst, int e_src) {
     d = fp6_sub(s0, s1);
   }
   Fp6 di = fp6_inv(d);
-  { Fp6 r0 = fp6_mul(vld_half(w, e_src, 0), di); Fp6 r1 = fp6_neg(fp6_mul(vld_half(w, e_src, 1), di)); vst_half(w, e_dst, 0, r0); vst_half(w, e_dst, 1, r1); }
+  { Fp6 r0 = fp6_mul_plain(vld_half(w, e_src, 0), di); Fp6 r1 = fp6_neg(fp6_mul_plain(vld_half(w, e_src, 1), di)); vst_half(w, e_dst, 0, r0); vst_half(w, e_dst, 1, r1); }
 }
 template <class W>
 BN_HD bool vm_f12_eq_const(W& w, int e, const int32_t* target /* 12 Fp in k-order, uniform memory */) {
