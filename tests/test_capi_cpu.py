@@ -94,6 +94,18 @@ def test_no_cpu_fallback(pkg):
         pkg.Groth16Verifier.verify(proofs[:256], vk, [1, 2])
 
 
+@pytest.mark.skipif(not _no_gpu(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback_plonk(pkg, fixtures):
+    """Same for the PlonK path: the key parses on the host, verification needs the GPU."""
+    fx, vk = fixtures
+    f = next(v for v in fx.values() if v["variant"] == "plonk")
+    p = pkg.PreparedPlonkVk(vk)
+    assert p.n_public == 2
+    with pytest.raises(pkg.Bn254Error) as ei:
+        p.verify_batch(bytes.fromhex(f["raw_proof"]), b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"]))
+    assert "-2" in str(ei.value) or "-3" in str(ei.value)
+
+
 def test_product_does_not_reference_oracle():
     pk = os.path.join(ROOT, "snark-bn254-verifier_amd")
     for dp, _, fns in os.walk(pk):
