@@ -11,6 +11,8 @@
 #include "bn254_host.hpp"
 #include "bn254_plonk.hpp"
 #include <thread>
+#include <chrono>
+#include <cstdio>
 
 static_assert(BN254_REJECT == BN254_ST_REJECT && BN254_ACCEPT == BN254_ST_ACCEPT && BN254_ERR_NOT_MEMBER == BN254_ST_NOT_MEMBER &&
               BN254_ERR_NOT_ON_CURVE == BN254_ST_NOT_ON_CURVE && BN254_ERR_NOT_IN_SUBGROUP == BN254_ST_NOT_IN_SUBGROUP &&
@@ -382,8 +384,12 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   const PlonkKey& key = pvk->key;
   const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key);
   const FrM lambda = fr_ctx().from_u64(0x9e3779b97f4a7c15ull);  // the reference draws it at random (kzg.rs:149-154); any value works
+  static const bool timing = getenv("BN254_PLONK_TIMING") != nullptr;   // stage durations on stderr (diagnostics)
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   for (size_t off = 0; off < n; off += PLONK_MAX_LAUNCH) {
     const size_t m = n - off < (size_t)PLONK_MAX_LAUNCH ? n - off : (size_t)PLONK_MAX_LAUNCH;
+    auto t0 = now();
     std::vector<PlonkWork> work(m);
     std::vector<MsmTerm> terms(m * (size_t)(T1 > T2 ? T1 : T2));
     std::vector<uint8_t> flags(m * (size_t)(T1 > T2 ? T1 : T2), 0), st(m), inf(m);
@@ -394,6 +400,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
       work[i].lambda = lambda;
       work[i].status = plonk_stage1(key, proofs + (off + i) * proof_stride, proof_stride, public_inputs + (off + i) * n_public * 32, n_public, work[i], &terms[i * T1]);
     });
+    auto t1_ = now();
     // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
     HIPCK(hipMemcpy(d->terms, terms.data(), m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice));
     HIPCK(hipMemset(d->flags, 0, m * (size_t)T1));
@@ -402,6 +409,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     HIPCK(hipDeviceSynchronize());
     HIPCK(hipMemcpy(words.data(), d->words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIPCK(hipMemcpy(inf.data(), d->inf, m, hipMemcpyDeviceToHost));
+    auto t2_ = now();
     // ---- stage 2 on the host threads
     std::vector<MsmTerm> t1(m * 2);
     memset(t1.data(), 0, t1.size() * sizeof(MsmTerm));
@@ -415,6 +423,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
         st[i] = (uint8_t)work[i].status;
       }
     });
+    auto t3_ = now();
     // ---- P0, P1 and the pairing check on the GPU
     HIPCK(hipMemcpy(d->status, st.data(), m, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(d->terms, terms.data(), m * T2 * sizeof(MsmTerm), hipMemcpyHostToDevice));
@@ -429,6 +438,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
     HIPCK(hipDeviceSynchronize());
     HIPCK(hipMemcpy(status + off, d->status, m, hipMemcpyDeviceToHost));
+    if (timing) fprintf(stderr, "plonk batch %zu: stage1 %.2f ms, msm1 %.2f ms, stage2 %.2f ms, msm2+pairing %.2f ms\n", m, ms(t0, t1_), ms(t1_, t2_), ms(t2_, t3_), ms(t3_, now()));
   }
   return BN254_OK;
 }

@@ -32,6 +32,18 @@ struct DevWs {
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t row_bytes;  // n * 4: one row per (element, limb)
   uint32_t voff;       // lane * 4
+  int32_t* lds = nullptr;  // parking space of the operations that fuse two Fp12 products (72 dwords per lane, lane-interleaved)
+  __device__ __forceinline__ void park(int slot, const Fp2& a) const {
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+  }
+  __device__ __forceinline__ Fp2 unpark(int slot) const {
+    Fp2 r;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x]; }
+    BN_SETB(r.c0, 3.0, 0.5); BN_SETB(r.c1, 3.0, 0.5);
+    return r;
+  }
   __device__ __forceinline__ DevWs(int32_t* base, uint32_t n, uint32_t lane) {
     uint64_t b = (uint64_t)base;
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
@@ -96,6 +108,16 @@ __global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed(int32_t* ws, uint
   VM_KERNEL_PROLOGUE();
   FixedLine l; l.m = uni_ld2(entry); l.c = uni_ld2(entry + 2 * BN_NL); l.xc = uni_ld2(entry + 4 * BN_NL);
   vm_f12_mul_line_fixed(w, e, l, e_px, (st & inf_mask) != 0);  // inf_mask: the status bit that marks this pair's G1 point as the identity
+}
+__global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed2(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, const int32_t* __restrict__ entry0,
+                                                                int e_px0, int inf_mask0, const int32_t* __restrict__ entry1, int e_px1, int inf_mask1) {
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  FixedLine l0, l1;
+  l0.m = uni_ld2(entry0); l0.c = uni_ld2(entry0 + 2 * BN_NL); l0.xc = uni_ld2(entry0 + 4 * BN_NL);
+  l1.m = uni_ld2(entry1); l1.c = uni_ld2(entry1 + 2 * BN_NL); l1.xc = uni_ld2(entry1 + 4 * BN_NL);
+  vm_f12_mul_line_fixed2(w, e, l0, e_px0, (st & inf_mask0) != 0, l1, e_px1, (st & inf_mask1) != 0);
 }
 __global__ void __launch_bounds__(256, 2) k_miller_dbl_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_miller_dbl_var(w, e_t, e, e_px);
@@ -488,7 +510,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -509,6 +531,10 @@ struct LaunchOps {
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
     BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, inf_mask[t]);
+  }
+  void f12_mul_line_fixed2(int e, int st_, int ep0, int ep1) {
+    BN_LAUNCH(KID_MUL_LINE_FIXED2, k_f12_mul_line_fixed2, ws, n, status, e, tab[0] + (size_t)st_ * FIXED_LINE_DWORDS, ep0, inf_mask[0],
+              tab[1] + (size_t)st_ * FIXED_LINE_DWORDS, ep1, inf_mask[1]);
   }
   void f12_mul(int d, int a, int b, bool conj_b = false) { BN_LAUNCH(KID_F12_MUL, k_f12_mul, ws, n, status, d, a, b, conj_b ? 1 : 0); }
   void f12_copy(int d, int a) { BN_LAUNCH(KID_F12_COPY, k_f12_copy, ws, n, status, d, a); }
@@ -620,8 +646,7 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   BN_LAUNCH(KID_VM_INIT, k_vm_init, ws, nn, (const uint8_t*)status);
   for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
     if (step_kinds_host()[st_] == 0 && st_ != 0) ops.f12_sqr(VE_F);
-    ops.f12_mul_line_fixed(VE_F, 0, st_, VE_LX);
-    ops.f12_mul_line_fixed(VE_F, 1, st_, VE_CX);
+    ops.f12_mul_line_fixed2(VE_F, st_, VE_LX, VE_CX);
   }
   vm_final_exp_program(ops);
   BN_LAUNCH(KID_COMPARE, k_g16_compare, ws, nn, status, target_one, reject_code);

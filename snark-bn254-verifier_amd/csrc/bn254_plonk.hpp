@@ -67,7 +67,7 @@ struct Sha256 {
 // ---------------------------------------------------------------- Fr in Montgomery form (4 x 64), host only
 struct FrM { uint64_t l[4]; };
 struct FrCtx {
-  uint64_t m[4], inv; FrM one, r2;
+  uint64_t m[4], inv; FrM one, r2, shift256;
   FrCtx() {
     for (int i = 0; i < 4; i++) m[i] = (uint64_t)BN_R_WORDS[2 * i] | ((uint64_t)BN_R_WORDS[2 * i + 1] << 32);
     uint64_t x = 1; for (int i = 0; i < 6; i++) x *= 2 - m[0] * x;   // m[0]^-1 mod 2^64 (Newton)
@@ -77,6 +77,7 @@ struct FrCtx {
     one = t;                                                         // 2^256 mod r
     for (int i = 0; i < 256; i++) t = dbl_mod(t);
     r2 = t;                                                          // 2^512 mod r
+    shift256 = mul(one, r2);                                         // Montgomery form of 2^256: (2^256 mod r) * R
   }
   bool geq_m(const FrM& a) const { for (int i = 3; i >= 0; i--) { if (a.l[i] > m[i]) return true; if (a.l[i] < m[i]) return false; } return true; }
   FrM sub_m(const FrM& a) const { FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)a.l[i] - m[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r; }
@@ -128,11 +129,22 @@ struct FrCtx {
     for (int i = 255; i >= 0; i--) { r = mul(r, r); if ((e[i / 64] >> (i % 64)) & 1) r = mul(r, a); }
     return r;
   }
-  // big-endian bytes of any length, reduced mod r (Fr::from_slice stores the raw value and every later operation is mod r; the
-  // challenges and hash_to_field reduce explicitly): Horner over the bytes
+  // big-endian bytes, reduced mod r (Fr::from_slice stores the raw value and every later operation is mod r; the challenges and
+  // hash_to_field reduce explicitly).  One Montgomery product per 32-byte block: mul(raw, r2) is exact for any raw < 2^256.
+  FrM from_be32(const uint8_t* b) const {
+    FrM raw;
+    for (int i = 0; i < 4; i++) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = v << 8 | b[(3 - i) * 8 + j]; raw.l[i] = v; }
+    return mul(raw, r2);
+  }
   FrM from_be_reduce(const uint8_t* b, size_t n) const {
-    FrM acc = {{0, 0, 0, 0}}, c256 = from_u64(256);
-    for (size_t i = 0; i < n; i++) acc = add(mul(acc, c256), from_u64(b[i]));
+    if (n == 32) return from_be32(b);
+    uint8_t pad[32];
+    FrM acc = {{0, 0, 0, 0}};
+    // Horner over 32-byte blocks from the most significant end; the first block may be short
+    size_t first = n % 32 ? n % 32 : 32;
+    memset(pad, 0, 32); memcpy(pad + 32 - first, b, first);
+    acc = from_be32(pad);
+    for (size_t off = first; off < n; off += 32) acc = add(mul(acc, shift256), from_be32(b + off));
     return acc;
   }
   void to_be(uint8_t out[32], const FrM& a) const {
@@ -150,6 +162,7 @@ struct PlonkKey {
   G1Aff s[3], ql, qr, qm, qo, qk, qcp[PLONK_MAX_QCP]; uint32_t n_qcp;
   G1Aff kzg_g1; G2Aff kzg_g2[2];
   uint64_t cci[PLONK_MAX_QCP]; uint64_t n_cci;
+  FrM wpow[PLONK_MAX_QCP];             // generator^(nb_public + cci[i]): the evaluation point of the i-th BSB22 Lagrange term
   uint8_t enc[8 + PLONK_MAX_QCP][64];  // uncompressed encodings of s1..3, ql, qr, qm, qo, qk, qcp[]: what the transcript binds
 };
 inline uint64_t be64(const uint8_t* b) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = v << 8 | b[i]; return v; }
@@ -176,7 +189,7 @@ inline int parse_plonk_vk(PlonkKey& vk, const uint8_t* b, size_t n) {
   off += 160 + 33788;
   vk.n_cci = be64(b + off); off += 8;
   if (vk.n_cci > PLONK_MAX_QCP || n < off + 8 * vk.n_cci) return DEC_MALFORMED;
-  for (uint64_t i = 0; i < vk.n_cci; i++, off += 8) vk.cci[i] = be64(b + off);
+  for (uint64_t i = 0; i < vk.n_cci; i++, off += 8) { vk.cci[i] = be64(b + off); vk.wpow[i] = F.pow_u64(vk.generator, vk.nb_public + vk.cci[i]); }
   return DEC_OK;
 }
 struct PlonkProof {
@@ -289,23 +302,42 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
   FrM zh_zeta = F.sub(zeta_n, one);
   FrM zm1 = F.sub(zeta, one);
   if (F.is_zero(zm1)) return PL_INVERSE;
-  FrM lagrange_one = F.mul(F.mul(F.inverse(zm1), zh_zeta), vk.size_inv);
-  // verify.rs:109-137: PI = sum_i L_i(zeta) w_i (batch_invert leaves zeros alone)
+  // every inversion of the proof in one (Montgomery's trick): zeta - 1, zeta - omega^i (public inputs), zeta - omega^(n_pub + cci)
+  // (BSB22).  A zero denominator keeps the reference's behaviour: batch_invert leaves zeros alone (verify.rs:377,389) and the
+  // BSB22 division by zero gives zero.
+  FrM den[2 + 64 + PLONK_MAX_QCP], pre[2 + 64 + PLONK_MAX_QCP], inv[2 + 64 + PLONK_MAX_QCP];
+  bool zero[2 + 64 + PLONK_MAX_QCP];
+  int nden = 0;
+  den[nden++] = zm1;
+  const size_t n_in = n_inputs <= 64 ? n_inputs : 64;   // larger public-input counts fall back to per-term inversions below
+  {
+    FrM accw = one;
+    for (size_t i = 0; i < n_in; i++) { den[nden++] = F.sub(zeta, accw); accw = F.mul(accw, vk.generator); }
+  }
+  for (uint64_t i = 0; i < vk.n_cci; i++) den[nden++] = F.sub(zeta, vk.wpow[i]);
+  {
+    FrM acc = one;
+    for (int i = 0; i < nden; i++) { zero[i] = F.is_zero(den[i]); pre[i] = acc; if (!zero[i]) acc = F.mul(acc, den[i]); }
+    FrM ai = F.inverse(acc);
+    for (int i = nden - 1; i >= 0; i--) {
+      if (zero[i]) { inv[i] = den[i]; continue; }
+      inv[i] = F.mul(ai, pre[i]); ai = F.mul(ai, den[i]);
+    }
+  }
+  FrM lagrange_one = F.mul(F.mul(inv[0], zh_zeta), vk.size_inv);
+  // verify.rs:109-137: PI = sum_i L_i(zeta) w_i
   FrM pi = {{0, 0, 0, 0}}, accw = one;
+  const FrM zs = F.mul(zh_zeta, vk.size_inv);
   for (size_t i = 0; i < n_inputs; i++) {
-    FrM den = F.sub(zeta, accw);
-    FrM inv = F.is_zero(den) ? den : F.inverse(den);
-    FrM x = F.mul(F.mul(F.mul(zh_zeta, inv), vk.size_inv), accw);
-    x = F.mul(x, F.from_be_reduce(inputs + 32 * i, 32));
+    FrM iv = i < n_in ? inv[1 + i] : (F.is_zero(F.sub(zeta, accw)) ? F.sub(zeta, accw) : F.inverse(F.sub(zeta, accw)));
+    FrM x = F.mul(F.mul(F.mul(zs, iv), accw), F.from_be32(inputs + 32 * i));
     accw = F.mul(accw, vk.generator);
     pi = F.add(pi, x);
   }
   // verify.rs:139-163: BSB22 commitments enter the public-input polynomial through hash_to_field
   for (uint64_t i = 0; i < vk.n_cci; i++) {
     FrM hashed = bsb22_hash_to_field(proof + pr.off_bsb + 64 * i);
-    FrM wpow = F.pow_u64(vk.generator, vk.nb_public + vk.cci[i]);
-    FrM den = F.sub(zeta, wpow);
-    FrM lag = F.mul(F.mul(F.mul(F.mul(zh_zeta, wpow), F.inverse(den)), vk.size_inv), hashed);
+    FrM lag = F.mul(F.mul(F.mul(zs, vk.wpow[i]), inv[1 + n_in + i]), hashed);
     pi = F.add(pi, lag);
   }
   // verify.rs:165-214: the constant term of the linearised polynomial must equal the claimed opening
@@ -336,7 +368,7 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
   _s2 = F.neg(F.mul(_s2, alpha));
   FrM coeff_z = F.add(a2l1, _s2);
   FrM rl = F.mul(l, r);
-  FrM zn2 = F.pow_u64(zeta, vk.size + 2);
+  FrM zn2 = F.mul(zeta_n, F.mul(zeta, zeta));                              // zeta^(n+2)
   FrM zn2sq = F.mul(zn2, zn2);
   zn2 = F.neg(F.mul(zn2, zh_zeta));
   zn2sq = F.neg(F.mul(zn2sq, zh_zeta));

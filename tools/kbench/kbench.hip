@@ -246,6 +246,57 @@ __global__ void __launch_bounds__(256, LFW) k_op(int32_t* base, uint32_t n) {
   st2(ws, 10, fp2_select(inf, k5, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2))));
 #endif
 }
+#elif defined(V_LF2)
+// two precomputed-line multiplications in one launch: f <- f * l1(P1) * l2(P2).  The intermediate product never goes to HBM:
+// four of its six coefficients are parked in LDS (72 dwords per lane, lane-interleaved: conflict-free), two stay in registers.
+__device__ __forceinline__ Fp uld(const int32_t* p) { Fp r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) r.v[l] = p[l];
+  return r; }
+__device__ __forceinline__ Fp2 uld2(const int32_t* p) { Fp2 r; r.c0 = uld(p); r.c1 = uld(p + 9); return r; }
+__device__ __forceinline__ void lds_put(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lds_get(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  __shared__ int32_t lds[72 * 256];
+  WS_SETUP
+  const int32_t* __restrict__ e1 = base + (size_t)n * 9 * 38;
+  const int32_t* __restrict__ e2 = e1 + 64;
+  Fp2 r4, r5;
+  {
+    FixedLine l; l.m = uld2(e1); l.c = uld2(e1 + 18); l.xc = uld2(e1 + 36);
+    Fp px = ws.ld(12), d0 = ws.ld(13);
+    Fp2 d3 = fp2_mul_fp(l.m, px);
+    Fp2 x3 = fp2_mul_xi(d3);
+    const Fp2 &d4 = l.c, &x4 = l.xc;
+    Fp2 k0 = ld2(ws, 0), k1 = ld2(ws, 2), k2 = ld2(ws, 4), k3 = ld2(ws, 6), k4 = ld2(ws, 8), k5 = ld2(ws, 10);
+    lds_put(lds, 0, fp2_dot_line(d0, k0, x3, k5, x4, k3));
+    lds_put(lds, 1, fp2_dot_line(d0, k1, d3, k0, x4, k4));
+    lds_put(lds, 2, fp2_dot_line(d0, k2, d3, k1, x4, k5));
+    lds_put(lds, 3, fp2_dot_line(d0, k3, d3, k2, d4, k0));
+    r4 = fp2_dot_line(d0, k4, d3, k3, d4, k1);
+    r5 = fp2_dot_line(d0, k5, d3, k4, d4, k2);
+  }
+  {
+    FixedLine l; l.m = uld2(e2); l.c = uld2(e2 + 18); l.xc = uld2(e2 + 36);
+    Fp px = ws.ld(14), d0 = ws.ld(15);
+    Fp2 d3 = fp2_mul_fp(l.m, px);
+    Fp2 x3 = fp2_mul_xi(d3);
+    const Fp2 &d4 = l.c, &x4 = l.xc;
+    Fp2 k0 = lds_get(lds, 0), k1 = lds_get(lds, 1), k2 = lds_get(lds, 2), k3 = lds_get(lds, 3), k4 = r4, k5 = r5;
+    st2(ws, 0, fp2_dotk(kfp(k0, d0), kp(x3, k5), kp(x4, k3)));
+    st2(ws, 2, fp2_dotk(kfp(k1, d0), kp(d3, k0), kp(x4, k4)));
+    st2(ws, 4, fp2_dotk(kfp(k2, d0), kp(d3, k1), kp(x4, k5)));
+    st2(ws, 6, fp2_dotk(kfp(k3, d0), kp(d3, k2), kp(d4, k0)));
+    st2(ws, 8, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1)));
+    st2(ws, 10, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2)));
+  }
+}
 #elif defined(V_COPY)
 __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
   WS_SETUP
