@@ -122,6 +122,12 @@ __global__ void __launch_bounds__(256, 2) k_f12_mul_line_fixed2(int32_t* ws, uin
 __global__ void __launch_bounds__(256, 2) k_miller_dbl_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_miller_dbl_var(w, e_t, e, e_px);
 }
+__global__ void __launch_bounds__(256, 2) k_miller_sqr_dbl_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_px) {
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  vm_miller_sqr_dbl_var(w, e_t, e, e_px);
+}
 __global__ void __launch_bounds__(256, 2) k_miller_add_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_b, int which, int e, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_miller_add_var(w, e_t, e_b, which, e, e_px);
 }
@@ -510,7 +516,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -528,6 +534,7 @@ struct LaunchOps {
   int uni(int x) { return x; }
   void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
   void miller_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_DBL_VAR, k_miller_dbl_var, ws, n, status, et, e, ep); }
+  void miller_sqr_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_SQR_DBL_VAR, k_miller_sqr_dbl_var, ws, n, status, et, e, ep); }
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
     BN_LAUNCH(KID_MUL_LINE_FIXED, k_f12_mul_line_fixed, ws, n, status, e, tab[t] + (size_t)st_ * FIXED_LINE_DWORDS, ep, inf_mask[t]);

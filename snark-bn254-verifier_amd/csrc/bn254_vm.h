@@ -130,6 +130,42 @@ BN_HD void vm_miller_add_var(W& w, int e_t, int e_b, int which, int e, int e_px)
   vm_f12_mul_line_regs(w, e, l, e_px);
 }
 
+// ---- fused doubling step: f <- f^2, T <- 2T, f <- f * line(P).  f^2 is not written back: four coefficients are parked (w.park),
+// two stay in registers across the G2 doubling, then the line product consumes them.
+template <class W>
+BN_HD void vm_miller_sqr_dbl_var(W& w, int e_t, int e, int e_px) {
+  Fp2 r4, r5;
+  {
+    Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+    Fp2 x3 = fp2_mul_xi(k3), x4 = fp2_mul_xi(k4), x5 = fp2_mul_xi(k5);
+    w.park(0, fp2_dotp(pp(k0, k0), pp2(k1, x5), pp2(k2, x4), pp(k3, x3)));
+    w.park(1, fp2_dotp(pp2(k0, k1), pp2(k2, x5), pp2(k3, x4)));
+    w.park(2, fp2_dotp(pp2(k0, k2), pp(k1, k1), pp2(k3, x5), pp(k4, x4)));
+    w.park(3, fp2_dotp(pp2(k0, k3), pp2(k1, k2), pp2(k4, x5)));
+    r4 = fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5));
+    r5 = fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3));
+  }
+  G2Line l;
+  {
+    G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+    l = g2_double_step(t);
+    vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  }
+  BN_SCHED_FENCE();  // keep the parked coefficients out of the registers until the G2 step is done
+  Fp px = w.ld(e_px), py = w.ld(e_px + 1);
+  Fp2 d0 = fp2_mul_fp(l.r0, py), d3 = fp2_mul_fp(l.r1, px), d4 = l.r2;
+  Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
+  BN_SCHED_FENCE();
+  Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3);
+  const Fp2 &k4 = r4, &k5 = r5;
+  vst2(w, e, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3)));
+  vst2(w, e + 2, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4)));
+  vst2(w, e + 4, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5)));
+  vst2(w, e + 6, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0)));
+  vst2(w, e + 8, fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1)));
+  vst2(w, e + 10, fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2)));
+}
+
 // ---- r-torsion test of B from the point the Miller loop has already computed ----------------------------------------------------------
 // After vm_miller_program the running point is T = [6u+2]B + psi(B) - psi^2(B).  For B on the twist E'(Fp2):
 //     B in G2  <=>  T == -psi^3(B)          (T finite)
@@ -271,7 +307,7 @@ BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS
   // f = 1, T = B are set by the caller
   for (int s = 0; s < BN_ATE_STEPS; s++) {
     int kind = ops.uni(step_kinds[s]);
-    if (kind == 0) { if (s != 0) ops.f12_sqr(VE_F); ops.miller_dbl_var(VE_T, VE_F, VE_AX); }
+    if (kind == 0) { if (s != 0) ops.miller_sqr_dbl_var(VE_T, VE_F, VE_AX); else ops.miller_dbl_var(VE_T, VE_F, VE_AX); }
     else ops.miller_add_var(VE_T, VE_B, kind - 1, VE_F, VE_AX);
     if (with_fixed_pairs) ops.f12_mul_line_fixed2(VE_F, s, VE_LX, VE_CX);  // tables 0 (paired with L) and 1 (paired with C), step s
   }
