@@ -36,6 +36,8 @@ KERNEL_ALGO_BYTES = {
     "k_f12_sqr": 2 * 432, "k_f12_cyclo_sqr": 2 * 432, "k_f12_cyclo_sqr_n": 2 * 432, "k_f12_conj": 2 * 432, "k_f12_copy": 2 * 432, "k_f12_frob": 2 * 432, "k_f12_inv": 2 * 432,
     "k_f12_mul_line_fixed": 2 * 432 + 72,        # f in/out, G1 point (the line table entry is wave-uniform: scalar loads)
     "k_f12_mul_line_fixed2": 2 * 432 + 2 * 72,   # f in/out, two G1 points
+    "k_miller_step_dbl": 2 * 432 + 2 * 216 + 3 * 72,            # f, T in/out, three G1 points
+    "k_miller_step_add": 2 * 432 + 2 * 216 + 144 + 3 * 72,      # + Q in
     "k_miller_sqr_dbl_var": 2 * 432 + 2 * 216 + 72,
     "k_miller_dbl_var": 2 * 432 + 2 * 216 + 72, "k_miller_add_var": 2 * 432 + 2 * 216 + 144 + 72,   # f, T in/out (, Q), G1 point
     "k_g16_prepare": 321 + 10 * 36, "k_g16_subgroup": 144, "k_vm_init": 432 + 216, "k_g16_compare": 432 + 1,

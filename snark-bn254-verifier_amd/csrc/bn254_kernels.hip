@@ -128,6 +128,32 @@ __global__ void __launch_bounds__(256, 2) k_miller_sqr_dbl_var(int32_t* ws, uint
   w.lds = park_lds;
   vm_miller_sqr_dbl_var(w, e_t, e, e_px);
 }
+// the whole Miller step of the three pairs (bn254_vm.h::vm_miller_step): doubling steps (with the squaring of f, except the first)
+// and addition steps as two kernels so that each carries only its own G2 formulas
+template <bool DO_SQR>
+__global__ void __launch_bounds__(256, 2) k_miller_step_dbl(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_pa,
+                                                            const int32_t* __restrict__ entry0, int e_p0, int inf_mask0,
+                                                            const int32_t* __restrict__ entry1, int e_p1, int inf_mask1) {
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  FixedLine l0, l1;
+  l0.m = uni_ld2(entry0); l0.c = uni_ld2(entry0 + 2 * BN_NL); l0.xc = uni_ld2(entry0 + 4 * BN_NL);
+  l1.m = uni_ld2(entry1); l1.c = uni_ld2(entry1 + 2 * BN_NL); l1.xc = uni_ld2(entry1 + 4 * BN_NL);
+  vm_miller_step<DO_SQR>(w, 0, e_t, 0, e, e_pa, l0, e_p0, (st & inf_mask0) != 0, l1, e_p1, (st & inf_mask1) != 0);
+}
+__global__ void __launch_bounds__(256, 2) k_miller_step_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int kind, int e_t, int e_b, int e, int e_pa,
+                                                            const int32_t* __restrict__ entry0, int e_p0, int inf_mask0,
+                                                            const int32_t* __restrict__ entry1, int e_p1, int inf_mask1) {
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  FixedLine l0, l1;
+  l0.m = uni_ld2(entry0); l0.c = uni_ld2(entry0 + 2 * BN_NL); l0.xc = uni_ld2(entry0 + 4 * BN_NL);
+  l1.m = uni_ld2(entry1); l1.c = uni_ld2(entry1 + 2 * BN_NL); l1.xc = uni_ld2(entry1 + 4 * BN_NL);
+  int k = __builtin_amdgcn_readfirstlane(kind);
+  vm_miller_step<false>(w, k < 1 ? 1 : k, e_t, e_b, e, e_pa, l0, e_p0, (st & inf_mask0) != 0, l1, e_p1, (st & inf_mask1) != 0);
+}
 __global__ void __launch_bounds__(256, 2) k_miller_add_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_b, int which, int e, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_miller_add_var(w, e_t, e_b, which, e, e_px);
 }
@@ -516,7 +542,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var", "k_miller_step_dbl", "k_miller_step_add"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -534,6 +560,12 @@ struct LaunchOps {
   int uni(int x) { return x; }
   void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
   void miller_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_DBL_VAR, k_miller_dbl_var, ws, n, status, et, e, ep); }
+  void miller_step(bool do_sqr, int kind, int st_, int et, int eb, int e, int epa, int ep0, int ep1) {
+    const int32_t *t0 = tab[0] + (size_t)st_ * FIXED_LINE_DWORDS, *t1 = tab[1] + (size_t)st_ * FIXED_LINE_DWORDS;
+    if (kind == 0 && do_sqr) BN_LAUNCH(KID_MILLER_STEP_DBL, k_miller_step_dbl<true>, ws, n, status, et, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
+    else if (kind == 0) BN_LAUNCH(KID_MILLER_STEP_DBL, k_miller_step_dbl<false>, ws, n, status, et, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
+    else BN_LAUNCH(KID_MILLER_STEP_ADD, k_miller_step_add, ws, n, status, kind, et, eb, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
+  }
   void miller_sqr_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_SQR_DBL_VAR, k_miller_sqr_dbl_var, ws, n, status, et, e, ep); }
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {

@@ -166,6 +166,83 @@ BN_HD void vm_miller_sqr_dbl_var(W& w, int e_t, int e, int e_px) {
   vst2(w, e + 10, fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2)));
 }
 
+// ---- one whole Miller step in one operation: [f <- f^2,] T <- 2T or T + Q, f <- f * line_T(A) * line_0(P0) * line_1(P1) ------------
+// Between the stages f travels "in flight": coefficients k0..k3 parked (w.park / w.unpark: LDS on the GPU), k4 and k5 in registers;
+// only the last product writes f back to the workspace.  Every stage reads slot j before it overwrites it (each output
+// coefficient r_j depends on the input coefficient k_j), so the four slots can be reused in place.
+// kind: 0 doubling, 1..4 addition of +B, -B, psi(B), -psi^2(B).
+template <bool DO_SQR, class W>
+BN_HD void vm_miller_step(W& w, int kind, int e_t, int e_b, int e, int e_pa, const FixedLine& l0, int e_p0, bool inf0,
+                          const FixedLine& l1, int e_p1, bool inf1) {
+  Fp2 f4, f5;
+  if constexpr (DO_SQR) {
+    Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+    Fp2 x3 = fp2_mul_xi(k3), x4 = fp2_mul_xi(k4), x5 = fp2_mul_xi(k5);
+    w.park(0, fp2_dotp(pp(k0, k0), pp2(k1, x5), pp2(k2, x4), pp(k3, x3)));
+    w.park(1, fp2_dotp(pp2(k0, k1), pp2(k2, x5), pp2(k3, x4)));
+    w.park(2, fp2_dotp(pp2(k0, k2), pp(k1, k1), pp2(k3, x5), pp(k4, x4)));
+    w.park(3, fp2_dotp(pp2(k0, k3), pp2(k1, k2), pp2(k4, x5)));
+    f4 = fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5));
+    f5 = fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3));
+  }
+  G2Line l;
+  {
+    G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+    if (kind == 0) {
+      l = g2_double_step(t);
+    } else {
+      G2Aff q; q.x = vld2(w, e_b); q.y = vld2(w, e_b + 2);
+      if (kind == 2) q = g2_neg(q);
+      else if (kind == 3) q = g2_psi_affine(q);
+      else if (kind == 4) q = g2_neg(g2_psi2_affine(q));
+      l = g2_add_step(t, q);
+    }
+    vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  }
+  {  // the variable pair's line
+    Fp px = w.ld(e_pa), py = w.ld(e_pa + 1);
+    Fp2 d0 = fp2_mul_fp(l.r0, py), d3 = fp2_mul_fp(l.r1, px), d4 = l.r2;
+    Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
+    Fp2 k0, k1, k2, k3, k4, k5;
+    if constexpr (DO_SQR) { k0 = w.unpark(0); k1 = w.unpark(1); k2 = w.unpark(2); k3 = w.unpark(3); k4 = f4; k5 = f5; }
+    else { k0 = vld2(w, e); k1 = vld2(w, e + 2); k2 = vld2(w, e + 4); k3 = vld2(w, e + 6); k4 = vld2(w, e + 8); k5 = vld2(w, e + 10); }
+    w.park(0, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3)));
+    w.park(1, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4)));
+    w.park(2, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5)));
+    w.park(3, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0)));
+    Fp2 n4 = fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1));
+    f5 = fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2));
+    f4 = n4;
+  }
+  {  // first key-side line: plain dot products (the two in-flight coefficients leave no room for the Karatsuba operand sums)
+    Fp px = w.ld(e_p0), d0 = w.ld(e_p0 + 1);
+    Fp2 d3 = fp2_mul_fp(l0.m, px);
+    Fp2 x3 = fp2_mul_xi(d3);
+    const Fp2 &d4 = l0.c, &x4 = l0.xc;
+    Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3), k4 = f4, k5 = f5;
+    w.park(0, fp2_select(inf0, k0, fp2_dot_line(d0, k0, x3, k5, x4, k3)));
+    w.park(1, fp2_select(inf0, k1, fp2_dot_line(d0, k1, d3, k0, x4, k4)));
+    w.park(2, fp2_select(inf0, k2, fp2_dot_line(d0, k2, d3, k1, x4, k5)));
+    w.park(3, fp2_select(inf0, k3, fp2_dot_line(d0, k3, d3, k2, d4, k0)));
+    f4 = fp2_select(inf0, k4, fp2_dot_line(d0, k4, d3, k3, d4, k1));
+    f5 = fp2_select(inf0, k5, fp2_dot_line(d0, k5, d3, k4, d4, k2));
+  }
+  {  // second key-side line: Karatsuba dot products, result to the workspace
+    Fp px = w.ld(e_p1), d0 = w.ld(e_p1 + 1);
+    Fp2 d3 = fp2_mul_fp(l1.m, px);
+    Fp2 x3 = fp2_mul_xi(d3);
+    const Fp2 &d4 = l1.c, &x4 = l1.xc;
+    Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3);
+    const Fp2 &k4 = f4, &k5 = f5;
+    vst2(w, e, fp2_select(inf1, k0, fp2_dotk(kfp(k0, d0), kp(x3, k5), kp(x4, k3))));
+    vst2(w, e + 2, fp2_select(inf1, k1, fp2_dotk(kfp(k1, d0), kp(d3, k0), kp(x4, k4))));
+    vst2(w, e + 4, fp2_select(inf1, k2, fp2_dotk(kfp(k2, d0), kp(d3, k1), kp(x4, k5))));
+    vst2(w, e + 6, fp2_select(inf1, k3, fp2_dotk(kfp(k3, d0), kp(d3, k2), kp(d4, k0))));
+    vst2(w, e + 8, fp2_select(inf1, k4, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1))));
+    vst2(w, e + 10, fp2_select(inf1, k5, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2))));
+  }
+}
+
 // ---- r-torsion test of B from the point the Miller loop has already computed ----------------------------------------------------------
 // After vm_miller_program the running point is T = [6u+2]B + psi(B) - psi^2(B).  For B on the twist E'(Fp2):
 //     B in G2  <=>  T == -psi^3(B)          (T finite)
@@ -307,9 +384,13 @@ BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS
   // f = 1, T = B are set by the caller
   for (int s = 0; s < BN_ATE_STEPS; s++) {
     int kind = ops.uni(step_kinds[s]);
+    if (with_fixed_pairs) {
+      // the whole step is one operation: [squaring,] G2 step, variable line, both key-side lines (tables 0 / 1, step s)
+      ops.miller_step(kind == 0 && s != 0, kind, s, VE_T, VE_B, VE_F, VE_AX, VE_LX, VE_CX);
+      continue;
+    }
     if (kind == 0) { if (s != 0) ops.miller_sqr_dbl_var(VE_T, VE_F, VE_AX); else ops.miller_dbl_var(VE_T, VE_F, VE_AX); }
     else ops.miller_add_var(VE_T, VE_B, kind - 1, VE_F, VE_AX);
-    if (with_fixed_pairs) ops.f12_mul_line_fixed2(VE_F, s, VE_LX, VE_CX);  // tables 0 (paired with L) and 1 (paired with C), step s
   }
 }
 // x^u on the cyclotomic subgroup: dst <- src^u (dst != src), width-4 signed windows of u (BN_U_W4: digits +-1, +-3, +-5, +-7).
