@@ -3,9 +3,9 @@
 // Pipeline per batch (DESIGN.md "Kernels"):
 //   k_g16_prepare     parse 256 proof bytes (coalesced through LDS), range / on-curve checks of A, B, C, Montgomery
 //                     conversion, L = K0 + sum x_i K_i by fixed-base 8-bit windows      (groth16/converter.rs:14-26, verify.rs:53-63)
-//   k_vm_init, k_f12_sqr, k_miller_dbl_var, k_miller_add_var, k_f12_mul_line_fixed
-//                     the shared Miller loop f = Miller(A,B) * lines_G(L) * lines_D(C), one launch per Fp12-level
-//                     operation of bn254_vm.h::vm_miller_program; G/D line tables shared by the batch  (verify.rs:73-77)
+//   k_vm_init, k_miller_step_dbl, k_miller_step_add
+//                     the shared Miller loop f = Miller(A,B) * lines_G(L) * lines_D(C), one launch per STEP (squaring, G2 step,
+//                     three line products; bn254_vm.h::vm_miller_step); G/D line tables shared by the batch  (verify.rs:73-77)
 //   k_g16_subgroup    r-torsion test of B from the loop's final G2 point, status precedence   (converter.rs:152)
 //   k_f12_inv, k_f12_conj, k_f12_frob, k_f12_mul, k_f12_cyclo_sqr(_n), k_f12_copy
 //                     f^((p^12-1)/r), bn254_vm.h::vm_final_exp_program                          (verify.rs:77)
@@ -18,7 +18,7 @@
 // check returns 0 for their loads and drops their stores.
 //
 // Every operation is its own kernel: it gets the full 256-VGPR budget of a 2-waves-per-SIMD launch and keeps nothing in
-// registers between operations.  The host walks the program (LaunchOps below) and enqueues ~500 launches per batch.
+// registers between operations.  The host walks the program (LaunchOps below) and enqueues ~210 launches per batch.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "bn254_vm.h"

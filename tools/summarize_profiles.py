@@ -9,7 +9,10 @@ out = os.path.join(root, "profiles")
 
 
 def short(name):
-    return name.split("(")[0].replace("bn254::", "").strip()
+    n = name.split("(")[0].replace("bn254::", "").strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0].strip()   # template instances (k_miller_step_dbl<true> / <false>) count as one kernel kind
 
 
 # ---- kernel trace: per-kernel calls / total / average (ns) from the raw trace (the --stats file carries the same numbers)
