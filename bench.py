@@ -11,10 +11,10 @@ For N > 1 every rank verifies its own 2^20-proof shard of an N * 2^20 batch (wea
 After the timed region the statuses are compared with the generator's expected statuses: a wrong answer aborts the bench.
 
 One JSON line on rank 0, with `roofline` for the dominant kernel -- the kernel kind with the largest summed duration over a
-batch (k_f12_mul, the general Fp12 product of the final exponentiation, on this code) -- whose launches are bracketed by HIP
-events on their launch stream INSIDE the timed region, and `cpu_baseline` (the CPU oracle = C port of the reference algorithm,
+batch (k_miller_step_dbl, one whole doubling step of the shared Miller loop, on this code) -- whose launches are bracketed by
+HIP events on their launch stream INSIDE the timed region, and `cpu_baseline` (the CPU oracle = C port of the reference algorithm,
 timed on this box's host cores on a bounded sample; rank 0, N = 1 only).  The last warm-up step brackets every launch of every
-kernel kind instead (`kernels_ms`, informational; ~1400 event records, outside the timed region).
+kernel kind instead (`kernels_ms`, informational; ~420 event records, outside the timed region).
 """
 import argparse
 import importlib
