@@ -405,6 +405,18 @@ def test_batch_65536_expected_statuses(pkg, L):
     pvk.close()
 
 
+def test_full_size_batch_two_chunks(pkg, L):
+    """BASELINE's full batch size and beyond: 2^20 + 777 proofs run as two workspace chunks (and sub-batch streams); the status
+    vector must be the generator's (every 16th proof invalid, cycling through the five failure classes)."""
+    n = (1 << 20) + 777
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540077, 2, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert len(st) == n and st == exp
+    assert st.count(bytes([pkg.ACCEPT])) == n - n // 16
+    pvk.close()
+
+
 def test_more_public_inputs(pkg, O, L):
     """nPublic = 5: a different key shape through the same kernels (window tables per input)."""
     n = 40
