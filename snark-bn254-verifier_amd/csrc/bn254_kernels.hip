@@ -158,7 +158,10 @@ __global__ void __launch_bounds__(256, 2) k_miller_add_var(int32_t* ws, uint32_t
   VM_KERNEL_PROLOGUE(); vm_miller_add_var(w, e_t, e_b, which, e, e_px);
 }
 __global__ void __launch_bounds__(256, 2) k_f12_mul(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a, int b, int conj_b) {
-  VM_KERNEL_PROLOGUE(); vm_f12_mul(w, d, a, b, conj_b != 0);
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  vm_f12_mul(w, d, a, b, conj_b != 0);
 }
 __global__ void __launch_bounds__(256, 2) k_f12_copy(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_copy(w, d, a); }
 __global__ void __launch_bounds__(256, 2) k_f12_cyclo_sqr(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int d, int a) { VM_KERNEL_PROLOGUE(); vm_f12_cyclo_sqr(w, d, a); }

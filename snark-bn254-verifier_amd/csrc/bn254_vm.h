@@ -262,15 +262,20 @@ BN_HD bool vm_g2_ate_check(W& w, int e_t, int e_b) {
   return !fp2_is_zero(Z) & fp2_eq(X, fp2_mul(sx, Z)) & fp2_eq(Y, fp2_mul(sy, Z));
 }
 
-// ---- general Fp12 product dst <- a * b (dst may alias a or b), Karatsuba over Fp6 with two workspace temporaries ----------------------
+// ---- general Fp12 product dst <- a * b (dst may alias a or b), Karatsuba over Fp6; temporaries: 4 parking slots + 2 workspace Fp2 ----------------------
 // tower halves in k-order storage: c0 = (k0, k2, k4), c1 = (k1, k3, k5)
 template <class W> BN_HD Fp6 vld_half(W& w, int e, int h) { Fp6 r; r.c0 = vld2(w, e + 2 * h); r.c1 = vld2(w, e + 4 + 2 * h); r.c2 = vld2(w, e + 8 + 2 * h); return r; }
 template <class W> BN_HD void vst_half(W& w, int e, int h, const Fp6& a) { vst2(w, e + 2 * h, a.c0); vst2(w, e + 4 + 2 * h, a.c1); vst2(w, e + 8 + 2 * h, a.c2); }
 // conj_b: multiply by conj(b) = b^(p^6) (the inverse of b on the cyclotomic subgroup): the odd half of b is negated on load
 template <class W>
 BN_HD void vm_f12_mul(W& w, int e_dst, int e_a, int e_b, bool conj_b = false) {
-  { Fp6 v0 = fp6_mul(vld_half(w, e_a, 0), vld_half(w, e_b, 0)); vst6(w, VE_TMPA, v0); }
-  { Fp6 b1 = vld_half(w, e_b, 1); if (conj_b) b1 = fp6_neg(b1); Fp6 v1 = fp6_mul(vld_half(w, e_a, 1), b1); vst6(w, VE_TMPB, v1); }
+  // v0 = a0 b0 and the first coefficient of v1 = a1 b1 wait in the parking slots (LDS), the rest of v1 in a workspace temporary
+  { Fp6 v0 = fp6_mul(vld_half(w, e_a, 0), vld_half(w, e_b, 0)); w.park(0, v0.c0); w.park(1, v0.c1); w.park(2, v0.c2); }
+  {
+    Fp6 b1 = vld_half(w, e_b, 1); if (conj_b) b1 = fp6_neg(b1);
+    Fp6 v1 = fp6_mul(vld_half(w, e_a, 1), b1);
+    w.park(3, v1.c0); vst2(w, VE_TMPB + 2, v1.c1); vst2(w, VE_TMPB + 4, v1.c2);
+  }
   Fp6 s;
   {
     Fp6 sa = fp6_add(vld_half(w, e_a, 0), vld_half(w, e_a, 1));
@@ -278,7 +283,9 @@ BN_HD void vm_f12_mul(W& w, int e_dst, int e_a, int e_b, bool conj_b = false) {
     Fp6 sb = fp6_add(vld_half(w, e_b, 0), b1);
     s = fp6_mul(sa, sb);
   }
-  Fp6 v0 = vld6(w, VE_TMPA), v1 = vld6(w, VE_TMPB);
+  Fp6 v0, v1;
+  v0.c0 = w.unpark(0); v0.c1 = w.unpark(1); v0.c2 = w.unpark(2);
+  v1.c0 = w.unpark(3); v1.c1 = vld2(w, VE_TMPB + 2); v1.c2 = vld2(w, VE_TMPB + 4);
   Fp6 c0, c1;
   c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
   c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);

@@ -165,12 +165,12 @@ __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
 #endif
   base[(size_t)n * 9 * 30 + blockIdx.x * 256 + threadIdx.x] = ok;
 }
-#elif defined(V_MUL_OLD) || defined(V_MUL_K)
+#elif defined(V_MUL_OLD) || defined(V_MUL_K) || defined(V_MUL_L)
 __device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
 __device__ __forceinline__ void sth(const Ws& w, int e, int h, const Fp6& a) { st2(w, e + 2 * h, a.c0); st2(w, e + 4 + 2 * h, a.c1); st2(w, e + 8 + 2 * h, a.c2); }
 __device__ __forceinline__ Fp6 ld6(const Ws& w, int e) { Fp6 r; r.c0 = ld2(w, e); r.c1 = ld2(w, e + 2); r.c2 = ld2(w, e + 4); return r; }
 __device__ __forceinline__ void st6(const Ws& w, int e, const Fp6& a) { st2(w, e, a.c0); st2(w, e + 2, a.c1); st2(w, e + 4, a.c2); }
-#ifdef V_MUL_K
+#if defined(V_MUL_K) || defined(V_MUL_L)
 __device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
   Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
   Fp6 r;
@@ -183,10 +183,27 @@ __device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
 #else
 #define F6MUL fp6_mul
 #endif
+#ifdef V_MUL_L
+__device__ __forceinline__ void lput(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lget(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+#endif
 __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+#ifdef V_MUL_L
+  __shared__ int32_t lds[54 * 256];
+#endif
   WS_SETUP
   const int e_a = 0, e_b = 12, e_dst = 0, TA = 24, TB = 30;
+#ifdef V_MUL_L
+  { Fp6 v0 = F6MUL(ldh(ws, e_a, 0), ldh(ws, e_b, 0)); lput(lds, 0, v0.c0); lput(lds, 1, v0.c1); lput(lds, 2, v0.c2); }
+#else
   { Fp6 v0 = F6MUL(ldh(ws, e_a, 0), ldh(ws, e_b, 0)); st6(ws, TA, v0); }
+#endif
   { Fp6 v1 = F6MUL(ldh(ws, e_a, 1), ldh(ws, e_b, 1)); st6(ws, TB, v1); }
   Fp6 s;
   {
@@ -194,108 +211,16 @@ __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
     Fp6 sb = fp6_add(ldh(ws, e_b, 0), ldh(ws, e_b, 1));
     s = F6MUL(sa, sb);
   }
+#ifdef V_MUL_L
+  Fp6 v0; v0.c0 = lget(lds, 0); v0.c1 = lget(lds, 1); v0.c2 = lget(lds, 2);
+  Fp6 v1 = ld6(ws, TB);
+#else
   Fp6 v0 = ld6(ws, TA), v1 = ld6(ws, TB);
+#endif
   Fp6 c0, c1;
   c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
   c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
   sth(ws, e_dst, 0, c0); sth(ws, e_dst, 1, c1);
-}
-#elif defined(V_LF_CUR) || defined(V_LF_K) || defined(V_LF_P)
-#ifndef LFW
-#define LFW 2
-#endif
-__device__ __forceinline__ Fp uld(const int32_t* p) { Fp r;
-#pragma unroll
-  for (int l = 0; l < 9; l++) r.v[l] = p[l];
-  return r; }
-__device__ __forceinline__ Fp2 uld2(const int32_t* p) { Fp2 r; r.c0 = uld(p); r.c1 = uld(p + 9); return r; }
-__global__ void __launch_bounds__(256, LFW) k_op(int32_t* base, uint32_t n) {
-  WS_SETUP
-  const int32_t* __restrict__ entry = base + (size_t)n * 9 * 38;
-  const bool inf = (base[(size_t)n * 9 * 37 + blockIdx.x * 256 + threadIdx.x] & 0xfffffff) == 0x1234567;  // per-lane flag, practically never set
-  FixedLine l; l.m = uld2(entry); l.c = uld2(entry + 18); l.xc = uld2(entry + 36);
-  Fp px = ws.ld(12), d0 = ws.ld(13);
-  Fp2 d3 = fp2_mul_fp(l.m, px);
-  Fp2 x3 = fp2_mul_xi(d3);
-  Fp2 k0 = ld2(ws, 0), k1 = ld2(ws, 2), k2 = ld2(ws, 4), k3 = ld2(ws, 6), k4 = ld2(ws, 8), k5 = ld2(ws, 10);
-#if defined(V_LF_CUR)
-  Fp2 z = fp2_zero();
-  Fp2 d4 = fp2_select(inf, z, l.c), x4 = fp2_select(inf, z, l.xc);
-  st2(ws, 0, fp2_dot_line(d0, k0, x3, k5, x4, k3));
-  st2(ws, 2, fp2_dot_line(d0, k1, d3, k0, x4, k4));
-  st2(ws, 4, fp2_dot_line(d0, k2, d3, k1, x4, k5));
-  st2(ws, 6, fp2_dot_line(d0, k3, d3, k2, d4, k0));
-  st2(ws, 8, fp2_dot_line(d0, k4, d3, k3, d4, k1));
-  st2(ws, 10, fp2_dot_line(d0, k5, d3, k4, d4, k2));
-#elif defined(V_LF_P)
-  // plain dots, uniform d4 / x4 straight from the scalar registers, identity handled by selecting the output
-  const Fp2 &d4 = l.c, &x4 = l.xc;
-  st2(ws, 0, fp2_select(inf, k0, fp2_dot_line(d0, k0, x3, k5, x4, k3)));
-  st2(ws, 2, fp2_select(inf, k1, fp2_dot_line(d0, k1, d3, k0, x4, k4)));
-  st2(ws, 4, fp2_select(inf, k2, fp2_dot_line(d0, k2, d3, k1, x4, k5)));
-  st2(ws, 6, fp2_select(inf, k3, fp2_dot_line(d0, k3, d3, k2, d4, k0)));
-  st2(ws, 8, fp2_select(inf, k4, fp2_dot_line(d0, k4, d3, k3, d4, k1)));
-  st2(ws, 10, fp2_select(inf, k5, fp2_dot_line(d0, k5, d3, k4, d4, k2)));
-#else
-  const Fp2 &d4 = l.c, &x4 = l.xc;
-  st2(ws, 0, fp2_select(inf, k0, fp2_dotk(kfp(k0, d0), kp(x3, k5), kp(x4, k3))));
-  st2(ws, 2, fp2_select(inf, k1, fp2_dotk(kfp(k1, d0), kp(d3, k0), kp(x4, k4))));
-  st2(ws, 4, fp2_select(inf, k2, fp2_dotk(kfp(k2, d0), kp(d3, k1), kp(x4, k5))));
-  st2(ws, 6, fp2_select(inf, k3, fp2_dotk(kfp(k3, d0), kp(d3, k2), kp(d4, k0))));
-  st2(ws, 8, fp2_select(inf, k4, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1))));
-  st2(ws, 10, fp2_select(inf, k5, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2))));
-#endif
-}
-#elif defined(V_LF2)
-// two precomputed-line multiplications in one launch: f <- f * l1(P1) * l2(P2).  The intermediate product never goes to HBM:
-// four of its six coefficients are parked in LDS (72 dwords per lane, lane-interleaved: conflict-free), two stay in registers.
-__device__ __forceinline__ Fp uld(const int32_t* p) { Fp r;
-#pragma unroll
-  for (int l = 0; l < 9; l++) r.v[l] = p[l];
-  return r; }
-__device__ __forceinline__ Fp2 uld2(const int32_t* p) { Fp2 r; r.c0 = uld(p); r.c1 = uld(p + 9); return r; }
-__device__ __forceinline__ void lds_put(int32_t* lds, int slot, const Fp2& a) {
-#pragma unroll
-  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
-}
-__device__ __forceinline__ Fp2 lds_get(const int32_t* lds, int slot) { Fp2 r;
-#pragma unroll
-  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
-  return r; }
-__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
-  __shared__ int32_t lds[72 * 256];
-  WS_SETUP
-  const int32_t* __restrict__ e1 = base + (size_t)n * 9 * 38;
-  const int32_t* __restrict__ e2 = e1 + 64;
-  Fp2 r4, r5;
-  {
-    FixedLine l; l.m = uld2(e1); l.c = uld2(e1 + 18); l.xc = uld2(e1 + 36);
-    Fp px = ws.ld(12), d0 = ws.ld(13);
-    Fp2 d3 = fp2_mul_fp(l.m, px);
-    Fp2 x3 = fp2_mul_xi(d3);
-    const Fp2 &d4 = l.c, &x4 = l.xc;
-    Fp2 k0 = ld2(ws, 0), k1 = ld2(ws, 2), k2 = ld2(ws, 4), k3 = ld2(ws, 6), k4 = ld2(ws, 8), k5 = ld2(ws, 10);
-    lds_put(lds, 0, fp2_dot_line(d0, k0, x3, k5, x4, k3));
-    lds_put(lds, 1, fp2_dot_line(d0, k1, d3, k0, x4, k4));
-    lds_put(lds, 2, fp2_dot_line(d0, k2, d3, k1, x4, k5));
-    lds_put(lds, 3, fp2_dot_line(d0, k3, d3, k2, d4, k0));
-    r4 = fp2_dot_line(d0, k4, d3, k3, d4, k1);
-    r5 = fp2_dot_line(d0, k5, d3, k4, d4, k2);
-  }
-  {
-    FixedLine l; l.m = uld2(e2); l.c = uld2(e2 + 18); l.xc = uld2(e2 + 36);
-    Fp px = ws.ld(14), d0 = ws.ld(15);
-    Fp2 d3 = fp2_mul_fp(l.m, px);
-    Fp2 x3 = fp2_mul_xi(d3);
-    const Fp2 &d4 = l.c, &x4 = l.xc;
-    Fp2 k0 = lds_get(lds, 0), k1 = lds_get(lds, 1), k2 = lds_get(lds, 2), k3 = lds_get(lds, 3), k4 = r4, k5 = r5;
-    st2(ws, 0, fp2_dotk(kfp(k0, d0), kp(x3, k5), kp(x4, k3)));
-    st2(ws, 2, fp2_dotk(kfp(k1, d0), kp(d3, k0), kp(x4, k4)));
-    st2(ws, 4, fp2_dotk(kfp(k2, d0), kp(d3, k1), kp(x4, k5)));
-    st2(ws, 6, fp2_dotk(kfp(k3, d0), kp(d3, k2), kp(d4, k0)));
-    st2(ws, 8, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1)));
-    st2(ws, 10, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2)));
-  }
 }
 #elif defined(V_COPY)
 __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
