@@ -20,3 +20,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
 done
 cd $R
 find gpurun_out/prof gpurun_out/pmc_* -name "*.csv" | head -20
+# secondary configurations (BASELINE configs[3] and [4])
+python tools/bench_plonk.py > gpurun_out/bench_plonk.json 2> gpurun_out/bench_plonk.err || { tail -20 gpurun_out/bench_plonk.err; exit 1; }
+python bench.py --n-public 1024 --batch-log2 12 --steps 5 --warmup 1 > gpurun_out/bench_cfg5.json 2> gpurun_out/bench_cfg5.err || { tail -20 gpurun_out/bench_cfg5.err; exit 1; }
+echo "secondary benches done"
