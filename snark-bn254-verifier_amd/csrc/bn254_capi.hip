@@ -219,8 +219,10 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
   // BN254_STREAMS = 1..4 sub-batches in flight (default 2: +4.5 % over one stream at 2^20, profiles/r01_streams.txt)
   static const int n_streams = [] { const char* e = getenv("BN254_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
   hipStream_t user = (hipStream_t)hip_stream;
-  for (size_t off = 0; off < n; off += G16_MAX_BATCH) {
-    size_t m = n - off < (size_t)G16_MAX_BATCH ? n - off : (size_t)G16_MAX_BATCH;
+  // BN254_CHUNK_LOG2 (experiment): proofs per workspace chunk, default 2^20
+  static const size_t chunk = [] { const char* e = getenv("BN254_CHUNK_LOG2"); int v = e ? atoi(e) : 20; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
+  for (size_t off = 0; off < n; off += chunk) {
+    size_t m = n - off < chunk ? n - off : chunk;
     // sub-batches on concurrent streams: the tail of one sub-batch's kernel overlaps the head of the other's
     // keys with many public inputs (config 5): the MSM runs as (proof, chunk) lanes through a partial-sum buffer that is shared
     // by the launches of a batch, so they stay on the caller's stream and cover at most G16_WIDE_MSM_MAX_PROOFS proofs each
