@@ -47,6 +47,16 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_MAD_PER_S = 35.1e12   # measured v_mad_u64_u32 lane-rate, profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64)
 
 
+# 32x32+64 multiply-adds (v_mad_i64_i32) per proof and LAUNCH of each kernel kind: static counts from the gfx950 code object for the
+# straight-line kernels, loop trip counts applied for the others (prepare: 64 window additions + one Fermat inversion; cyclo_sqr_n:
+# per squaring, multiplied by the run length below).  The binding roofline of this path: DESIGN.md section 5.
+KERNEL_MADS = {
+    "k_miller_step_dbl": 30354, "k_miller_step_add": 25000, "k_f12_mul": 8271, "k_f12_cyclo_sqr": 3657, "k_f12_inv": 16800,
+    "k_f12_frob": 810, "k_g16_prepare": 170000, "k_g16_subgroup": 1992,
+}
+CYCLO_SQUARINGS_IN_RUNS = 186   # 3 exp-by-u x 62 squarings inside the 39 k_f12_cyclo_sqr_n launches
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +197,7 @@ def main():
                          "launches_timed": launches, "proofs_per_launch": per_launch,
                          "note": "HIP events around every launch of this kernel kind inside the timed region; the kernel is 64-bit "
                                  "integer multiply-add (VALU) work, no MFMA: see DESIGN.md for its VALU roofline"},
+            "valu_roofline": _valu_roofline(breakdown, value / world, args.n_public),
             "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},
             "phases_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
         }
@@ -196,6 +207,17 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _valu_roofline(breakdown, proofs_per_s_per_gpu, n_public):
+    """Whole-path VALU utilisation of one GPU: multiply-adds per proof (launch counts of the profiled warm-up step x KERNEL_MADS)
+    x proofs/s against the measured v_mad peak (profiles/r01_ubench_valu.txt).  Informational, next to the contract's `roofline`."""
+    if n_public != 2:
+        return None
+    mads = sum(cnt * KERNEL_MADS.get(k, 0) for k, (cnt, _ms) in breakdown.items()) + CYCLO_SQUARINGS_IN_RUNS * KERNEL_MADS["k_f12_cyclo_sqr"]
+    achieved = mads * proofs_per_s_per_gpu
+    return {"bound": "valu (64-bit integer multiply-add issue)", "mads_per_proof": mads, "achieved": achieved / 1e12, "peak": VALU_PEAK_MAD_PER_S / 1e12,
+            "unit": "T mad/s", "frac": achieved / VALU_PEAK_MAD_PER_S}
 
 
 def _measured_traffic(kernel, proofs_per_launch):
