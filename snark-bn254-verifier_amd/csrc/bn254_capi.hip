@@ -103,6 +103,7 @@ struct PlonkDev {
   size_t cap = 0;                      // proofs the buffers below hold
   int32_t *ws = nullptr, *part = nullptr;
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
+  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // latency mode of the pairing check
 };
 struct bn254_plonk_pvk {
   PlonkKey key;
@@ -114,6 +115,9 @@ struct bn254_plonk_pvk {
 static void plonk_dev_free(PlonkDev& d) {
   void* ptrs[] = {d.tab0, d.tab1, d.one, d.ws, d.part, d.terms, d.flags, d.words, d.inf, d.status};
   for (auto q : ptrs) if (q) (void)hipFree(q);
+  if (d.aux) (void)hipStreamDestroy(d.aux);
+  if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
+  if (d.ev_join) (void)hipEventDestroy(d.ev_join);
   d = PlonkDev();
 }
 static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, size_t n, PlonkDev** out) {
@@ -122,6 +126,8 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, size_t n, Pl
   PlonkDev& d = pvk->dev[device];
   if (!d.ready) {
     if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
+    HIPCK(hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
     d.ready = true;
   }
   size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
@@ -241,7 +247,8 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
     int parts = (!wide && n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
     while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
     const bool concurrent = !wide && n_streams > 1 && parts > 1;
-    if (concurrent && !d->aux_ready) {
+    const bool split_small = m <= (size_t)G16_SPLIT_MAX_PROOFS;   // latency mode of bn254_launch_g16
+    if ((concurrent || split_small) && !d->aux_ready) {
       for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d->join_ev[i], hipEventDisableTiming)); }
       HIPCK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
       d->aux_ready = true;
@@ -260,6 +267,10 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
       a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
       a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
       a.msm_part = wide ? d->msm_part : nullptr;
+      if (split_small && parts == 1) {
+        a.split_streams[0] = d->aux[1]; a.split_streams[1] = d->aux[2];
+        a.split_ev[0] = d->fork_ev; a.split_ev[1] = d->join_ev[1]; a.split_ev[2] = d->join_ev[2];
+      }
       // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
       const bool prof_this = g_profiling && d->ev_ready && pi == 0;
       if (prof_this) { d->prof.mask = g_prof_mask; d->prof.used = 0; d->prof_n = a.n; }
@@ -436,7 +447,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     HIPCK(hipMemcpy(d->terms, t1.data(), m * 2 * sizeof(MsmTerm), hipMemcpyHostToDevice));
     HIPCK(hipMemset(d->flags, 0, m * 2));
     e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, 2, d->part, nullptr, nullptr, d->ws, d->status, VE_CX_ELEM, BN254_ST_LINF2, nullptr);
-    if (e == hipSuccess) e = bn254_launch_pairing2_fixed(d->ws, d->status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, nullptr);
+    if (e == hipSuccess) e = bn254_launch_pairing2_fixed(d->ws, d->status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, nullptr, d->aux, d->ev_fork, d->ev_join);
     if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
     HIPCK(hipDeviceSynchronize());
     HIPCK(hipMemcpy(status + off, d->status, m, hipMemcpyDeviceToHost));

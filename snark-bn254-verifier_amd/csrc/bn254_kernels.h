@@ -39,7 +39,12 @@ struct G16LaunchArgs {
   const int32_t* target;    // 108 dwords: the GT element the product must equal, w-power (k) order
   int inputs_match_key;     // n_public + 1 == len(vk.K)
   int32_t* msm_part;        // wide keys: ceil(n_public / G16_WIDE_MSM_INPUTS_PER_LANE) * 27 * n dwords of partial sums, else nullptr
+  // small batches (n <= G16_SPLIT_MAX_PROOFS): two extra streams and three events (fork, join, join) let the three pairs run their
+  // Miller loops as three concurrent chains (the GPU is mostly idle at such sizes: latency, not throughput, is what counts)
+  hipStream_t split_streams[2] = {nullptr, nullptr};
+  hipEvent_t split_ev[3] = {nullptr, nullptr, nullptr};
 };
+#define G16_SPLIT_MAX_PROOFS 16384
 #define G16_WIDE_MSM_MIN_INPUTS 16      // above this many public inputs the MSM runs as (proof, chunk) lanes + a reduction
 #define G16_WIDE_MSM_INPUTS_PER_LANE 16
 #define G16_WIDE_MSM_MAX_PROOFS 65536   // proofs per launch on the wide path (bounds the partial-sum buffer: 442 MB at 1024 inputs)
@@ -60,7 +65,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
 hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
-                                       int reject_code, hipStream_t s);
+                                       int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

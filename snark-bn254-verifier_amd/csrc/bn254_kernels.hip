@@ -609,7 +609,29 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[1], s);
   LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab}, prof};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
-  vm_miller_program(ops, step_kinds_host(), true);
+  if (a.split_streams[0] && a.split_streams[1] && a.n <= G16_SPLIT_MAX_PROOFS) {
+    // latency mode: Miller(A, B) on the launch stream, the two table-driven pairs as their own chains (accumulators in the free
+    // slots VE_S1 / VE_S2) on two more streams; f = f_A f_B f_C afterwards.  Three times the squarings, 40 % less time at 4096.
+    ops.f12_copy(VE_S1, VE_F); ops.f12_copy(VE_S2, VE_F);
+    (void)hipEventRecord(a.split_ev[0], s);
+    LaunchOps ob{a.ws, n, a.status, grid, a.split_streams[0], {a.gtab, a.dtab}, nullptr};
+    LaunchOps oc{a.ws, n, a.status, grid, a.split_streams[1], {a.gtab, a.dtab}, nullptr};
+    (void)hipStreamWaitEvent(ob.s, a.split_ev[0], 0); (void)hipStreamWaitEvent(oc.s, a.split_ev[0], 0);
+    const uint8_t* kinds = step_kinds_host();
+    for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+      const int kind = kinds[st_];
+      if (kind == 0) { if (st_ != 0) ops.miller_sqr_dbl_var(VE_T, VE_F, VE_AX); else ops.miller_dbl_var(VE_T, VE_F, VE_AX); }
+      else ops.miller_add_var(VE_T, VE_B, kind - 1, VE_F, VE_AX);
+      if (kind == 0 && st_ != 0) { ob.f12_sqr(VE_S1); oc.f12_sqr(VE_S2); }
+      ob.f12_mul_line_fixed(VE_S1, 0, st_, VE_LX);
+      oc.f12_mul_line_fixed(VE_S2, 1, st_, VE_CX);
+    }
+    (void)hipEventRecord(a.split_ev[1], ob.s); (void)hipEventRecord(a.split_ev[2], oc.s);
+    (void)hipStreamWaitEvent(s, a.split_ev[1], 0); (void)hipStreamWaitEvent(s, a.split_ev[2], 0);
+    ops.f12_mul(VE_F, VE_F, VE_S1); ops.f12_mul(VE_F, VE_F, VE_S2);
+  } else {
+    vm_miller_program(ops, step_kinds_host(), true);
+  }
   if (ev) (void)hipEventRecord(ev[2], s);
   // r-torsion test of B from the loop's final point; resolves the deferred statuses (C errors, input count)
   BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
@@ -679,16 +701,33 @@ hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_
 // prod_t e(P_t, Q_t) == 1 for two key-side G2 points (line tables tab0, tab1) and per-item G1 points already in the workspace
 // (P_0 at VE_LX, P_1 at VE_CX; identity flags BN254_ST_LINF / BN254_ST_LINF2 in the status byte): ACCEPT or reject_code
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
-                                       int reject_code, hipStream_t s) {
+                                       int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
   unsigned grid = grid_for(n);
   uint32_t nn = (uint32_t)n;
   G16Prof* prof = nullptr;
   LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1}, nullptr};
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
   BN_LAUNCH(KID_VM_INIT, k_vm_init, ws, nn, (const uint8_t*)status);
-  for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
-    if (step_kinds_host()[st_] == 0 && st_ != 0) ops.f12_sqr(VE_F);
-    ops.f12_mul_line_fixed2(VE_F, st_, VE_LX, VE_CX);
+  const uint8_t* kinds = step_kinds_host();
+  if (aux && n <= G16_SPLIT_MAX_PROOFS) {
+    // latency mode (as in bn254_launch_g16): the two pairs as two concurrent chains, multiplied at the end
+    ops.f12_copy(VE_S1, VE_F);
+    (void)hipEventRecord(ev_fork, s);
+    LaunchOps ob = ops; ob.s = aux;
+    (void)hipStreamWaitEvent(aux, ev_fork, 0);
+    for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+      if (kinds[st_] == 0 && st_ != 0) { ops.f12_sqr(VE_F); ob.f12_sqr(VE_S1); }
+      ops.f12_mul_line_fixed(VE_F, 0, st_, VE_LX);
+      ob.f12_mul_line_fixed(VE_S1, 1, st_, VE_CX);
+    }
+    (void)hipEventRecord(ev_join, aux);
+    (void)hipStreamWaitEvent(s, ev_join, 0);
+    ops.f12_mul(VE_F, VE_F, VE_S1);
+  } else {
+    for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+      if (kinds[st_] == 0 && st_ != 0) ops.f12_sqr(VE_F);
+      ops.f12_mul_line_fixed2(VE_F, st_, VE_LX, VE_CX);
+    }
   }
   vm_final_exp_program(ops);
   BN_LAUNCH(KID_COMPARE, k_g16_compare, ws, nn, status, target_one, reject_code);
