@@ -394,7 +394,7 @@ k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32
 // variable-base G1 multi-scalar multiplication (PlonK: linearised-polynomial digest, folded digests and quotients)
 // =====================================================================================================================
 // lane g = t * n + i: term t of item i.  terms[g * 26]: 18 digits of the affine point, 8 little-endian words of the scalar
-// (canonical, < r).  Double-and-always-add with the complete formulas: data-independent control, no special cases.
+// (canonical, < r).  Fixed 2-bit windows with the complete formulas: data-independent control, no special cases.
 // flags[g] != 0: the point is the identity (the term contributes nothing).  Partial results: part[(t * 27 + k) * n + i].
 __global__ void __launch_bounds__(256, 2)
 k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part) {
@@ -413,15 +413,23 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
 #pragma unroll
     for (int k = 0; k < 8; k++) sw[k] = 0;
   }
+  // 2-bit fixed windows, most significant first: table {P, 2P, 3P} in registers, per window two doublings and one complete
+  // addition of the selected entry (the result is kept only for a non-zero digit): 28 field products per 2 bits instead of 38
+  G1Proj P1 = g1_from_affine(P), P2 = g1_dbl(P1), P3 = g1_add_mixed(P2, P);
   G1Proj acc = g1_identity();
-  for (int b = 0; b < 256; b++) {  // most significant bit first; the 256-bit array is shifted up by one each time
-    const bool bit = (sw[7] >> 31) != 0;
+  for (int b = 0; b < 128; b++) {
+    const uint32_t dig = sw[7] >> 30;
 #pragma unroll
-    for (int k = 7; k > 0; k--) sw[k] = (sw[k] << 1) | (sw[k - 1] >> 31);
-    sw[0] <<= 1;
-    acc = g1_dbl(acc);
-    G1Proj c = g1_add_mixed(acc, P);
-    acc.x = fp_select(bit, c.x, acc.x); acc.y = fp_select(bit, c.y, acc.y); acc.z = fp_select(bit, c.z, acc.z);
+    for (int k = 7; k > 0; k--) sw[k] = (sw[k] << 2) | (sw[k - 1] >> 30);
+    sw[0] <<= 2;
+    acc = g1_dbl(g1_dbl(acc));
+    G1Proj q;
+    q.x = fp_select(dig == 3, P3.x, fp_select(dig == 2, P2.x, P1.x));
+    q.y = fp_select(dig == 3, P3.y, fp_select(dig == 2, P2.y, P1.y));
+    q.z = fp_select(dig == 3, P3.z, fp_select(dig == 2, P2.z, P1.z));
+    G1Proj c = g1_add(acc, q);
+    const bool take = dig != 0;
+    acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
   }
   int32_t* o = part + (size_t)t * 27 * n + i;
 #pragma unroll
