@@ -87,8 +87,8 @@ __device__ __forceinline__ Fp2 uni_ld2(const int32_t* p) { Fp2 r; r.c0 = uni_ld(
 
 // ---- every VM operation (bn254_vm.h) is its own kernel ------------------------------------------------------------------------
 // The VM programs (vm_miller_program, vm_final_exp_program) are host-compilable: the host walks them and enqueues one launch
-// per operation (~700 per batch, all asynchronous on one stream, so launch overhead hides behind the previous kernel for any
-// batch that matters).  No device-side function calls: each kernel gets exactly the registers it needs and no stack.
+// per operation (~210 per batch, all asynchronous on the sub-batch's stream, so launch overhead hides behind the previous kernel
+// for any batch that matters).  No device-side function calls: each kernel gets exactly the registers it needs and no stack.
 // A wave whose 64 proofs have all failed earlier checks exits at once.
 #define VM_KERNEL_PROLOGUE()                                                                     \
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;                                           \

@@ -369,8 +369,8 @@ BN_HD bool vm_f12_eq_const(W& w, int e, const int32_t* target /* 12 Fp in k-orde
 }
 
 // =======================================================================================================================================
-// Programs.  OPS is the dispatcher that decides how an operation is invoked (the kernels route each one through a noinline
-// device function so that every operation is compiled once; hostsim calls them directly).
+// Programs.  OPS is the dispatcher that decides how an operation is invoked: LaunchOps (bn254_kernels.hip) enqueues one kernel
+// launch per operation, HostOps (tests/hostsim) calls the operation directly on plain arrays.
 // =======================================================================================================================================
 // step table of the optimal-ate loop: one entry per Miller step (BN_ATE_STEPS = 88): 0 = doubling (with f squaring),
 // 1 = add +B, 2 = add -B, 3 = add pi(B), 4 = add -pi^2(B)
