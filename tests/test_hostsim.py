@@ -217,3 +217,20 @@ def test_reference_plonk_fixtures_through_product_arithmetic(hostsim, O, fixture
         assert bytes(o) == one, name
         n += 1
     assert n == 4
+
+
+def test_latency_mode_program_matches(hostsim, O):
+    """The small-batch launch plan (three separate Miller chains multiplied at the end) under the bound tracker: same GT element
+    as the oracle and as the fused per-step program."""
+    hs = hostsim
+    rng = random.Random(41)
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    pa, pl, pc = (O.g1_mul(g1, rng.randrange(1, R)) for _ in range(3))
+    qb, qg, qd = (O.g2_mul(g2, rng.randrange(1, R)) for _ in range(3))
+    for l_inf in (0, 1):
+        o1 = (C.c_uint8 * 384)(); o2 = (C.c_uint8 * 384)()
+        assert hs.hs_vm_pairing3(o1, pa, qb, pl, qg, pc, qd, l_inf) == 1
+        assert hs.hs_vm_pairing3_split(o2, pa, qb, pl, qg, pc, qd, l_inf) == 1
+        assert bytes(o1) == bytes(o2)
+        exp = O.pairing(pa + pc, qb + qd) if l_inf else O.pairing(pa + pl + pc, qb + qg + qd)
+        assert bytes(o2) == exp
