@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- Groth16 batch-verify throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1: if the process was started by torch.distributed.run (WORLD_SIZE set) it is one rank of
+the job; otherwise bench.py starts the N ranks ITSELF -- `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child process, before this process has imported torch or touched a GPU -- relays the child's JSON line and exits with its code.
 
 A step = one pass of the whole hot path (parse + checks + public-input MSM, G2 subgroup test, 3-pair Miller loop, final
 exponentiation, status bytes) over one batch of synthetic gnark-format proofs that are ALREADY RESIDENT IN HBM, followed by
@@ -10,54 +14,37 @@ Workload at N = 1: BASELINE.json configs[2], batch 2^20, 2 public inputs, 1/16 o
 For N > 1 every rank verifies its own 2^20-proof shard of an N * 2^20 batch (weak scaling, no data-path communication).
 After the timed region the statuses are compared with the generator's expected statuses: a wrong answer aborts the bench.
 
-One JSON line on rank 0, with `roofline` for the dominant kernel -- the kernel kind with the largest summed duration over a
-batch (k_miller_step_dbl, one whole doubling step of the shared Miller loop, on this code) -- whose launches are bracketed by
-HIP events on their launch stream INSIDE the timed region, and `cpu_baseline` (the CPU oracle = C port of the reference algorithm,
-timed on this box's host cores on a bounded sample; rank 0, N = 1 only).  The last warm-up step brackets every launch of every
-kernel kind instead (`kernels_ms`, informational; ~420 event records, outside the timed region).
+One JSON line on rank 0:
+  roofline      the binding bound of this path, the integer VALU: 32x32+64-bit multiply-adds of the dominant kernel kind (static count
+                from the gfx950 code object, profiles/kernel_mads.json written by tools/count_mads.py) x proofs per launch / the
+                kernel's average launch duration (HIP events around every launch of that kind INSIDE the timed region, on the
+                launch stream), against the measured v_mad_u64_u32 issue peak (profiles/r01_ubench_valu.txt).  `traffic` = HBM
+                bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json).
+  hbm_roofline  SURVEY.md section 8(d)'s algorithmic bytes (321 B/proof) x proofs/s against the HBM peak: the figure north_star
+                asks for, ~1e-4 because the path is arithmetic-bound.
+  cpu_baseline  the CPU oracle (C restatement of the reference algorithm) on this box's host cores on a bounded sample;
+                rank 0, N = 1 only.  Rows: reference-faithful on all cores (the headline `value`), on one core, and batch mode.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# SURVEY.md section 8(d): algorithmic bytes per proof of the path = 256 B proof + 64 B public inputs in, 1 B status out
-ALGO_BYTES_PER_PROOF = 321
-# Algorithmic HBM bytes per proof and LAUNCH of each kernel kind = operands read + results written in the per-proof workspace
-# (one Fp = 9 x 4 B, Fp2 = 72 B, Fp12 = 432 B; DESIGN.md "Kernels").  The workspace is the data these kernels exist to move:
-# an Fp12-level operation cannot keep its 432-byte operands in registers across launches.
-KERNEL_ALGO_BYTES = {
-    "k_f12_mul": 3 * 432,                    # a, b in; a*b out
-    "k_f12_sqr": 2 * 432, "k_f12_cyclo_sqr": 2 * 432, "k_f12_cyclo_sqr_n": 2 * 432, "k_f12_conj": 2 * 432, "k_f12_copy": 2 * 432, "k_f12_frob": 2 * 432, "k_f12_inv": 2 * 432,
-    "k_f12_mul_line_fixed": 2 * 432 + 72,        # f in/out, G1 point (the line table entry is wave-uniform: scalar loads)
-    "k_f12_mul_line_fixed2": 2 * 432 + 2 * 72,   # f in/out, two G1 points
-    "k_miller_step_dbl": 2 * 432 + 2 * 216 + 3 * 72,            # f, T in/out, three G1 points
-    "k_miller_step_add": 2 * 432 + 2 * 216 + 144 + 3 * 72,      # + Q in
-    "k_miller_sqr_dbl_var": 2 * 432 + 2 * 216 + 72,
-    "k_miller_dbl_var": 2 * 432 + 2 * 216 + 72, "k_miller_add_var": 2 * 432 + 2 * 216 + 144 + 72,   # f, T in/out (, Q), G1 point
-    "k_g16_prepare": 321 + 10 * 36, "k_g16_subgroup": 144, "k_vm_init": 432 + 216, "k_g16_compare": 432 + 1,
-}
+ALGO_BYTES_PER_PROOF = 321      # SURVEY.md section 8(d): 256 B proof + 64 B public inputs in, 1 B status out
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-# exact Fp-multiplication count per proof of THIS implementation (DESIGN.md "Work model"; counted by tests/hostsim)
 VALU_PEAK_MAD_PER_S = 35.1e12   # measured v_mad_u64_u32 lane-rate, profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64)
+METRIC = "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X"
+SEED = 0xB2540002
 
 
-# 32x32+64 multiply-adds (v_mad_i64_i32) per proof and LAUNCH of each kernel kind: static counts from the gfx950 code object for the
-# straight-line kernels, loop trip counts applied for the others (prepare: 64 window additions + one Fermat inversion; cyclo_sqr_n:
-# per squaring, multiplied by the run length below).  The binding roofline of this path: DESIGN.md section 5.
-KERNEL_MADS = {
-    "k_miller_step_dbl": 30354, "k_miller_step_add": 25000, "k_f12_mul": 8271, "k_f12_cyclo_sqr": 3657, "k_f12_inv": 16800,
-    "k_f12_frob": 810, "k_g16_prepare": 170000, "k_g16_subgroup": 1992,
-}
-CYCLO_SQUARINGS_IN_RUNS = 186   # 3 exp-by-u x 62 squarings inside the 39 k_f12_cyclo_sqr_n launches
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -65,188 +52,329 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20, help="proofs per GPU = 2^this (default: BASELINE 2^20)")
     ap.add_argument("--n-public", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="proofs timed on the host for cpu_baseline (~30 CPU-seconds)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="proofs timed on the host per cpu_baseline row")
+    ap.add_argument("--rlc", action="store_true", help="time the random-linear-combination batch mode instead of the exact path")
+    ap.add_argument("--host-buffers", action="store_true", help="also time the host-buffer entry (PCIe-inclusive), reported beside `value`")
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """Start the N ranks as children of this (GPU-untouched) process; never exec."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------------------------------
+def rotate_shard(proofs, inputs, expected, n, n_public, rank):
+    """Every rank shares the key (same seed); rank r > 0 takes the same proof stream rotated by (r * 7919) mod n so that shards
+    are not byte-identical.  Returns (proofs, inputs, expected)."""
+    k = (rank * 7919) % n if rank > 0 else 0
+    if k == 0:
+        return proofs, inputs, expected
+    sz = 32 * n_public
+    return proofs[256 * k:] + proofs[:256 * k], inputs[sz * k:] + inputs[:sz * k], expected[k:] + expected[:k]
+
+
+class GpuVerifier:
+    """The product path on one GPU: inputs resident in HBM, verify_batch_device on the current stream."""
+
+    def __init__(self, args, pkg, vk, proofs, inputs, local_rank):
+        import torch
+        self.torch = torch
+        self.args, self.pkg, self.local_rank = args, pkg, local_rank
+        self.n = len(proofs) // 256
+        self.dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(local_rank)
+        self.pvk = pkg.PreparedVk(vk, pkg.VK_REFERENCE)
+        self.pvk.reserve(self.n, local_rank)
+        self.d_proofs = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(self.dev)
+        self.d_inputs = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(self.dev)
+        self.d_status = torch.zeros(self.n, dtype=torch.uint8, device=self.dev)
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.flags = pkg.FLAG_RLC if args.rlc else 0
+        pkg.lib().bn254_set_profiling(1)
+
+    def step(self):
+        self.pvk.verify_batch_device(self.d_proofs.data_ptr(), self.d_inputs.data_ptr(), self.d_status.data_ptr(), self.n, 256,
+                                     self.args.n_public, self.local_rank, self.stream.cuda_stream, flags=self.flags)
+        return self.d_status
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def timer(self):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self.stream)
+        return ev
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    def select_kernels(self, names):
+        self.pkg.set_profile_kernels(names)
+
+    def kernel_profile(self):
+        return self.pvk.kernel_profile(self.local_rank)
+
+    def phases(self):
+        return self.pvk.last_kernel_ms(self.local_rank)
+
+    def status_bytes(self):
+        return bytes(self.d_status.cpu().numpy().tobytes())
+
+
+def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=print):
+    """The rank logic of the bench: workload (shared key, rotated shard), warm-up, K timed steps each ending in the status
+    all_gather, max-over-ranks timing, correctness check of the local and the gathered statuses, JSON line on rank 0.
+    make_verifier(vk, proofs, inputs, local_rank) -> object with step()/sync()/timer()/... (GpuVerifier, or a stand-in in the
+    gloo CPU test); synth(seed, n_public, n, threads) -> (vk, proofs, inputs, expected)."""
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    pkg = importlib.import_module("snark-bn254-verifier_amd")
     sharding = importlib.import_module("snark-bn254-verifier_amd.sharding")
-    L = pkg.lib()
 
     n = 1 << args.batch_log2                      # per-GPU shard
     n_total = n * world
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    # one verifying key for the whole job (seed fixed), per-rank proofs (the generator derives proof i from seed and index;
-    # different ranks use different seeds for the proofs but must share the key, so generate the key from the common seed and
-    # offset only the proof stream)
-    seed = 0xB2540002
-    vk, proofs, inputs, expected = pkg.synth_groth16(seed, args.n_public, n, invalid_every=16, agree=True, threads=threads)
-    if world > 1 and rank > 0:
-        # same key (same seed), a different slice of the proof stream: rotate this rank's data so shards are not byte-identical
-        k = (rank * 7919) % n
-        proofs = proofs[256 * k:] + proofs[:256 * k]
-        sz = 32 * args.n_public
-        inputs = inputs[sz * k:] + inputs[:sz * k]
-        expected = expected[k:] + expected[:k]
+    vk, proofs, inputs, expected = synth(SEED, args.n_public, n, threads)
+    proofs, inputs, expected = rotate_shard(proofs, inputs, expected, n, args.n_public, rank)
     gen_s = time.time() - t0
-
-    pvk = pkg.PreparedVk(vk, pkg.VK_REFERENCE)
-    pvk.reserve(n, local_rank)
-    d_proofs = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
-    d_inputs = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(dev)
-    d_status = torch.zeros(n, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    L.bn254_set_profiling(1)
+    v = make_verifier(vk, proofs, inputs, local_rank)
 
     def step():
-        pvk.verify_batch_device(d_proofs.data_ptr(), d_inputs.data_ptr(), d_status.data_ptr(), n, 256, args.n_public, local_rank, stream.cuda_stream)
-        return sharding.gather_status(d_status, n_total, world)   # the only collective of the path
+        st = v.step()
+        t_a = v.timer()
+        full = sharding.gather_status(st, n_total, world)   # the only collective of the path
+        t_b = v.timer()
+        return full, (t_a, t_b)
 
     def fence():
-        torch.cuda.synchronize(dev)
+        v.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        v.sync()
 
-    pkg.set_profile_kernels(None)                 # warm-up: bracket every launch (per-kind breakdown)
+    v.select_kernels(None)                        # warm-up: bracket every launch (per-kind breakdown)
     for _ in range(args.warmup):
         step()
     fence()
     breakdown = None
     if args.warmup:
-        breakdown, _per = pvk.kernel_profile(local_rank)
-        dom = max(breakdown, key=lambda k: breakdown[k][1])
-        pkg.set_profile_kernels([dom])            # timed region: events around the dominant kernel's launches only
-    prof = {}
-    phase_ms = {}
+        breakdown, _per = v.kernel_profile()
+        if breakdown:
+            dom = max(breakdown, key=lambda k: breakdown[k][1])
+            v.select_kernels([dom])               # timed region: events around the dominant kernel's launches only
+    prof, phase_ms, gathers = {}, {}, []
     per_launch = n
+    fence()
     t_start = time.perf_counter()
     full = None
     for _ in range(args.steps):
-        full = step()
-        # HIP-event durations of this step (events were recorded on the launch stream); reading them waits for the step's
-        # last event only, which the next step would have to wait for anyway (same stream)
-        kp, per_launch = pvk.kernel_profile(local_rank)
+        full, tg = step()
+        gathers.append(tg)
+        # HIP-event durations of this step (recorded on the launch stream); reading them waits for the step's last event only,
+        # which the next step would have to wait for anyway (same stream)
+        kp, per_launch = v.kernel_profile()
         for k, (cnt, ms) in kp.items():
             c0, m0 = prof.get(k, (0, 0.0))
             prof[k] = (c0 + cnt, m0 + ms)
-        for k, v in pvk.last_kernel_ms(local_rank).items():
-            phase_ms.setdefault(k, []).append(v)
+        for k, x in v.phases().items():
+            phase_ms.setdefault(k, []).append(x)
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=full.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    gather_ms = sum(v.elapsed_ms(a, b) for a, b in gathers) / max(1, len(gathers))
     if breakdown is None:
         breakdown = {k: (c // args.steps, m / args.steps) for k, (c, m) in prof.items()}
-    dom = max(prof, key=lambda k: prof[k][1])
 
-    # correctness of the timed work
-    got = bytes(d_status.cpu().numpy().tobytes())
-    assert got == expected, "rank %d: GPU statuses differ from the expected statuses" % rank
-    if world > 1:
-        lo, hi = sharding.shard_bounds(n_total, world, rank)
-        assert bytes(full[lo:hi].cpu().numpy().tobytes()) == expected, "gathered statuses are wrong"
-        assert full.numel() == n_total
+    # correctness of the timed work: this rank's shard, and its slice of the gathered vector
+    got = v.status_bytes()
+    assert got == expected, "rank %d: statuses differ from the expected statuses" % rank
+    lo, hi = sharding.shard_bounds(n_total, world, rank)
+    assert full.numel() == n_total, "gathered vector has the wrong length"
+    assert bytes(full[lo:hi].cpu().numpy().tobytes()) == expected, "gathered statuses are wrong"
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = n_total * args.steps / elapsed
-        launches, total_ms = prof[dom]
-        avg_launch_ms = total_ms / launches
-        algo = dict(KERNEL_ALGO_BYTES)
-        chunks = (args.n_public + 15) // 16
-        # wide-key MSM (configs[4]): scalars + one 80-byte table entry per 8-bit window in, one projective partial sum per chunk out
-        algo["k_g16_msm_partial"] = args.n_public * (32 + 32 * 80) + chunks * 108
-        algo["k_g16_msm_reduce"] = chunks * 108 + 72
-        algo["k_g16_prepare"] = 256 + 10 * 36 + (0 if args.n_public > 16 else args.n_public * (32 + 32 * 80))
-        algo_launch = algo[dom] * per_launch
-        achieved = algo_launch / (avg_launch_ms * 1e-3) / 1e9
+        headline = (args.n_public, args.batch_log2, bool(args.rlc)) == (2, 20, False)
         out = {
-            "metric": "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X" if (args.n_public, args.batch_log2) == (2, 20)
-                      else "Groth16 verifies/sec (%d pub-inputs) at batch=2^%d" % (args.n_public, args.batch_log2),
+            "metric": METRIC if headline else "Groth16 verifies/sec (%d pub-inputs) at batch=2^%d%s" % (args.n_public, args.batch_log2, ", RLC batch mode" if args.rlc else ""),
             "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: batch 2^%d Groth16 proofs per GPU, %d public inputs, gnark-format bytes, 1/16 invalid"
                                    % (4 if args.n_public == 1024 else 2, args.batch_log2, args.n_public),
                        "batch_per_gpu": n, "global_batch": n_total, "n_public": args.n_public, "vk_mode": "reference",
+                       "mode": "rlc (random linear combination, exact fallback)" if args.rlc else "exact",
                        "parallelism": "independent proof shards x%d + all_gather of status bytes" % world,
-                       "streams_per_gpu": int(os.environ.get("BN254_STREAMS", "2")),
-                       "gen_seconds": round(gen_s, 1)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(dom, per_launch),
-                         "algorithmic_bytes_per_launch": algo_launch, "avg_launch_ms": avg_launch_ms,
-                         "launches_timed": launches, "proofs_per_launch": per_launch,
-                         "note": "HIP events around every launch of this kernel kind inside the timed region; the kernel is 64-bit "
-                                 "integer multiply-add (VALU) work, no MFMA: see DESIGN.md for its VALU roofline"},
-            "valu_roofline": _valu_roofline(breakdown, value / world, args.n_public),
+                       "gather_ms": gather_ms, "gen_seconds": round(gen_s, 1)},
+            "hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_proof": ALGO_BYTES_PER_PROOF, "achieved": value / world * ALGO_BYTES_PER_PROOF / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value / world * ALGO_BYTES_PER_PROOF / 1e9 / HBM_PEAK_GBPS,
+                             "note": "SURVEY.md 8(d): 256 B proof + 64 B inputs in, 1 B status out; the path is arithmetic-bound"},
             "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},
-            "phases_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
+            "phases_ms": {k: sum(x) / len(x) for k, x in phase_ms.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = _cpu_baseline(args, vk, proofs, inputs, expected)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if prof:
+            dom = max(prof, key=lambda k: prof[k][1])
+            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch)
+            out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
+        emit(json.dumps(out))
+    return out
 
 
-def _valu_roofline(breakdown, proofs_per_s_per_gpu, n_public):
-    """Whole-path VALU utilisation of one GPU: multiply-adds per proof (launch counts of the profiled warm-up step x KERNEL_MADS)
-    x proofs/s against the measured v_mad peak (profiles/r01_ubench_valu.txt).  Informational, next to the contract's `roofline`."""
-    if n_public != 2:
-        return None
-    mads = sum(cnt * KERNEL_MADS.get(k, 0) for k, (cnt, _ms) in breakdown.items()) + CYCLO_SQUARINGS_IN_RUNS * KERNEL_MADS["k_f12_cyclo_sqr"]
-    achieved = mads * proofs_per_s_per_gpu
-    return {"bound": "valu (64-bit integer multiply-add issue)", "mads_per_proof": mads, "achieved": achieved / 1e12, "peak": VALU_PEAK_MAD_PER_S / 1e12,
-            "unit": "T mad/s", "frac": achieved / VALU_PEAK_MAD_PER_S}
-
-
-def _measured_traffic(kernel, proofs_per_launch):
-    """HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE per proof from the committed rocprofv3 --pmc
-    run (profiles/pmc_traffic.json, corrected as MI355X_MICROARCH.md prescribes) x the proofs one launch covers; or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def _load_json(name):
     try:
-        e = json.load(open(p))[kernel]
-        return (e["read_bytes_per_proof"] + e["write_bytes_per_proof"]) * proofs_per_launch
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
 
 
+def _valu_roofline(dom, launches_ms, per_launch):
+    """The binding roofline, for the dominant kernel kind: multiply-adds per launch / average launch duration vs the v_mad peak."""
+    launches, total_ms = launches_ms
+    avg_ms = total_ms / max(1, launches)
+    mads = (_load_json("kernel_mads.json") or {}).get("kernels", {}).get(dom, {}).get("mads_per_proof_launch")
+    traffic = (_load_json("pmc_traffic.json") or {}).get(dom)
+    r = {"bound": "valu", "kernel": dom, "unit": "T mad/s", "peak": VALU_PEAK_MAD_PER_S / 1e12, "avg_launch_ms": avg_ms,
+         "launches_timed": launches, "proofs_per_launch": per_launch,
+         "traffic": (traffic["read_bytes_per_proof"] + traffic["write_bytes_per_proof"]) * per_launch if traffic else None,
+         "note": "v_mad_[iu]64_[iu]32 per proof and launch counted in the gfx950 code object (tools/count_mads.py -> profiles/kernel_mads.json) x proofs "
+                 "per launch / HIP-event launch duration inside the timed region; peak = measured issue rate (profiles/r01_ubench_valu.txt); "
+                 "launches of the concurrent sub-batch streams share the GPU, so one stream's launch sees about half the chip"}
+    if mads:
+        streams = int(os.environ.get("BN254_STREAMS", "2"))
+        # sub-batch streams run the same kernel kind side by side: a launch of one stream competes with the other stream's
+        ach = mads * per_launch / (avg_ms * 1e-3) / 1e12
+        r.update({"mads_per_proof_launch": mads, "achieved_one_stream": ach, "achieved": ach * streams, "concurrent_streams": streams,
+                  "frac": ach * streams / (VALU_PEAK_MAD_PER_S / 1e12)})
+    else:
+        r.update({"achieved": None, "frac": None})
+    return r
+
+
+def _valu_whole_path(breakdown, proofs_per_s_per_gpu):
+    km = (_load_json("kernel_mads.json") or {}).get("kernels")
+    if not km:
+        return None
+    mads, missing = 0, []
+    for k, (cnt, _ms) in breakdown.items():
+        e = km.get(k)
+        if e is None:
+            missing.append(k)
+            continue
+        mads += e.get("mads_per_proof_batch", cnt * e["mads_per_proof_launch"])
+    ach = mads * proofs_per_s_per_gpu
+    return {"mads_per_proof": mads, "achieved": ach / 1e12, "peak": VALU_PEAK_MAD_PER_S / 1e12, "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S,
+            "kernels_without_count": missing}
+
+
 def _cpu_baseline(args, vk, proofs, inputs, expected):
-    """The oracle (C port of the reference algorithm, reference-faithful: vk re-parsed per call, 4 Miller loops + 2 final
-    exponentiations, naive subgroup check) on the host cores of this box, on a prefix of the same workload."""
+    """The oracle (C port of the reference algorithm) on the host cores of this box, on a prefix of the same workload.
+    Rows: reference-faithful (vk re-parsed per call, 4 Miller loops + 2 final exponentiations, naive subgroup check) on all cores
+    and on one core; batch mode (vk prepared once: lib.rs:45-46 and groth16/verify.rs:70 hoisted) on all cores."""
     from oracle import oracle as O
     O.build(); O.lib()
-    m = min(args.cpu_sample if args.n_public <= 16 else 256, len(expected))  # ~30 CPU-seconds either way
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # the 1-GPU box's CPU share is 16 cores
-    O.set_threads(cores)
     sz = 32 * args.n_public
-    O.groth16_verify_many(proofs[:256 * 8], 256, vk, inputs[:sz * 8], args.n_public, 8, O.MODE_REFERENCE)
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))  # the 1-GPU box's CPU share is 16 cores
+    wide = args.n_public > 16
+
+    def run(m, threads, batch_mode):
+        O.set_threads(threads)
+        f = O.groth16_verify_many_prepared if batch_mode else O.groth16_verify_many
+        f(proofs[:256 * 4], 256, vk, inputs[:sz * 4], args.n_public, 4, O.MODE_REFERENCE)
+        t = time.perf_counter()
+        st = f(proofs[:256 * m], 256, vk, inputs[:sz * m], args.n_public, m, O.MODE_REFERENCE)
+        dt = time.perf_counter() - t
+        assert st == expected[:m], "oracle disagrees with the expected statuses"
+        return m / dt, dt
+
+    m_all = min(args.cpu_sample if not wide else 128, len(expected))
+    m_one = min(max(64, m_all // 16) if not wide else 16, len(expected))
+    v_all, dt_all = run(m_all, cores, False)
+    v_one, dt_one = run(m_one, 1, False)
+    v_bat, dt_bat = run(m_all, cores, True)
+    flags = O.build_flags()
+    return {"value": v_all, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "first %d proofs of the same batch, %.1f s wall, OpenMP over %d threads; C restatement of the reference algorithm (vk re-parsed and "
+                      "e(alpha,beta) recomputed per proof, naive subgroup check), not the Rust binary; %s" % (m_all, dt_all, cores, flags),
+            "single_core": {"value": v_one, "unit": "proofs/s", "cores": 1, "sample": "first %d proofs, %.1f s" % (m_one, dt_one)},
+            "batch_mode": {"value": v_bat, "unit": "proofs/s", "cores": cores,
+                           "sample": "first %d proofs, %.1f s; vk parsed once, e(alpha,beta) hoisted (reference waste at lib.rs:45-46, groth16/verify.rs:70 removed)" % (m_all, dt_bat)}}
+
+
+def _host_buffer_line(args, pkg, vk, proofs, inputs, expected, local_rank):
+    """PCIe-inclusive rate of the host-buffer entry point (never `value`)."""
+    pvk = pkg.PreparedVk(vk, pkg.VK_REFERENCE)
+    n = len(expected)
+    pvk.verify_batch(proofs, inputs, n, 256, args.n_public, local_rank)     # warm-up (allocations, pinned staging)
     t = time.perf_counter()
-    st = O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:sz * m], args.n_public, m, O.MODE_REFERENCE)
+    st = pvk.verify_batch(proofs, inputs, n, 256, args.n_public, local_rank)
     dt = time.perf_counter() - t
-    assert st == expected[:m], "oracle disagrees with the expected statuses"
-    return {"value": m / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "first %d proofs of the same batch, %.1f s wall, OpenMP over %d threads; C restatement of the reference algorithm, not the Rust binary" % (m, dt, cores)}
+    assert st == expected
+    pvk.close()
+    return {"value": n / dt, "unit": "proofs/s", "ms": dt * 1e3, "note": "bn254_groth16_verify_batch on pageable host buffers: H2D of proofs and inputs, compute, D2H of status"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    keep = {}
+
+    def make(vk, proofs, inputs, lr):
+        keep.update(vk=vk, proofs=proofs, inputs=inputs)
+        return GpuVerifier(args, pkg, vk, proofs, inputs, lr)
+
+    def synth(seed, n_public, n, threads):
+        r = pkg.synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=threads)
+        keep["expected0"] = r[3]
+        return r
+
+    lines = []
+    out = run_rank(args, make, "nccl", rank, world, local_rank, synth, emit=lines.append)
+    if rank == 0:
+        if world == 1:
+            if args.host_buffers:
+                out["host_buffers"] = _host_buffer_line(args, pkg, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"], local_rank)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = _cpu_baseline(args, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

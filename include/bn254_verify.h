@@ -14,7 +14,9 @@
  *   - Return value = infrastructure status (BN254_OK or a negative BN254_E_* code).  Per-proof outcomes are reported
  *     only through status bytes (BN254_REJECT ... below); nothing panics, unlike the reference's unwrap()s.
  *   - The caller owns every buffer it passes; the library owns the opaque prepared-vk handle.
- *   - A prepared vk is immutable and may be shared between threads; a (handle, stream) pair runs one batch at a time.
+ *   - A prepared vk is immutable and may be shared between threads.  The library keeps one workspace per (key, device): batches
+ *     against the same key and device are serialised by the library itself (enqueue under a per-device lock, each batch waits
+ *     on the previous batch's completion event before it touches the workspace), whatever streams the callers use.
  *   - There is NO CPU fallback: every verify entry point runs the HIP kernels and fails with BN254_E_NO_DEVICE if
  *     no gfx950 device is usable.
  */
@@ -61,6 +63,21 @@ enum {
  * y.c0 / y.c1 in different halves of [0,p) and delta2 in the same half (the SP1 key is presumably of this kind). */
 enum { BN254_VK_REFERENCE = 0, BN254_VK_GNARK = 1 };
 
+/* ---- per-call option flags of the batch entry points ------------------------------------------------------------
+ * BN254_FLAG_STRICT_SCALARS  public inputs >= r are answered with BN254_ERR_NOT_MEMBER instead of being used modulo r.  The
+ *     default (flag clear) is the reference's behaviour: bn::Fr::from_slice stores any 256-bit value and AffineG1 * Fr consumes it
+ *     bit by bit, so x and x + r verify alike (examples/script/src/main.rs:204-213).  In the reference's
+ *     typed API a range-checked Fr would fail at construction, before verify() is entered, so the strict error takes precedence
+ *     over every proof error.
+ * BN254_FLAG_RLC  random-linear-combination batch mode (the reference batches the same way inside KZG,
+ *     plonk/kzg.rs:149-187): proofs are checked in groups with fresh 128-bit random weights r_i,
+ *         prod_i e(r_i A_i, B_i) * e(sum r_i L_i, gamma') * e(sum r_i C_i, delta') * e(-(sum r_i) alpha, beta') == 1,
+ *     one variable-argument Miller loop per proof and one final exponentiation per group; proofs of a group that fails are
+ *     re-verified by the exact path, so the status bytes are those of the exact path except with probability <= 2^-120 per batch
+ *     (a false ACCEPT).  Loader errors (member / curve / subgroup) are always exact.  The weights come from ChaCha20 keyed by
+ *     getrandom(2) per call.  The call synchronises the stream once (to learn which groups failed). */
+enum { BN254_FLAG_STRICT_SCALARS = 1u, BN254_FLAG_RLC = 2u };
+
 typedef struct bn254_g16_pvk bn254_g16_pvk;
 
 /* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
@@ -76,7 +93,13 @@ size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk);
  * big-endian, NOT range-checked and used modulo r exactly like bn::Fr::from_slice + AffineG1 * Fr.
  * status: n bytes.  device: HIP device ordinal. */
 int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride,
-                               const uint8_t* public_inputs, size_t n_public, size_t n, uint8_t* status, int device);
+                               const uint8_t* public_inputs, size_t n_public, size_t n, uint8_t* status, int device, unsigned flags);
+/* Same over several GPUs of the node: bit d of device_mask selects HIP device d.  The batch is cut into contiguous shards, one
+ * host thread per device drives its shard through bn254_groth16_verify_batch, and the status bytes land in the caller's buffer
+ * (the gather of SURVEY.md section 8(e) done by the host threads; a multi-process job gathers with RCCL instead, see bench.py). */
+int bn254_groth16_verify_batch_multi(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride,
+                                     const uint8_t* public_inputs, size_t n_public, size_t n, uint8_t* status,
+                                     uint64_t device_mask, unsigned flags);
 
 /* Same, with proofs / public_inputs / status already resident in the memory of `device` (the bench path: inputs in
  * HBM when the timed region starts).  hip_stream is a hipStream_t (NULL = default stream); the call only enqueues
@@ -84,7 +107,7 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
  * keep the call free of allocations (graph capture). */
 int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_proofs, size_t proof_stride,
                                       const void* d_public_inputs, size_t n_public, size_t n, void* d_status,
-                                      int device, void* hip_stream);
+                                      int device, void* hip_stream, unsigned flags);
 /* pre-allocate the per-device workspace for batches of up to n proofs and upload the key's tables */
 int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
 
@@ -92,6 +115,11 @@ int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
  * byte.  Runs on the GPU (device 0). */
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
+
+/* Raw gnark proof writer: A (64) | B (128: x.c1, x.c0, y.c1, y.c0) | C (64) | u32 0 (no commitments) | 64 zero bytes (commitment PoK):
+ * the 324-byte form load_groth16_proof_from_bytes reads (groth16/converter.rs:14-26; SP1 fixtures carry exactly this). */
+#define BN254_GROTH16_RAW_PROOF_LEN 324
+int bn254_groth16_proof_write_raw(const uint8_t a[64], const uint8_t b[128], const uint8_t c[64], uint8_t out[BN254_GROTH16_RAW_PROOF_LEN]);
 
 /* ---- PlonK (gnark / SP1 format), BASELINE configs[3] --------------------------------------------------------------
  * Replaces PlonkVerifier::verify (verifier/src/lib.rs:69-73) = load_plonk_proof_from_bytes (plonk/converter.rs:121-178) +

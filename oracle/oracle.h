@@ -168,6 +168,10 @@ int orc_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk
 /* loop of the above over a batch; returns 0 */
 int orc_groth16_verify_many(const uint8_t* proofs, size_t proof_stride, const uint8_t* vk, size_t vk_len,
                             const uint8_t* inputs, size_t n_inputs, size_t n, int mode, uint8_t* status);
+/* batch mode of the same algorithm: vk loaded once, pairing(alpha, beta) computed once */
+int orc_groth16_verify_many_prepared(const uint8_t* proofs, size_t proof_stride, const uint8_t* vk, size_t vk_len,
+                                     const uint8_t* inputs, size_t n_inputs, size_t n, int mode, uint8_t* status);
+const char* orc_build_flags(void);   /* compiler + flags of this build, for the cpu_baseline line */
 /* PlonkVerifier::verify (lib.rs:69-74).  lambda32 = the KZG batching scalar (the reference draws it from OsRng,
  * plonk/kzg.rs:149-154); pass NULL for a fixed non-trivial constant. */
 int orc_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,

@@ -141,6 +141,19 @@ def groth16_verify_many(proofs, stride, vk, inputs_bytes, n_inputs, n, mode=MODE
     return _b(st)
 
 
+def groth16_verify_many_prepared(proofs, stride, vk, inputs_bytes, n_inputs, n, mode=MODE_REFERENCE):
+    """Batch mode of the same algorithm: key loaded once, pairing(alpha, beta) hoisted (second CPU row)."""
+    st = _buf(n)
+    lib().orc_groth16_verify_many_prepared(proofs, C.c_size_t(stride), vk, C.c_size_t(len(vk)), inputs_bytes, C.c_size_t(n_inputs), C.c_size_t(n), mode, st)
+    return _b(st)
+
+
+def build_flags():
+    """Compiler and flags the oracle was built with (reported in bench.py's cpu_baseline line)."""
+    lib().orc_build_flags.restype = C.c_char_p
+    return lib().orc_build_flags().decode()
+
+
 def plonk_verify(proof, vk, inputs, lam=None):
     ib = b"".join(i if isinstance(i, (bytes, bytearray)) else be32(i) for i in inputs)
     return lib().orc_plonk_verify(proof, C.c_size_t(len(proof)), vk, C.c_size_t(len(vk)), ib, C.c_size_t(len(inputs)), be32(lam) if lam is not None else None)

@@ -204,55 +204,69 @@ static int load_g16_vk(g16_vk* vk, const uint8_t* b, size_t n, int mode) {
   return ORC_ACCEPT;
 }
 
-int orc_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vkb, size_t vk_len,
-                       const uint8_t* inputs, size_t n_inputs, int mode) {
-  orc_init();
-  int st;
-  /* groth16/converter.rs:14-26 (lib.rs:45: unwrap) */
-  if (proof_len < 256) return ORC_ERR_MALFORMED;
-  g1a A, C; g2a B;
-  if ((st = dec_g1_uncompressed(&A, proof)) != ORC_ACCEPT) return st;
-  if ((st = dec_g2_uncompressed(&B, proof + 64)) != ORC_ACCEPT) return st;
-  if ((st = dec_g1_uncompressed(&C, proof + 192)) != ORC_ACCEPT) return st;
-  /* lib.rs:46 */
-  g16_vk vk;
-  if ((st = load_g16_vk(&vk, vkb, vk_len, mode)) != ORC_ACCEPT) { free(vk.k); return st; }
-  /* groth16/verify.rs:65-78 */
+/* groth16/verify.rs:65-78 given the loaded key and (batch mode only) a precomputed right-hand side */
+static void g16_rhs(fp12* rhs, const g16_vk* vk, int mode) {
+  if (mode == ORC_MODE_REFERENCE) {
+    pairing_batch(rhs, &vk->alpha, &vk->beta_neg2, 1);          /* verify.rs:70: pairing(alpha, vk.g2.beta) with g2.beta = -beta */
+  } else {
+    g2a beta; g2_neg_affine(&beta, &vk->beta_neg2);
+    pairing_batch(rhs, &vk->alpha, &beta, 1);
+  }
+}
+static int g16_core(const g1a* A, const g2a* B, const g1a* C, const g16_vk* vk, const fp12* rhs_pre,
+                    const uint8_t* inputs, size_t n_inputs, int mode) {
   fp12 lhs, rhs;
   g1a ps[3]; g2a qs[3];
-  if (mode == ORC_MODE_REFERENCE) {
-    pairing_batch(&rhs, &vk.alpha, &vk.beta_neg2, 1);          /* verify.rs:70: pairing(alpha, vk.g2.beta) with g2.beta = -beta */
-  } else {
-    g2a beta; g2_neg_affine(&beta, &vk.beta_neg2);
-    pairing_batch(&rhs, &vk.alpha, &beta, 1);
-  }
+  if (rhs_pre) rhs = *rhs_pre; else g16_rhs(&rhs, vk, mode);
   /* verify.rs:53-63 prepare_inputs */
-  if (n_inputs + 1 != vk.nk) { free(vk.k); return ORC_ERR_INPUT_LEN; }
-  g1j acc; g1_from_affine(&acc, &vk.k[0]);
+  if (n_inputs + 1 != vk->nk) return ORC_ERR_INPUT_LEN;
+  g1j acc; g1_from_affine(&acc, &vk->k[0]);
   for (size_t i = 0; i < n_inputs; i++) {
     u256 s; u256_from_be(&s, inputs + 32 * i); /* Fr::from_slice: stored as-is, no range check */
-    g1j b, t; g1_from_affine(&b, &vk.k[i + 1]);
+    g1j b, t; g1_from_affine(&b, &vk->k[i + 1]);
     g1_mul(&t, &b, &s);
     g1a ta; g1_to_affine(&ta, &t);             /* AffineG1 * Fr yields an affine point, then affine + */
     g1j tj; g1_from_affine(&tj, &ta);
     g1_add(&acc, &acc, &tj);
   }
   g1a L; g1_to_affine(&L, &acc);
-  ps[0] = A; qs[0] = B;
+  ps[0] = *A; qs[0] = *B;
   ps[1] = L;
-  ps[2] = C;
+  ps[2] = *C;
   if (mode == ORC_MODE_REFERENCE) {
-    qs[1] = vk.gamma;                            /* verify.rs:75 */
-    g2_neg_affine(&qs[2], &vk.delta2);           /* verify.rs:76 */
+    qs[1] = vk->gamma;                           /* verify.rs:75 */
+    g2_neg_affine(&qs[2], &vk->delta2);          /* verify.rs:76 */
     pairing_batch(&lhs, ps, qs, 3);
   } else {
     /* gnark: e(A,B) e(L,-gamma) e(C,-delta) == e(alpha,beta) */
-    g2_neg_affine(&qs[1], &vk.gamma);
-    g2_neg_affine(&qs[2], &vk.delta2);
+    g2_neg_affine(&qs[1], &vk->gamma);
+    g2_neg_affine(&qs[2], &vk->delta2);
     pairing_batch(&lhs, ps, qs, 3);
   }
-  free(vk.k);
   return fp12_eq(&lhs, &rhs) ? ORC_ACCEPT : ORC_REJECT;
+}
+/* groth16/converter.rs:14-26 (lib.rs:45: unwrap) */
+static int g16_load_proof(g1a* A, g2a* B, g1a* C, const uint8_t* proof, size_t proof_len) {
+  int st;
+  if (proof_len < 256) return ORC_ERR_MALFORMED;
+  if ((st = dec_g1_uncompressed(A, proof)) != ORC_ACCEPT) return st;
+  if ((st = dec_g2_uncompressed(B, proof + 64)) != ORC_ACCEPT) return st;
+  if ((st = dec_g1_uncompressed(C, proof + 192)) != ORC_ACCEPT) return st;
+  return ORC_ACCEPT;
+}
+
+int orc_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vkb, size_t vk_len,
+                       const uint8_t* inputs, size_t n_inputs, int mode) {
+  orc_init();
+  int st;
+  g1a A, C; g2a B;
+  if ((st = g16_load_proof(&A, &B, &C, proof, proof_len)) != ORC_ACCEPT) return st;
+  /* lib.rs:46 */
+  g16_vk vk;
+  if ((st = load_g16_vk(&vk, vkb, vk_len, mode)) != ORC_ACCEPT) { free(vk.k); return st; }
+  st = g16_core(&A, &B, &C, &vk, NULL, inputs, n_inputs, mode);
+  free(vk.k);
+  return st;
 }
 
 int orc_groth16_verify_many(const uint8_t* proofs, size_t proof_stride, const uint8_t* vk, size_t vk_len,
@@ -263,6 +277,29 @@ int orc_groth16_verify_many(const uint8_t* proofs, size_t proof_stride, const ui
   for (long i = 0; i < (long)n; i++)
     status[i] = (uint8_t)orc_groth16_verify(proofs + (size_t)i * proof_stride, proof_stride, vk, vk_len,
                                             inputs + (size_t)i * n_inputs * 32, n_inputs, mode);
+  return 0;
+}
+
+/* Batch mode of the same algorithm (second CPU row): the key is loaded once (lib.rs:46 hoisted) and
+ * pairing(alpha, beta) computed once (groth16/verify.rs:70 hoisted); everything per proof is unchanged (naive subgroup check,
+ * bit-by-bit prepare_inputs, 3-pair pairing_batch with its final exponentiation).  Same status bytes as orc_groth16_verify_many. */
+int orc_groth16_verify_many_prepared(const uint8_t* proofs, size_t proof_stride, const uint8_t* vkb, size_t vk_len,
+                                     const uint8_t* inputs, size_t n_inputs, size_t n, int mode, uint8_t* status) {
+  orc_init();
+  { g1a g; g1_generator(&g); }
+  g16_vk vk;
+  int vst = load_g16_vk(&vk, vkb, vk_len, mode);
+  fp12 rhs;
+  if (vst == ORC_ACCEPT) g16_rhs(&rhs, &vk, mode);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (long i = 0; i < (long)n; i++) {
+    g1a A, C; g2a B;
+    int st = g16_load_proof(&A, &B, &C, proofs + (size_t)i * proof_stride, proof_stride);   /* proof errors come first (lib.rs:45) */
+    if (st == ORC_ACCEPT) st = vst;
+    if (st == ORC_ACCEPT) st = g16_core(&A, &B, &C, &vk, &rhs, inputs + (size_t)i * n_inputs * 32, n_inputs, mode);
+    status[i] = (uint8_t)st;
+  }
+  free(vk.k);
   return 0;
 }
 
@@ -689,3 +726,7 @@ void orc_set_threads(int n) {
 #endif
 }
 void orc_reset_fp_mul_count(void) { orc_fp_mul_count = 0; }
+#ifndef ORC_CFLAGS
+#define ORC_CFLAGS "unknown flags"
+#endif
+const char* orc_build_flags(void) { return "gcc " __VERSION__ " " ORC_CFLAGS; }

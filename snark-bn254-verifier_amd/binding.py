@@ -7,6 +7,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 REJECT, ACCEPT, ERR_NOT_MEMBER, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP, ERR_INPUT_LEN, ERR_MALFORMED = range(7)
 VK_REFERENCE, VK_GNARK = 0, 1
+FLAG_STRICT_SCALARS, FLAG_RLC = 1, 2
+RAW_PROOF_LEN = 324
 NUM_KERNELS = 4
 
 
@@ -45,8 +47,10 @@ def lib():
         L.bn254_groth16_vk_prepare.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.POINTER(C.c_void_p)]
         L.bn254_groth16_vk_free.argtypes = [C.c_void_p]
         L.bn254_groth16_vk_num_public.argtypes = [C.c_void_p]
-        L.bn254_groth16_verify_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
-        L.bn254_groth16_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        L.bn254_groth16_verify_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_uint]
+        L.bn254_groth16_verify_batch_multi.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint]
+        L.bn254_groth16_proof_write_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p]
+        L.bn254_groth16_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
         L.bn254_groth16_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
         L.bn254_groth16_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p]
         L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
@@ -139,19 +143,29 @@ class PreparedVk:
     def handle(self):
         return self._h
 
-    def verify_batch(self, proofs, public_inputs, n=None, proof_stride=256, n_public=None, device=0):
-        """proofs: bytes (n * proof_stride); public_inputs: bytes (n * n_public * 32). Returns n status bytes."""
+    def verify_batch(self, proofs, public_inputs, n=None, proof_stride=256, n_public=None, device=0, flags=0):
+        """proofs: bytes (n * proof_stride); public_inputs: bytes (n * n_public * 32). Returns n status bytes.
+        flags: FLAG_STRICT_SCALARS | FLAG_RLC (include/bn254_verify.h)."""
         n_public = self.n_public if n_public is None else n_public
         if n is None:
             n = len(proofs) // proof_stride
         st = (C.c_uint8 * max(n, 1))()
-        _check(lib().bn254_groth16_verify_batch(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device))
+        _check(lib().bn254_groth16_verify_batch(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device, flags))
         return bytes(st)[:n]
 
-    def verify_batch_device(self, d_proofs, d_inputs, d_status, n, proof_stride=256, n_public=None, device=0, stream=None):
-        """Raw device pointers (ints); enqueues on `stream` (a hipStream_t value) and returns."""
+    def verify_batch_multi(self, proofs, public_inputs, device_mask, n=None, proof_stride=256, n_public=None, flags=0):
+        """Same over the GPUs selected by the bits of device_mask (contiguous shards, one host thread per device)."""
         n_public = self.n_public if n_public is None else n_public
-        _check(lib().bn254_groth16_verify_batch_device(self._h, d_proofs, proof_stride, d_inputs, n_public, n, d_status, device, stream))
+        if n is None:
+            n = len(proofs) // proof_stride
+        st = (C.c_uint8 * max(n, 1))()
+        _check(lib().bn254_groth16_verify_batch_multi(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device_mask, flags))
+        return bytes(st)[:n]
+
+    def verify_batch_device(self, d_proofs, d_inputs, d_status, n, proof_stride=256, n_public=None, device=0, stream=None, flags=0):
+        """Raw device pointers (ints); enqueues on `stream` (a hipStream_t value) and returns (FLAG_RLC: after one stream sync)."""
+        n_public = self.n_public if n_public is None else n_public
+        _check(lib().bn254_groth16_verify_batch_device(self._h, d_proofs, proof_stride, d_inputs, n_public, n, d_status, device, stream, flags))
 
     def reserve(self, n, device=0):
         _check(lib().bn254_groth16_reserve(self._h, n, device))
@@ -207,6 +221,13 @@ class Groth16Verifier:
             return [ERR_MALFORMED if s else v for s, v in zip(short, st)]
         finally:
             pvk.close()
+
+
+def proof_write_raw(a, b, c):
+    """The 324-byte raw gnark proof (A | B | C | no commitments | zero PoK) that groth16/converter.rs:14-26 reads."""
+    out = (C.c_uint8 * RAW_PROOF_LEN)()
+    _check(lib().bn254_groth16_proof_write_raw(bytes(a), bytes(b), bytes(c), out))
+    return bytes(out)
 
 
 def synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=0):

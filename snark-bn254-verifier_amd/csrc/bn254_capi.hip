@@ -10,6 +10,9 @@
 #include "../../include/bn254_verify.h"
 #include "bn254_host.hpp"
 #include "bn254_plonk.hpp"
+#include "bn254_rlc.h"
+#include <sys/random.h>
+#include <atomic>
 #include <thread>
 #include <chrono>
 #include <cstdio>
@@ -21,26 +24,52 @@ static_assert(BN254_REJECT == BN254_ST_REJECT && BN254_ACCEPT == BN254_ST_ACCEPT
 using namespace bn254host;
 
 static thread_local std::string g_err;
-static int g_profiling = 0;
-static unsigned g_prof_mask = 0xffffffffu;
+static std::atomic<int> g_profiling{0};
+static std::atomic<unsigned> g_prof_mask{0xffffffffu};
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(BN254_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+// BN254_FLAG_RLC: per (key, device) buffers of the random-linear-combination batch mode (bn254_rlc.h)
+#define RLC_MIN_BATCH 64
+struct RlcDev {
+  bool ready = false;
+  int32_t *btab = nullptr, *tab = nullptr, *one = nullptr;            // key-side tables (uploaded once)
+  uint8_t* grp_status = nullptr; size_t grp_cap = 0;
+  uint32_t* idx = nullptr; size_t idx_cap = 0;
+  uint8_t *fb_proofs = nullptr, *fb_inputs = nullptr, *fb_status = nullptr; size_t fb_cap = 0, fb_in_cap = 0;
+  uint8_t* h_status = nullptr; uint32_t* h_idx = nullptr; size_t h_cap = 0;   // pinned
+};
+static void rlc_dev_free(RlcDev& r) {
+  void* ptrs[] = {r.btab, r.tab, r.one, r.grp_status, r.idx, r.fb_proofs, r.fb_inputs, r.fb_status};
+  for (auto q : ptrs) if (q) (void)hipFree(q);
+  if (r.h_status) (void)hipHostFree(r.h_status);
+  if (r.h_idx) (void)hipHostFree(r.h_idx);
+  r = RlcDev();
+}
+
+// Per (key, device) state.  `mu` serialises everything that touches it: uploads, (re)allocation and the enqueue of a batch.  The
+// workspace and the staging buffers are shared by all batches against this key on this device, so a batch first waits (on the GPU:
+// hipStreamWaitEvent) for `busy_ev`, the completion event of the previous batch, whatever stream that one ran on.
 struct DevState {
+  std::mutex mu;
   bool ready = false;
   int32_t *k0 = nullptr, *gtab = nullptr, *dtab = nullptr, *target = nullptr, *msm = nullptr;
   int32_t* ws = nullptr; size_t ws_cap = 0;                         // proofs the workspace can hold
   int32_t* msm_part = nullptr; size_t msm_part_cap = 0;             // wide keys: partial sums of the public-input MSM (proofs it holds)
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
   size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
+  hipStream_t host_stream = nullptr, copy_stream = nullptr; std::vector<hipEvent_t> copy_ev;   // host-buffer entry: chunked copy/compute overlap
+  hipEvent_t busy_ev = nullptr; bool busy_valid = false;
   hipEvent_t ev[5]; bool ev_ready = false; bool ev_recorded = false;
-  hipStream_t aux[4]; hipEvent_t fork_ev, join_ev[4]; bool aux_ready = false;  // concurrent sub-batches (see verify_batch_device)
+  hipStream_t aux[4]; hipEvent_t fork_ev, join_ev[4]; bool aux_ready = false;  // concurrent sub-batches (see g16_enqueue)
   // per-launch timing of the first sub-batch (bn254_groth16_kernel_profile)
   std::vector<hipEvent_t> prof_ev; std::vector<uint8_t> prof_kid; G16Prof prof{0, nullptr, nullptr, 0, 0}; size_t prof_n = 0;
+  RlcDev rlc;                                                       // BN254_FLAG_RLC buffers (bn254_rlc.hpp)
 };
 struct bn254_g16_pvk {
   G16Prepared host;
-  mutable std::mutex mu;
+  mutable G16PreparedRlc rlc_host;       // built on the first BN254_FLAG_RLC batch (under mu)
+  mutable std::mutex mu;                 // protects the map below (lookup / insertion only) and rlc_host
   mutable std::map<int, DevState> dev;
 };
 
@@ -58,25 +87,30 @@ template <typename T> static int upload(T** dst, const std::vector<T>& src) {
   if (!src.empty()) HIPCK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
   return BN254_OK;
 }
-static int ensure_dev(const bn254_g16_pvk* pvk, int device, size_t n, DevState** out) {
+static DevState* dev_state(const bn254_g16_pvk* pvk, int device) {
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  return &pvk->dev[device];   // std::map nodes never move
+}
+// caller holds d.mu
+static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t n) {
   int rc = check_device(device);
   if (rc) return rc;
-  DevState& d = pvk->dev[device];
   if (!d.ready) {
     if ((rc = upload(&d.k0, pvk->host.k0)) || (rc = upload(&d.gtab, pvk->host.gtab)) || (rc = upload(&d.dtab, pvk->host.dtab)) ||
         (rc = upload(&d.target, pvk->host.target)) || (rc = upload(&d.msm, pvk->host.msm)))
       return rc;
+    HIPCK(hipEventCreateWithFlags(&d.busy_ev, hipEventDisableTiming));
     d.ready = true;
   }
   if ((n > G16_MAX_BATCH ? (size_t)G16_MAX_BATCH : n) > d.ws_cap) {
-    if (d.ws) HIPCK(hipFree(d.ws));
+    if (d.ws) HIPCK(hipFree(d.ws));   // hipFree waits for the device: no batch is still using the old workspace
     d.ws = nullptr; d.ws_cap = 0;
     size_t cap = (n + 255) / 256 * 256;
     if (cap > G16_MAX_BATCH) cap = G16_MAX_BATCH;  // larger batches run in chunks (32-bit buffer offsets)
     HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_BYTES_PER_PROOF));
     d.ws_cap = cap;
   }
-  if (g_profiling && !d.ev_ready) {
+  if (g_profiling.load() && !d.ev_ready) {
     for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i]));
     const int cap = 1024;  // launches per sub-batch: ~720
     d.prof_ev.resize(2 * cap); d.prof_kid.resize(cap);
@@ -84,8 +118,27 @@ static int ensure_dev(const bn254_g16_pvk* pvk, int device, size_t n, DevState**
     d.prof.ev = d.prof_ev.data(); d.prof.kid = d.prof_kid.data(); d.prof.cap = cap;
     d.ev_ready = true;
   }
-  *out = &d;
   return BN254_OK;
+}
+static int ensure_aux(DevState& d) {
+  if (d.aux_ready) return BN254_OK;
+  for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d.aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d.join_ev[i], hipEventDisableTiming)); }
+  HIPCK(hipEventCreateWithFlags(&d.fork_ev, hipEventDisableTiming));
+  d.aux_ready = true;
+  return BN254_OK;
+}
+static void dev_free(DevState& d) {
+  int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, d.msm_part};
+  for (auto q : ptrs) if (q) (void)hipFree(q);
+  uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
+  for (auto q : bp) if (q) (void)hipFree(q);
+  if (d.ev_ready) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(d.ev[i]); for (auto& e : d.prof_ev) (void)hipEventDestroy(e); }
+  if (d.aux_ready) { for (int i = 0; i < 4; i++) { (void)hipStreamDestroy(d.aux[i]); (void)hipEventDestroy(d.join_ev[i]); } (void)hipEventDestroy(d.fork_ev); }
+  if (d.busy_ev) (void)hipEventDestroy(d.busy_ev);
+  if (d.host_stream) (void)hipStreamDestroy(d.host_stream);
+  if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
+  for (auto& e : d.copy_ev) (void)hipEventDestroy(e);
+  rlc_dev_free(d.rlc);
 }
 static int grow(uint8_t** p, size_t* cap, size_t need) {
   if (need <= *cap) return BN254_OK;
@@ -172,8 +225,8 @@ const char* bn254_status_string(int s) {
     default: return "unknown";
   }
 }
-void bn254_set_profiling(int enabled) { g_profiling = enabled; }
-void bn254_set_profile_kernels(unsigned mask) { g_prof_mask = mask; }
+void bn254_set_profiling(int enabled) { g_profiling.store(enabled); }
+void bn254_set_profile_kernels(unsigned mask) { g_prof_mask.store(mask); }
 int bn254_groth16_num_kernel_kinds(void) { return KID_COUNT; }
 const char* bn254_groth16_kernel_kind_name(int i) { return (i >= 0 && i < KID_COUNT) ? bn254_kernel_kind_names[i] : ""; }
 const char* bn254_groth16_kernel_name(int i) {
@@ -195,13 +248,9 @@ int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn
 void bn254_groth16_vk_free(bn254_g16_pvk* pvk) {
   if (!pvk) return;
   for (auto& kv : pvk->dev) {
-    DevState& d = kv.second;
     if (hipSetDevice(kv.first) != hipSuccess) continue;
-    int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, d.msm_part};
-    for (auto q : ptrs) if (q) (void)hipFree(q);
-    uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
-    for (auto q : bp) if (q) (void)hipFree(q);
-    if (d.ev_ready) for (int i = 0; i < 5; i++) (void)hipEventDestroy(d.ev[i]);
+    (void)hipDeviceSynchronize();
+    dev_free(kv.second);
   }
   delete pvk;
 }
@@ -209,24 +258,21 @@ size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk) { return pvk ? pvk-
 
 int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device) {
   if (!pvk) return set_err(BN254_E_BAD_ARG, "null key");
-  std::lock_guard<std::mutex> lk(pvk->mu);
-  DevState* d;
-  return ensure_dev(pvk, device, n ? n : 1, &d);
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  return ensure_dev(pvk, *d, device, n ? n : 1);
 }
 
-int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_inputs,
-                                      size_t n_public, size_t n, void* d_status, int device, void* hip_stream) {
-  if (!pvk || (n && (!d_proofs || !d_status)) || proof_stride < 256 || (n && n_public && !d_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
-  if (n == 0) return BN254_OK;
-  std::lock_guard<std::mutex> lk(pvk->mu);
-  DevState* d;
-  int rc = ensure_dev(pvk, device, n, &d);
-  if (rc) return rc;
+}  // extern "C"
+
+// Enqueue the exact pipeline for n proofs on `user`.  Caller holds d->mu and has called ensure_dev.
+static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* d_proofs, size_t proof_stride, const void* d_inputs,
+                             size_t n_public, size_t n, void* d_status, hipStream_t user, unsigned flags) {
   // BN254_STREAMS = 1..4 sub-batches in flight (default 2: +4.5 % over one stream at 2^20, profiles/r01_streams.txt)
   static const int n_streams = [] { const char* e = getenv("BN254_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-  hipStream_t user = (hipStream_t)hip_stream;
   // BN254_CHUNK_LOG2 (experiment): proofs per workspace chunk, default 2^20
   static const size_t chunk = [] { const char* e = getenv("BN254_CHUNK_LOG2"); int v = e ? atoi(e) : 20; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
+  const int profiling = g_profiling.load();
   for (size_t off = 0; off < n; off += chunk) {
     size_t m = n - off < chunk ? n - off : chunk;
     // sub-batches on concurrent streams: the tail of one sub-batch's kernel overlaps the head of the other's
@@ -248,11 +294,7 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
     while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
     const bool concurrent = !wide && n_streams > 1 && parts > 1;
     const bool split_small = m <= (size_t)G16_SPLIT_MAX_PROOFS;   // latency mode of bn254_launch_g16
-    if ((concurrent || split_small) && !d->aux_ready) {
-      for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d->join_ev[i], hipEventDisableTiming)); }
-      HIPCK(hipEventCreateWithFlags(&d->fork_ev, hipEventDisableTiming));
-      d->aux_ready = true;
-    }
+    if (concurrent || split_small) { int rc = ensure_aux(*d); if (rc) return rc; }
     if (concurrent) HIPCK(hipEventRecord(d->fork_ev, user));
     size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
     for (int pi = 0; pi < parts; pi++) {
@@ -266,41 +308,167 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
       a.ws = d->ws + lo * (size_t)(G16_WS_BYTES_PER_PROOF / 4); a.status = (uint8_t*)d_status + off + lo; a.msm_tab = d->msm; a.k0 = d->k0;
       a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
       a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
+      a.strict_scalars = (flags & BN254_FLAG_STRICT_SCALARS) ? 1 : 0;
       a.msm_part = wide ? d->msm_part : nullptr;
       if (split_small && parts == 1) {
         a.split_streams[0] = d->aux[1]; a.split_streams[1] = d->aux[2];
         a.split_ev[0] = d->fork_ev; a.split_ev[1] = d->join_ev[1]; a.split_ev[2] = d->join_ev[2];
       }
       // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
-      const bool prof_this = g_profiling && d->ev_ready && pi == 0;
-      if (prof_this) { d->prof.mask = g_prof_mask; d->prof.used = 0; d->prof_n = a.n; }
+      const bool prof_this = profiling && d->ev_ready && pi == 0;
+      if (prof_this) { d->prof.mask = g_prof_mask.load(); d->prof.used = 0; d->prof_n = a.n; }
       hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : nullptr);
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));
       if (concurrent && (pi + 4 >= parts)) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
     }
   }
-  d->ev_recorded = g_profiling && d->ev_ready;
+  d->ev_recorded = profiling && d->ev_ready;
   return BN254_OK;
+}
+
+// ---- BN254_FLAG_RLC (bn254_rlc.h): first pass in groups, exact second pass over the proofs of groups that failed -----------------------------
+static int rlc_ensure(const bn254_g16_pvk* pvk, DevState* d, size_t n, size_t n_public) {
+  RlcDev& r = d->rlc;
+  if (!r.ready) {
+    {
+      std::lock_guard<std::mutex> lk(pvk->mu);
+      if (!pvk->rlc_host.ready && !prepare_g16_rlc(pvk->rlc_host, pvk->host)) return set_err(BN254_E_VK, "degenerate key element (RLC tables)");
+    }
+    int rc;
+    if ((rc = upload(&r.btab, pvk->rlc_host.btab)) || (rc = upload(&r.tab, pvk->rlc_host.tab)) || (rc = upload(&r.one, pvk->rlc_host.one))) return rc;
+    r.ready = true;
+  }
+  if (n > r.grp_cap) {
+    if (r.grp_status) HIPCK(hipFree(r.grp_status));
+    if (r.idx) HIPCK(hipFree(r.idx));
+    if (r.h_status) HIPCK(hipHostFree(r.h_status));
+    if (r.h_idx) HIPCK(hipHostFree(r.h_idx));
+    r.grp_status = nullptr; r.idx = nullptr; r.h_status = nullptr; r.h_idx = nullptr; r.grp_cap = r.idx_cap = r.h_cap = 0;
+    const size_t cap = (n + 255) / 256 * 256 + 1024;   // group status regions of the launch parts are rounded up to 256 each
+    HIPCK(hipMalloc((void**)&r.grp_status, cap));
+    HIPCK(hipMalloc((void**)&r.idx, cap * sizeof(uint32_t)));
+    HIPCK(hipHostMalloc((void**)&r.h_status, cap, hipHostMallocDefault));
+    HIPCK(hipHostMalloc((void**)&r.h_idx, cap * sizeof(uint32_t), hipHostMallocDefault));
+    r.grp_cap = r.idx_cap = r.h_cap = n;
+  }
+  (void)n_public;
+  return BN254_OK;
+}
+static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, const void* d_proofs, size_t proof_stride, const void* d_inputs,
+                           size_t n_public, size_t n, void* d_status, hipStream_t user, unsigned flags) {
+  (void)device;
+  static const int n_streams = [] { const char* e = getenv("BN254_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  static const int log2_group = [] { const char* e = getenv("BN254_RLC_GROUP_LOG2"); int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+  uint32_t key[11];
+  if (getrandom(key, sizeof key, 0) != (ssize_t)sizeof key) return set_err(BN254_E_HIP, "getrandom failed: no weights for the RLC mode");
+  const size_t chunk = G16_MAX_BATCH;
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t m = n - off < chunk ? n - off : chunk;
+    int rc = rlc_ensure(pvk, d, m, n_public);
+    if (rc) return rc;
+    RlcDev& r = d->rlc;
+    int parts = (n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
+    while ((m + parts - 1) / parts > (size_t)G16_MAX_LAUNCH) parts++;
+    const bool concurrent = parts > 1;
+    if (concurrent) { rc = ensure_aux(*d); if (rc) return rc; HIPCK(hipEventRecord(d->fork_ev, user)); }
+    const size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
+    size_t grp_off = 0;
+    for (int pi = 0; pi < parts; pi++) {
+      const size_t lo = (size_t)pi * per, hi = lo + per < m ? lo + per : m;
+      if (lo >= hi) break;
+      hipStream_t st = concurrent ? d->aux[pi % 4] : user;
+      if (concurrent && pi < 4) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
+      G16LaunchArgs a;
+      a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
+      a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
+      a.ws = d->ws + lo * (size_t)(G16_WS_BYTES_PER_PROOF / 4); a.status = (uint8_t*)d_status + off + lo; a.msm_tab = d->msm; a.k0 = d->k0;
+      a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
+      a.inputs_match_key = 1;
+      a.strict_scalars = (flags & BN254_FLAG_STRICT_SCALARS) ? 1 : 0;
+      a.msm_part = nullptr;
+      RlcLaunchArgs ra;
+      memcpy(ra.key, key, sizeof key);
+      ra.counter_base = (uint32_t)(off + lo);
+      ra.plan = rlc_plan((uint32_t)a.n, log2_group);
+      ra.grp_status = r.grp_status + grp_off; grp_off += ((size_t)ra.plan.groups + 255) / 256 * 256;
+      ra.btab = r.btab; ra.rlc_tab = r.tab; ra.one = r.one;
+      hipError_t e = bn254_launch_g16_rlc(a, ra, st);
+      if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
+                                           std::string("kernel launch (rlc): ") + hipGetErrorString(e));
+      if (concurrent && (pi + 4 >= parts)) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
+    }
+    // which proofs are still pending (their group's product was not one)?  One stream synchronisation per chunk.
+    HIPCK(hipMemcpyAsync(r.h_status, (const uint8_t*)d_status + off, m, hipMemcpyDeviceToHost, user));
+    HIPCK(hipStreamSynchronize(user));
+    uint32_t cnt = 0;
+    for (size_t i = 0; i < m; i++) if (r.h_status[i] == BN254_ST_PENDING) r.h_idx[cnt++] = (uint32_t)i;
+    if (cnt == 0) continue;
+    if (cnt > r.fb_cap || (size_t)cnt * n_public * 32 > r.fb_in_cap) {
+      void* ptrs[] = {r.fb_proofs, r.fb_inputs, r.fb_status};
+      for (auto q : ptrs) if (q) HIPCK(hipFree(q));
+      r.fb_proofs = r.fb_inputs = r.fb_status = nullptr; r.fb_cap = r.fb_in_cap = 0;
+      const size_t cap = ((size_t)cnt + 4095) / 4096 * 4096;
+      HIPCK(hipMalloc((void**)&r.fb_proofs, cap * 256));
+      HIPCK(hipMalloc((void**)&r.fb_inputs, cap * (n_public ? n_public : 1) * 32));
+      HIPCK(hipMalloc((void**)&r.fb_status, cap));
+      r.fb_cap = cap; r.fb_in_cap = cap * n_public * 32;
+    }
+    HIPCK(hipMemcpyAsync(r.idx, r.h_idx, (size_t)cnt * sizeof(uint32_t), hipMemcpyHostToDevice, user));
+    hipError_t e = bn254_launch_gather_rows(r.fb_proofs, (const uint8_t*)d_proofs + off * proof_stride, proof_stride, 256, r.idx, cnt, user);
+    if (e == hipSuccess && n_public) e = bn254_launch_gather_rows(r.fb_inputs, (const uint8_t*)d_inputs + off * n_public * 32, n_public * 32, (uint32_t)(n_public * 32), r.idx, cnt, user);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("gather launch: ") + hipGetErrorString(e));
+    rc = g16_enqueue_exact(pvk, d, r.fb_proofs, 256, r.fb_inputs, n_public, cnt, r.fb_status, user, flags);
+    if (rc) return rc;
+    e = bn254_launch_scatter_status((uint8_t*)d_status + off, r.fb_status, r.idx, cnt, user);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("scatter launch: ") + hipGetErrorString(e));
+  }
+  return BN254_OK;
+}
+// one batch on `user`: waits for the previous batch of this (key, device), runs the exact or the RLC pipeline, records busy_ev
+static int g16_enqueue(const bn254_g16_pvk* pvk, DevState* d, int device, const void* d_proofs, size_t proof_stride, const void* d_inputs,
+                       size_t n_public, size_t n, void* d_status, hipStream_t user, unsigned flags) {
+  if (d->busy_valid) HIPCK(hipStreamWaitEvent(user, d->busy_ev, 0));
+  int rc;
+  const bool rlc = (flags & BN254_FLAG_RLC) && n_public + 1 == pvk->host.n_k && n_public <= (size_t)RLC_MAX_PUBLIC && n >= (size_t)RLC_MIN_BATCH;
+  if (rlc) rc = g16_enqueue_rlc(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
+  else rc = g16_enqueue_exact(pvk, d, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
+  if (rc) return rc;
+  HIPCK(hipEventRecord(d->busy_ev, user));
+  d->busy_valid = true;
+  return BN254_OK;
+}
+
+extern "C" {
+
+int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_inputs,
+                                      size_t n_public, size_t n, void* d_status, int device, void* hip_stream, unsigned flags) {
+  if (!pvk || (n && (!d_proofs || !d_status)) || proof_stride < 256 || (n && n_public && !d_inputs) || (flags & ~3u)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (n == 0) return BN254_OK;
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  int rc = ensure_dev(pvk, *d, device, n);
+  if (rc) return rc;
+  return g16_enqueue(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, (hipStream_t)hip_stream, flags);
 }
 
 int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]) {
   if (!pvk || !ms) return set_err(BN254_E_BAD_ARG, "bad argument");
-  std::lock_guard<std::mutex> lk(pvk->mu);
-  auto it = pvk->dev.find(device);
-  if (it == pvk->dev.end() || !it->second.ev_recorded) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (!d->ev_recorded) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
   HIPCK(hipSetDevice(device));
-  HIPCK(hipEventSynchronize(it->second.ev[4]));
-  for (int i = 0; i < BN254_G16_NUM_KERNELS; i++) HIPCK(hipEventElapsedTime(&ms[i], it->second.ev[i], it->second.ev[i + 1]));
+  HIPCK(hipEventSynchronize(d->ev[4]));
+  for (int i = 0; i < BN254_G16_NUM_KERNELS; i++) HIPCK(hipEventElapsedTime(&ms[i], d->ev[i], d->ev[i + 1]));
   return BN254_OK;
 }
 
 int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned launches[], float total_ms[], size_t* proofs_per_launch) {
   if (!pvk || !launches || !total_ms) return set_err(BN254_E_BAD_ARG, "bad argument");
-  std::lock_guard<std::mutex> lk(pvk->mu);
-  auto it = pvk->dev.find(device);
-  if (it == pvk->dev.end() || !it->second.ev_recorded) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
-  DevState& d = it->second;
+  DevState* dp = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(dp->mu);
+  DevState& d = *dp;
+  if (!d.ev_recorded) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
   HIPCK(hipSetDevice(device));
   for (int k = 0; k < KID_COUNT; k++) { launches[k] = 0; total_ms[k] = 0.f; }
   for (int i = 0; i < d.prof.used; i++) {
@@ -313,28 +481,66 @@ int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned 
   return BN254_OK;
 }
 
+// Host buffers: the batch is cut into chunks; the copy of chunk k + 1 (on the copy stream) overlaps the kernels of chunk k (on the
+// compute stream), only stream-scoped synchronisation, one status copy at the end.  The device lock is held for the whole call:
+// the staging buffers belong to this batch until its statuses are back.
 int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
-                               size_t n_public, size_t n, uint8_t* status, int device) {
-  if (!pvk || (n && (!proofs || !status)) || proof_stride < 256 || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+                               size_t n_public, size_t n, uint8_t* status, int device, unsigned flags) {
+  if (!pvk || (n && (!proofs || !status)) || proof_stride < 256 || (n && n_public && !public_inputs) || (flags & ~3u)) return set_err(BN254_E_BAD_ARG, "bad argument");
   if (n == 0) return BN254_OK;
-  uint8_t *dp, *di, *ds;
-  {
-    std::lock_guard<std::mutex> lk(pvk->mu);
-    DevState* d;
-    int rc = ensure_dev(pvk, device, n, &d);
-    if (rc) return rc;
-    size_t pb = n * proof_stride, ib = n * n_public * 32;
-    if ((rc = grow(&d->st_proofs, &d->st_proofs_cap, pb)) || (rc = grow(&d->st_inputs, &d->st_inputs_cap, ib ? ib : 32)) ||
-        (rc = grow(&d->st_status, &d->st_status_cap, n)))
-      return rc;
-    dp = d->st_proofs; di = d->st_inputs; ds = d->st_status;
-    HIPCK(hipMemcpy(dp, proofs, pb, hipMemcpyHostToDevice));
-    if (ib) HIPCK(hipMemcpy(di, public_inputs, ib, hipMemcpyHostToDevice));
-  }
-  int rc = bn254_groth16_verify_batch_device(pvk, dp, proof_stride, di, n_public, n, ds, device, nullptr);
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  int rc = ensure_dev(pvk, *d, device, n);
   if (rc) return rc;
-  HIPCK(hipDeviceSynchronize());
-  HIPCK(hipMemcpy(status, ds, n, hipMemcpyDeviceToHost));
+  size_t pb = n * proof_stride, ib = n * n_public * 32;
+  if ((rc = grow(&d->st_proofs, &d->st_proofs_cap, pb)) || (rc = grow(&d->st_inputs, &d->st_inputs_cap, ib ? ib : 32)) ||
+      (rc = grow(&d->st_status, &d->st_status_cap, n)))
+    return rc;
+  if (!d->host_stream) { HIPCK(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking)); }
+  static const size_t hchunk = [] { const char* e = getenv("BN254_HOST_CHUNK_LOG2"); int v = e ? atoi(e) : 18; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
+  // the RLC mode forms its groups over the whole batch it is handed: keep it in one piece
+  const size_t step = (flags & BN254_FLAG_RLC) ? n : hchunk;
+  size_t ci = 0;
+  for (size_t off = 0; off < n; off += step, ci++) {
+    const size_t m = n - off < step ? n - off : step;
+    if (ci >= d->copy_ev.size()) { hipEvent_t e; HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->copy_ev.push_back(e); }
+    HIPCK(hipMemcpyAsync(d->st_proofs + off * proof_stride, proofs + off * proof_stride, m * proof_stride, hipMemcpyHostToDevice, d->copy_stream));
+    if (ib) HIPCK(hipMemcpyAsync(d->st_inputs + off * n_public * 32, public_inputs + off * n_public * 32, m * n_public * 32, hipMemcpyHostToDevice, d->copy_stream));
+    HIPCK(hipEventRecord(d->copy_ev[ci], d->copy_stream));
+    HIPCK(hipStreamWaitEvent(d->host_stream, d->copy_ev[ci], 0));
+    rc = g16_enqueue(pvk, d, device, d->st_proofs + off * proof_stride, proof_stride, d->st_inputs + off * n_public * 32, n_public, m, d->st_status + off, d->host_stream, flags);
+    if (rc) return rc;
+  }
+  HIPCK(hipMemcpyAsync(status, d->st_status, n, hipMemcpyDeviceToHost, d->host_stream));
+  HIPCK(hipStreamSynchronize(d->host_stream));
+  return BN254_OK;
+}
+
+int bn254_groth16_verify_batch_multi(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                                     size_t n_public, size_t n, uint8_t* status, uint64_t device_mask, unsigned flags) {
+  if (!pvk || !device_mask) return set_err(BN254_E_BAD_ARG, "bad argument");
+  std::vector<int> devs;
+  for (int b = 0; b < 64; b++) if ((device_mask >> b) & 1) devs.push_back(b);
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return set_err(BN254_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  for (int dv : devs) if (dv >= cnt) return set_err(BN254_E_BAD_ARG, "device_mask selects a device that does not exist");
+  const size_t w = devs.size();
+  if (w == 1) return bn254_groth16_verify_batch(pvk, proofs, proof_stride, public_inputs, n_public, n, status, devs[0], flags);
+  // contiguous balanced shards (the first n % w devices get one more proof), one host thread per device
+  std::vector<int> rcs(w, BN254_OK); std::vector<std::string> errs(w);
+  std::vector<std::thread> th;
+  const size_t base = n / w, rem = n % w;
+  for (size_t r = 0; r < w; r++) {
+    const size_t lo = r * base + (r < rem ? r : rem), cntp = base + (r < rem ? 1 : 0);
+    th.emplace_back([&, r, lo, cntp]() {
+      if (!cntp) return;
+      rcs[r] = bn254_groth16_verify_batch(pvk, proofs + lo * proof_stride, proof_stride, public_inputs ? public_inputs + lo * n_public * 32 : nullptr, n_public, cntp,
+                                          status + lo, devs[r], flags);
+      if (rcs[r]) errs[r] = g_err;   // thread-local in the worker
+    });
+  }
+  for (auto& t : th) t.join();
+  for (size_t r = 0; r < w; r++) if (rcs[r]) return set_err(rcs[r], "device " + std::to_string(devs[r]) + ": " + errs[r]);
   return BN254_OK;
 }
 
@@ -354,9 +560,16 @@ int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* 
     return BN254_OK;
   }
   if (rc) return rc;
-  rc = bn254_groth16_verify_batch(pvk, proof, proof_len, public_inputs, n_public, 1, status, 0);
+  rc = bn254_groth16_verify_batch(pvk, proof, proof_len, public_inputs, n_public, 1, status, 0, 0);
   bn254_groth16_vk_free(pvk);
   return rc;
+}
+
+int bn254_groth16_proof_write_raw(const uint8_t a[64], const uint8_t b[128], const uint8_t c[64], uint8_t out[BN254_GROTH16_RAW_PROOF_LEN]) {
+  if (!a || !b || !c || !out) return set_err(BN254_E_BAD_ARG, "bad argument");
+  memcpy(out, a, 64); memcpy(out + 64, b, 128); memcpy(out + 192, c, 64);
+  memset(out + 256, 0, BN254_GROTH16_RAW_PROOF_LEN - 256);   // u32 nbCommitments = 0, then the 64-byte commitment PoK (zero)
+  return BN254_OK;
 }
 
 // ---------------------------------------------------------------- PlonK (BASELINE configs[3]): entry points

@@ -157,6 +157,7 @@ struct G16Prepared {
   std::vector<int32_t> gtab, dtab;       // BN_ATE_STEPS * FIXED_LINE_DWORDS
   std::vector<int32_t> target;           // 108
   std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS
+  G1Aff alpha, k0_pt; G2Aff b_arg;       // kept for the RLC tables (prepare_g16_rlc): alpha, K[0] and the G2 argument of the target pairing
 };
 inline void put_fp2(int32_t* o, const Fp2& a) { fp_to_limbs(o, a.c0); fp_to_limbs(o + BN_NL, a.c1); }
 inline void put_fp12(int32_t* o, const Fp12& a) {  // w-power (k) order, as the workspace stores Fp12 values (bn254_vm.h)
@@ -213,6 +214,7 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
     put_fp2(g_, tg[s].m); put_fp2(g_ + 2 * BN_NL, tg[s].c); put_fp2(g_ + 4 * BN_NL, tg[s].xc);
     put_fp2(d_, td[s].m); put_fp2(d_ + 2 * BN_NL, td[s].c); put_fp2(d_ + 4 * BN_NL, td[s].xc);
   }
+  out.alpha = vk.alpha; out.k0_pt = vk.k[0]; out.b_arg = b;
   Fp12 t = final_exponentiation(miller_loop<0>(vk.alpha, b, nullptr, nullptr));
   out.target.resize(12 * BN_NL);
   put_fp12(out.target.data(), t);
@@ -224,6 +226,29 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
   for (unsigned t_ = 0; t_ < hw; t_++)
     th.emplace_back([&, t_]() { for (size_t i = t_; i < nb; i += hw) build_window_table(out.msm.data() + i * 32 * 255 * MSM_ENTRY_DWORDS, vk.k[i + 1]); });
   for (auto& x : th) x.join();
+  return true;
+}
+
+// tables of the RLC batch mode (bn254_rlc.h): lines of the G2 argument paired with alpha, window tables of -alpha and K[0], 1 in GT
+struct G16PreparedRlc {
+  bool ready = false;
+  std::vector<int32_t> btab, tab, one;
+};
+inline bool prepare_g16_rlc(G16PreparedRlc& out, const G16Prepared& base) {
+  std::vector<FixedLine> tb(BN_ATE_STEPS);
+  if (!fixed_line_table(tb.data(), base.b_arg)) return false;
+  out.btab.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS);
+  for (int s = 0; s < BN_ATE_STEPS; s++) {
+    int32_t* b_ = out.btab.data() + (size_t)s * FIXED_LINE_DWORDS;
+    put_fp2(b_, tb[s].m); put_fp2(b_ + 2 * BN_NL, tb[s].c); put_fp2(b_ + 4 * BN_NL, tb[s].xc);
+  }
+  out.tab.assign((size_t)2 * 32 * 255 * MSM_ENTRY_DWORDS, 0);
+  std::thread t0([&]() { build_window_table(out.tab.data(), g1_neg(base.alpha)); });
+  build_window_table(out.tab.data() + (size_t)32 * 255 * MSM_ENTRY_DWORDS, base.k0_pt);
+  t0.join();
+  out.one.resize(12 * BN_NL);
+  put_fp12(out.one.data(), fp12_one());
+  out.ready = true;
   return true;
 }
 

@@ -14,7 +14,8 @@
 #define BN254_ST_MALFORMED 6
 #define BN254_ST_PENDING 0x80  // internal: no error so far (low 6 bits: deferred error of point C)
 #define BN254_ST_LINF 0x40     // internal: the public-input point L is the identity
-#define BN254_ST_LINF2 0x20    // internal (PlonK pairing check): the G1 point of the second fixed pair is the identity
+#define BN254_ST_LINF2 0x20    // internal (PlonK pairing check, RLC group stage): the G1 point of the second fixed pair is the identity
+#define BN254_ST_LINF3 0x10    // internal (RLC group stage): the G1 point of the third fixed pair is the identity
 
 #define MSM_ENTRY_DWORDS 20    // affine G1 point, 2 x 9 limbs + 2 pad: 80-byte entries, 16-byte aligned
 #define FIXED_LINE_DWORDS 54   // one precomputed Miller step of a fixed G2 argument: m, c, xi*c (3 Fp2)
@@ -38,6 +39,7 @@ struct G16LaunchArgs {
   const int32_t* dtab;      // same for the one paired with C
   const int32_t* target;    // 108 dwords: the GT element the product must equal, w-power (k) order
   int inputs_match_key;     // n_public + 1 == len(vk.K)
+  int strict_scalars = 0;   // BN254_FLAG_STRICT_SCALARS: inputs >= r -> NOT_MEMBER
   int32_t* msm_part;        // wide keys: ceil(n_public / G16_WIDE_MSM_INPUTS_PER_LANE) * 27 * n dwords of partial sums, else nullptr
   // small batches (n <= G16_SPLIT_MAX_PROOFS): two extra streams and three events (fork, join, join) let the three pairs run their
   // Miller loops as three concurrent chains (the GPU is mostly idle at such sizes: latency, not throughput, is what counts)
@@ -62,6 +64,20 @@ struct G16Prof {
   int cap, used;
 };
 hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev, G16Prof* prof);
+// RLC batch mode (bn254_rlc.h): one launch part = n <= G16_MAX_LAUNCH proofs forming plan.groups groups
+#include "bn254_rlc_plan.h"
+struct RlcLaunchArgs {
+  uint32_t key[11];         // ChaCha20 key (8 words) + nonce (3 words), fresh per call
+  uint32_t counter_base;    // global index of this part's first proof (weights are a function of the global index)
+  bn254::RlcPlan plan;
+  uint8_t* grp_status;      // >= round_up(plan.groups, 256) bytes
+  const int32_t* btab;      // line table of the G2 argument paired with alpha
+  const int32_t* rlc_tab;   // window tables of -alpha and K[0]: 2 * 32 * 255 entries of MSM_ENTRY_DWORDS
+  const int32_t* one;       // 108 dwords: 1 in GT
+};
+hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, hipStream_t s);
+hipError_t bn254_launch_gather_rows(uint8_t* dst, const uint8_t* src, size_t src_stride, uint32_t row_bytes, const uint32_t* idx, uint32_t m, hipStream_t s);
+hipError_t bn254_launch_scatter_status(uint8_t* status, const uint8_t* fb_status, const uint32_t* idx, uint32_t m, hipStream_t s);
 hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "bn254_vm.h"
+#include "bn254_rlc.h"
 #include "bn254_kernels.h"
 
 namespace bn254 {
@@ -319,6 +320,23 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   if (live) status[i] = err ? (uint8_t)err : (uint8_t)(BN254_ST_PENDING | (l_inf ? BN254_ST_LINF : 0) | err_c);
 }
 
+// BN254_FLAG_STRICT_SCALARS: a public input >= r makes the proof's status NOT_MEMBER, ahead of every other outcome (the
+// reference's bn::Fr::from_slice does not range-check; this is the opt-in stricter policy).  Runs right after
+// k_g16_prepare, so that such proofs are no longer pending for the rest of the pipeline.
+__global__ void __launch_bounds__(256, 2)
+k_g16_check_scalars(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, uint8_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  bool bad = false;
+  for (int s = 0; s < n_public; s++) {
+    const uint8_t* sp = inputs + ((size_t)i * (size_t)n_public + s) * 32;
+    uint32_t w[8];
+    words_from_be(w, sp);
+    bad |= words_ge(w, BN_R_WORDS);
+  }
+  if (bad) status[i] = BN254_ST_NOT_MEMBER;
+}
+
 // =====================================================================================================================
 // public-input MSM for keys with many inputs (BASELINE config 5: 1024): the inputs of one proof are spread over `chunks` lanes
 // =====================================================================================================================
@@ -494,6 +512,111 @@ __global__ void __launch_bounds__(256, 2) k_dbg_g2_ate(int32_t* ws, uint32_t n, 
 }
 
 // =====================================================================================================================
+// random-linear-combination batch mode (bn254_rlc.h)
+// =====================================================================================================================
+// accessor of the fold: element ids >= RLC_HI address the partner lane's column of the same workspace
+struct DevWs2 {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t row_bytes, voff_lo, voff_hi;
+  int32_t* lds;
+  __device__ __forceinline__ DevWs2(int32_t* base, uint32_t n, uint32_t lane_lo, uint32_t lane_hi, int32_t* lds_) : lds(lds_) {
+    DevWs t(base, n, lane_lo);
+    rsrc = t.rsrc; row_bytes = t.row_bytes; voff_lo = lane_lo * 4u; voff_hi = lane_hi * 4u;
+  }
+  __device__ __forceinline__ void park(int slot, const Fp2& a) const {
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+  }
+  __device__ __forceinline__ Fp2 unpark(int slot) const {
+    Fp2 r;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x]; }
+    return r;
+  }
+  __device__ __forceinline__ Fp ld(int e) const {
+    Fp r;
+    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
+    const bool hi = eu >= (uint32_t)RLC_HI;   // wave-uniform
+    if (hi) eu -= (uint32_t)RLC_HI;
+    const uint32_t vo = hi ? voff_hi : voff_lo;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) r.v[l] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
+    return r;
+  }
+  __device__ __forceinline__ void st(int e, const Fp& a) const {
+    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) __builtin_amdgcn_raw_buffer_store_b32(a.v[l], rsrc, voff_lo, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
+  }
+};
+// per pending proof: weight r_i = ChaCha20(key, counter_base + i), A <- r A, C' <- r C, t_j = r x_j (bn254_rlc.h::vm_rlc_scale)
+__global__ void __launch_bounds__(256, 2)
+k_rlc_scale(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ inputs, int n_public, ChaChaKey key, uint32_t counter_base) {
+  VM_KERNEL_PROLOGUE();
+  const uint32_t ii = i < n ? i : n - 1;
+  uint32_t r[4];
+  chacha20_block4(r, key, counter_base + ii);
+  const uint8_t* in = inputs + (size_t)ii * (size_t)n_public * 32;
+  vm_rlc_scale(w, r, n_public, [&](int j, uint32_t* o) { words_from_be(o, in + 32 * j); });
+}
+// lanes that are no longer pending contribute the neutral element to their group
+__global__ void __launch_bounds__(256, 2)
+k_rlc_neutral(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int n_public) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool dead = i < n && (status[i] & BN254_ST_PENDING) == 0;
+  if (__builtin_amdgcn_ballot_w64(dead) == 0) return;
+  DevWs w(ws, n, dead ? i : DEAD_LANE);
+  vm_rlc_neutral(w, n_public);
+}
+// one fold round: lane j < cur - half takes lane j + half (bn254_rlc.h::vm_rlc_fold)
+__global__ void __launch_bounds__(256, 2)
+k_rlc_fold(int32_t* ws, uint32_t n, uint32_t cur, uint32_t half, int n_public) {
+  __shared__ int32_t park_lds[72 * 256];
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const bool act = j + half < cur;
+  if (__builtin_amdgcn_ballot_w64(act) == 0) return;
+  DevWs2 w(ws, n, act ? j : DEAD_LANE, act ? j + half : DEAD_LANE, park_lds);
+  vm_rlc_fold(w, n_public);
+}
+// group stage, one lane per group: the G1 arguments of the three table-driven pairs (bn254_rlc.h::vm_rlc_group_points)
+__global__ void __launch_bounds__(256, 2)
+k_rlc_group_points(int32_t* ws, uint32_t n, uint8_t* __restrict__ grp_status, uint32_t groups, int n_public, const int32_t* __restrict__ rlc_tab,
+                   const int32_t* __restrict__ msm_tab) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (__builtin_amdgcn_ballot_w64(g < groups) == 0) return;
+  DevWs w(ws, n, g < groups ? g : DEAD_LANE);
+  const int fl = vm_rlc_group_points(w, n_public, [&](int b, int wi, int d) {
+    return b < 2 ? msm_entry(rlc_tab, (size_t)(b * 32 + wi) * 255 + d) : msm_entry(msm_tab, (size_t)((b - 2) * 32 + wi) * 255 + d);
+  });
+  if (g < groups) grp_status[g] = (uint8_t)(BN254_ST_PENDING | ((fl & 1) ? BN254_ST_LINF : 0) | ((fl & 2) ? BN254_ST_LINF2 : 0) | ((fl & 4) ? BN254_ST_LINF3 : 0));
+}
+// every pending proof takes its group's verdict: ACCEPT, or it stays pending (0x80) for the exact path
+__global__ void __launch_bounds__(256, 2)
+k_rlc_scatter(uint8_t* __restrict__ status, uint32_t n, const uint8_t* __restrict__ grp_status, RlcPlan plan) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t st = status[i];
+  if (!(st & BN254_ST_PENDING)) return;
+  status[i] = grp_status[rlc_group_of(i, plan)] == BN254_ST_ACCEPT ? (uint8_t)BN254_ST_ACCEPT : (uint8_t)BN254_ST_PENDING;
+}
+// fallback plumbing: rows idx[k] of a strided byte array -> packed rows; statuses back
+__global__ void k_gather_rows(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t src_stride, uint32_t row_bytes, const uint32_t* __restrict__ idx, uint32_t m) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t per = row_bytes / 4;
+  if (t >= (size_t)m * per) return;
+  const uint32_t k = (uint32_t)(t / per), c = (uint32_t)(t % per);
+  const uint8_t* p = src + (size_t)idx[k] * src_stride + 4 * (size_t)c;
+  uint32_t v;
+  if ((((uintptr_t)src) | src_stride) & 3) v = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+  else v = *(const uint32_t*)p;
+  ((uint32_t*)dst)[t] = v;
+}
+__global__ void k_scatter_status(uint8_t* __restrict__ status, const uint8_t* __restrict__ fb_status, const uint32_t* __restrict__ idx, uint32_t m) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k < m) status[idx[k]] = fb_status[k];
+}
+
+// =====================================================================================================================
 // probes for the GPU parity tests
 // =====================================================================================================================
 __device__ __forceinline__ Fp probe_ld_fp(const uint8_t* p) {
@@ -565,9 +688,9 @@ struct ProfScope {  // records the event pair around one launch (no-op without a
 // host-side OPS for the VM programs: every operation is one kernel launch on the stream
 struct LaunchOps {
   int32_t* ws; uint32_t n; const uint8_t* status; unsigned grid; hipStream_t s;
-  const int32_t* tab[2];
+  const int32_t* tab[3];
   G16Prof* prof;
-  int inf_mask[2] = {BN254_ST_LINF, 0};   // status bits marking the G1 point of fixed pair 0 / 1 as the identity
+  int inf_mask[3] = {BN254_ST_LINF, 0, 0};   // status bits marking the G1 point of fixed pair 0 / 1 / 2 as the identity
   int uni(int x) { return x; }
   void f12_sqr(int e) { BN_LAUNCH(KID_F12_SQR, k_f12_sqr, ws, n, status, e); }
   void miller_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_DBL_VAR, k_miller_dbl_var, ws, n, status, et, e, ep); }
@@ -607,6 +730,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[0], s);
   const bool wide = a.msm_part != nullptr && a.inputs_match_key && a.n_public > G16_WIDE_MSM_MIN_INPUTS;
   BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, wide ? 1 : 0);
+  if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
   if (wide) {
     // inputs of one proof spread over `chunks` lanes, proofs in slices that fit the partial-sum buffer
     const int per = G16_WIDE_MSM_INPUTS_PER_LANE, chunks = (a.n_public + per - 1) / per;
@@ -615,15 +739,15 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     BN_LAUNCH(KID_MSM_REDUCE, k_g16_msm_reduce, (const int32_t*)a.msm_part, chunks, n, a.ws, a.status, a.k0);
   }
   if (ev) (void)hipEventRecord(ev[1], s);
-  LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab}, prof};
+  LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab, nullptr}, prof};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
   if (a.split_streams[0] && a.split_streams[1] && a.n <= G16_SPLIT_MAX_PROOFS) {
     // latency mode: Miller(A, B) on the launch stream, the two table-driven pairs as their own chains (accumulators in the free
     // slots VE_S1 / VE_S2) on two more streams; f = f_A f_B f_C afterwards.  Three times the squarings, 40 % less time at 4096.
     ops.f12_copy(VE_S1, VE_F); ops.f12_copy(VE_S2, VE_F);
     (void)hipEventRecord(a.split_ev[0], s);
-    LaunchOps ob{a.ws, n, a.status, grid, a.split_streams[0], {a.gtab, a.dtab}, nullptr};
-    LaunchOps oc{a.ws, n, a.status, grid, a.split_streams[1], {a.gtab, a.dtab}, nullptr};
+    LaunchOps ob{a.ws, n, a.status, grid, a.split_streams[0], {a.gtab, a.dtab, nullptr}, nullptr};
+    LaunchOps oc{a.ws, n, a.status, grid, a.split_streams[1], {a.gtab, a.dtab, nullptr}, nullptr};
     (void)hipStreamWaitEvent(ob.s, a.split_ev[0], 0); (void)hipStreamWaitEvent(oc.s, a.split_ev[0], 0);
     const uint8_t* kinds = step_kinds_host();
     for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
@@ -649,6 +773,58 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
+
+// ---- RLC batch mode: per-proof stage, fold, group stage, scatter (bn254_rlc.h; orchestration of the fallback in bn254_capi.hip) ---------------------
+hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, hipStream_t s) {
+  unsigned grid = grid_for(a.n);
+  uint32_t n = (uint32_t)a.n;
+  G16Prof* prof = nullptr;
+  ChaChaKey key;
+  for (int i = 0; i < 8; i++) key.k[i] = r.key[i];
+  for (int i = 0; i < 3; i++) key.nonce[i] = r.key[8 + i];
+  // parse + checks; the public-input MSM is skipped (done once per group): the wide flag of k_g16_prepare returns before it
+  BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, 1);
+  if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
+  LaunchOps ops{a.ws, n, a.status, grid, s, {nullptr, nullptr, nullptr}, nullptr};
+  BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
+  hipLaunchKernelGGL(k_rlc_scale, dim3(grid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, a.inputs, a.n_public, key, r.counter_base);
+  vm_miller_program(ops, step_kinds_host(), false);
+  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
+  hipLaunchKernelGGL(k_rlc_neutral, dim3(grid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, a.n_public);
+  uint32_t cur = n;
+  for (int k = 0; k < r.plan.rounds; k++) {
+    const uint32_t half = r.plan.half[k];
+    hipLaunchKernelGGL(k_rlc_fold, dim3(grid_for(cur - half)), dim3(256), 0, s, a.ws, n, cur, half, a.n_public);
+    cur = half;
+  }
+  // group stage: lanes [0, groups) of the same workspace, their own status bytes
+  const uint32_t groups = r.plan.groups;
+  const unsigned ggrid = grid_for(groups);
+  (void)hipMemsetAsync(r.grp_status, 0, ((size_t)groups + 255) / 256 * 256, s);
+  hipLaunchKernelGGL(k_rlc_group_points, dim3(ggrid), dim3(256), 0, s, a.ws, n, r.grp_status, groups, a.n_public, r.rlc_tab, a.msm_tab);
+  LaunchOps gops{a.ws, n, r.grp_status, ggrid, s, {a.gtab, a.dtab, r.btab}, nullptr};
+  gops.inf_mask[0] = BN254_ST_LINF; gops.inf_mask[1] = BN254_ST_LINF2; gops.inf_mask[2] = BN254_ST_LINF3;
+  const uint8_t* kinds = step_kinds_host();
+  for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+    if (kinds[st_] == 0 && st_ != 0) gops.f12_sqr(RLC_ACC);
+    gops.f12_mul_line_fixed2(RLC_ACC, st_, VE_LX, VE_CX);
+    gops.f12_mul_line_fixed(RLC_ACC, 2, st_, VE_AX);
+  }
+  gops.f12_mul(VE_F, VE_F, RLC_ACC);
+  vm_final_exp_program(gops);
+  { unsigned grid = ggrid; BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, r.grp_status, r.one, BN254_ST_REJECT); }
+  hipLaunchKernelGGL(k_rlc_scatter, dim3(grid), dim3(256), 0, s, a.status, n, (const uint8_t*)r.grp_status, r.plan);
+  return hipGetLastError();
+}
+hipError_t bn254_launch_gather_rows(uint8_t* dst, const uint8_t* src, size_t src_stride, uint32_t row_bytes, const uint32_t* idx, uint32_t m, hipStream_t s) {
+  const size_t threads = (size_t)m * (row_bytes / 4);
+  if (threads) hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, dst, src, src_stride, row_bytes, idx, m);
+  return hipGetLastError();
+}
+hipError_t bn254_launch_scatter_status(uint8_t* status, const uint8_t* fb_status, const uint32_t* idx, uint32_t m, hipStream_t s) {
+  if (m) hipLaunchKernelGGL(k_scatter_status, dim3(grid_for(m)), dim3(256), 0, s, status, fb_status, idx, m);
+  return hipGetLastError();
+}
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_dbg_fp_mul, dim3(grid_for(n)), dim3(256), 0, s, a, b, o, n);
   return hipGetLastError();
@@ -657,7 +833,7 @@ hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* 
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
   unsigned g = grid_for(n);
   uint32_t nn = (uint32_t)n;
-  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}, nullptr};
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr, nullptr}, nullptr};
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, (int)VE_F, a, 0);
   if (op == 0) { hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, (int)VE_S1, b, 0); ops.f12_mul(VE_S0, VE_F, VE_S1); }
   else if (op == 1) { ops.f12_sqr(VE_F); ops.f12_conj(VE_S0, VE_F); ops.f12_conj(VE_S0, VE_S0); }
@@ -672,7 +848,7 @@ hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, 
 hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
   unsigned g = grid_for(n);
   uint32_t nn = (uint32_t)n;
-  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}, nullptr};
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr, nullptr}, nullptr};
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g1, 1);
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g2, 2);
   hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, ws, nn, (const uint8_t*)status);
@@ -685,7 +861,7 @@ hipError_t bn254_launch_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_
 hipError_t bn254_launch_dbg_g2_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s) {
   unsigned g = grid_for(n);
   uint32_t nn = (uint32_t)n;
-  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr}, nullptr};
+  LaunchOps ops{ws, nn, status, g, s, {nullptr, nullptr, nullptr}, nullptr};
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g1, 1);
   hipLaunchKernelGGL(k_dbg_load, dim3(g), dim3(256), 0, s, ws, nn, status, 0, g2, 2);
   hipLaunchKernelGGL(k_vm_init, dim3(g), dim3(256), 0, s, ws, nn, (const uint8_t*)status);
@@ -713,7 +889,7 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   unsigned grid = grid_for(n);
   uint32_t nn = (uint32_t)n;
   G16Prof* prof = nullptr;
-  LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1}, nullptr};
+  LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1, nullptr}, nullptr};
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
   BN_LAUNCH(KID_VM_INIT, k_vm_init, ws, nn, (const uint8_t*)status);
   const uint8_t* kinds = step_kinds_host();

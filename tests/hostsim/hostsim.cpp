@@ -9,6 +9,7 @@
 #include "../../snark-bn254-verifier_amd/csrc/bn254_curve.h"
 #include "../../snark-bn254-verifier_amd/csrc/bn254_pairing.h"
 #include "../../snark-bn254-verifier_amd/csrc/bn254_vm.h"
+#include "../../snark-bn254-verifier_amd/csrc/bn254_rlc.h"
 #endif
 #include <cstring>
 using namespace bn254;

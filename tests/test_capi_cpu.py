@@ -158,3 +158,18 @@ def test_sp1_fixture_reader(pkg, fixtures):
         assert bytes(pis) == b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"])
         assert bytes(h).hex() == f["vkey_hash"]
     assert L.bn254_sp1_fixture_parse(b"\x03\x00", C.c_size_t(2), C.byref(variant), raw, C.c_size_t(2048), C.byref(raw_len), pis, h) != 0
+
+
+def test_raw_proof_writer_reproduces_reference_fixtures(pkg, fixtures):
+    """bn254_groth16_proof_write_raw(A, B, C) rebuilds, byte for byte, the 324-byte raw proofs of the reference's Groth16 fixtures
+    (examples/binaries/*_groth16_proof.bin; layout read by groth16/converter.rs:14-26)."""
+    fx, _ = fixtures
+    seen = 0
+    for name, f in sorted(fx.items()):
+        if f["variant"] != "groth16":
+            continue
+        raw = bytes.fromhex(f["raw_proof"])
+        assert len(raw) == pkg.RAW_PROOF_LEN
+        assert pkg.proof_write_raw(raw[0:64], raw[64:192], raw[192:256]) == raw
+        seen += 1
+    assert seen == 4

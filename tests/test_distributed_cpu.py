@@ -56,3 +56,89 @@ def test_shard_bounds_cover():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+# ---- bench.py's rank logic under gloo with a stand-in verifier, and its self-launch ------------------------------------------------------------------
+class _StandIn:
+    """Stand-in for bench.GpuVerifier on a CPU box: 'verifies' a proof by looking its bytes up in the generator's table (so the
+    rotation of the shards, the gather and the expected-status check of bench.run_rank are exercised, not the kernels)."""
+
+    def __init__(self, table, proofs):
+        import time
+        self._t = time
+        self.status = torch.tensor([table[proofs[256 * i:256 * i + 256]] for i in range(len(proofs) // 256)], dtype=torch.uint8)
+
+    def step(self): return self.status
+    def sync(self): pass
+    def timer(self): return self._t.perf_counter()
+    def elapsed_ms(self, a, b): return (b - a) * 1e3
+    def select_kernels(self, names): pass
+    def kernel_profile(self): return {}, self.status.numel()
+    def phases(self): return {}
+    def status_bytes(self): return bytes(self.status.numpy().tobytes())
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch-log2", "6"])
+    table = {}
+
+    def synth(seed, n_public, n, threads):
+        vk, proofs, inputs, exp = pkg.synth_groth16(seed, n_public, n, invalid_every=4, agree=True, threads=2)
+        for i in range(n):
+            table[proofs[256 * i:256 * i + 256]] = exp[i]
+        return vk, proofs, inputs, exp
+
+    lines = []
+    bench.run_rank(args, lambda vk, proofs, inputs, lr: _StandIn(table, proofs), "gloo", rank, world, rank, synth, emit=lines.append)
+    if rank == 0:
+        q.put(lines)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rank_logic_under_gloo():
+    import json
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    lines = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * 64 and out["config"]["batch_per_gpu"] == 64
+    assert out["scaling"] == "weak" and out["steps"] == 2 and out["value"] > 0 and "gather_ms" in out["config"]
+    assert out["hbm_roofline"]["algorithmic_bytes_per_proof"] == 321
+
+
+def test_bench_rotation_changes_the_shard():
+    sys.path.insert(0, ROOT)
+    import bench
+    proofs = b"".join(bytes([i]) * 256 for i in range(8)); inputs = b"".join(bytes([i]) * 64 for i in range(8)); exp = bytes(range(8))
+    p1, i1, e1 = bench.rotate_shard(proofs, inputs, exp, 8, 2, 1)
+    k = 7919 % 8
+    assert e1 == exp[k:] + exp[:k] and p1[:256] == bytes([k]) * 256 and i1[:64] == bytes([k]) * 64
+    assert bench.rotate_shard(proofs, inputs, exp, 8, 2, 0) == (proofs, inputs, exp)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver invokes it) starts two ranks itself; on this GPU-less box both
+    get as far as the GPU check."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch-log2", "6"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the GPU run")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]

@@ -1,0 +1,157 @@
+"""GPU tests of the round-2 additions, all through the C ABI: random-linear-combination batch mode (statuses identical to the exact
+path), strict scalars, concurrent callers sharing one prepared key, the multi-device entry, the size just above 65 536."""
+import ctypes as C
+import os
+import threading
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def be(v):
+    return int(v).to_bytes(32, "big")
+
+
+@pytest.fixture(scope="module")
+def L(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; the product has no CPU fallback"
+    return pkg.lib()
+
+
+@pytest.fixture(scope="module")
+def wl(pkg):
+    """4133 synthetic proofs (not a multiple of anything), every 8th invalid, cycling through the 5 failure classes."""
+    return pkg.synth_groth16(0xB2540011, 2, 4133, invalid_every=8, agree=True, threads=16)
+
+
+def test_rlc_statuses_identical_to_exact(pkg, O, wl, L):
+    """BN254_FLAG_RLC on the 5-class workload: every status byte equals the exact path's, which equals the generator's prediction
+    and, on a prefix, the oracle's verdicts.  Groups that contain a REJECT proof go through the exact fallback."""
+    vk, proofs, inputs, exp = wl
+    n = len(exp)
+    for mode, omode in ((pkg.VK_REFERENCE, O.MODE_REFERENCE), (pkg.VK_GNARK, O.MODE_GNARK)):
+        pvk = pkg.PreparedVk(vk, mode)
+        exact = pvk.verify_batch(proofs, inputs)
+        assert exact == exp
+        rlc = pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC)
+        assert rlc == exact
+        m = 64
+        assert O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:64 * m], 2, m, omode) == rlc[:m]
+        # a second call draws fresh weights: same answer
+        assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exact
+        pvk.close()
+
+
+def test_rlc_all_valid_all_invalid_and_sizes(pkg, O, L):
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540012, 2, 1500, invalid_every=0, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == bytes([1]) * 1500 == exp
+    # every proof a REJECT (inputs shifted by one proof): every group fails, the fallback decides everything
+    sh = inputs[64:] + inputs[:64]
+    st = pvk.verify_batch(proofs, sh, flags=pkg.FLAG_RLC)
+    assert st == bytes(1500) == pvk.verify_batch(proofs, sh)
+    # one bad proof among many; sizes around the group and wave boundaries, and below RLC_MIN_BATCH (exact path)
+    for n in (1, 63, 64, 65, 127, 128, 129, 255, 257, 1000):
+        bad = bytearray(inputs[:64 * n]); j = n // 2
+        bad[64 * j:64 * j + 32] = be(int.from_bytes(bad[64 * j:64 * j + 32], "big") ^ 1)
+        want = bytes(0 if i == j else 1 for i in range(n))
+        assert pvk.verify_batch(proofs[:256 * n], bytes(bad), n, flags=pkg.FLAG_RLC) == want, n
+    # wrong number of public inputs under the flag: exact semantics (INPUT_LEN)
+    assert pvk.verify_batch(proofs[:256 * 100], inputs[:32 * 100], 100, n_public=1, flags=pkg.FLAG_RLC) == bytes([pkg.ERR_INPUT_LEN]) * 100
+    pvk.close()
+
+
+def test_rlc_more_public_inputs(pkg, O, L):
+    for n_public in (1, 5, 8):
+        vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540013 + n_public, n_public, 300, invalid_every=7, agree=True, threads=16)
+        pvk = pkg.PreparedVk(vk)
+        assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exp == pvk.verify_batch(proofs, inputs)
+        m = 16
+        assert O.groth16_verify_many(proofs[:256 * m], 256, vk, inputs[:32 * n_public * m], n_public, m, O.MODE_REFERENCE) == exp[:m]
+        pvk.close()
+
+
+def test_strict_scalars(pkg, O, wl, L):
+    """Default: inputs are used modulo r like bn::Fr::from_slice (x + r verifies like x).  BN254_FLAG_STRICT_SCALARS: NOT_MEMBER,
+    ahead of every proof error."""
+    vk, proofs, inputs, exp = wl
+    good = [i for i in range(64) if exp[i] == 1][:3]
+    bad_a = next(i for i in range(len(exp)) if exp[i] == 3)
+    idx = good + [bad_a]
+    pr = b"".join(proofs[256 * i:256 * i + 256] for i in idx)
+    ins = [bytearray(inputs[64 * i:64 * i + 64]) for i in idx]
+    x0 = int.from_bytes(ins[0][:32], "big"); ins[0][:32] = be(x0 + R)            # >= r, same residue
+    x1 = int.from_bytes(ins[1][32:], "big"); ins[1][32:] = be(x1 + R)            # second input
+    ins[3][:32] = b"\xff" * 32                                                  # invalid proof AND out-of-range input
+    ii = b"".join(bytes(x) for x in ins)
+    pvk = pkg.PreparedVk(vk)
+    assert pvk.verify_batch(pr, ii, 4) == bytes([1, 1, 1, 3])
+    assert pvk.verify_batch(pr, ii, 4) == O.groth16_verify_many(pr, 256, vk, ii, 2, 4, O.MODE_REFERENCE)
+    for flags in (pkg.FLAG_STRICT_SCALARS, pkg.FLAG_STRICT_SCALARS | pkg.FLAG_RLC):
+        assert pvk.verify_batch(pr, ii, 4, flags=flags) == bytes([2, 2, 1, 2])
+    n = 200
+    big = bytearray(inputs[:64 * n]); big[64 * 77:64 * 77 + 32] = be(R)         # exactly r
+    want = bytearray(exp[:n]); want[77] = 2
+    assert pvk.verify_batch(proofs[:256 * n], bytes(big), n, flags=pkg.FLAG_STRICT_SCALARS | pkg.FLAG_RLC) == bytes(want)
+    pvk.close()
+
+
+def test_concurrent_callers_share_one_key(pkg, L):
+    """Two host threads and two device streams against ONE prepared key: the library serialises the batches on the key's workspace
+    (ADVICE round 1): every caller gets the statuses of its own proofs."""
+    import torch
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540014, 2, 3000, invalid_every=5, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    a = (proofs[:256 * 1700], inputs[:64 * 1700], exp[:1700])
+    b = (proofs[256 * 1700:], inputs[64 * 1700:], exp[1700:])
+    out = {}
+
+    def run(name, w, flags):
+        for it in range(3):
+            out[(name, it)] = pvk.verify_batch(w[0], w[1], flags=flags) == w[2]
+
+    ts = [threading.Thread(target=run, args=("a", a, 0)), threading.Thread(target=run, args=("b", b, pkg.FLAG_RLC))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert len(out) == 6 and all(out.values())
+    # two streams, device-resident buffers, no host synchronisation between the enqueues
+    dev = torch.device("cuda:0")
+    bufs = []
+    for w in (a, b):
+        bufs.append((torch.frombuffer(bytearray(w[0]), dtype=torch.uint8).to(dev), torch.frombuffer(bytearray(w[1]), dtype=torch.uint8).to(dev),
+                     torch.full((len(w[2]),), 0xEE, dtype=torch.uint8, device=dev), torch.cuda.Stream(dev)))
+    torch.cuda.synchronize(dev)
+    for rep in range(2):
+        for (dp, di, ds, st) in bufs:
+            pvk.verify_batch_device(dp.data_ptr(), di.data_ptr(), ds.data_ptr(), ds.numel(), 256, 2, 0, st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    assert bytes(bufs[0][2].cpu().numpy().tobytes()) == a[2] and bytes(bufs[1][2].cpu().numpy().tobytes()) == b[2]
+    pvk.close()
+
+
+def test_multi_device_entry_and_single_verify_loop(pkg, O, wl, L):
+    import torch
+    vk, proofs, inputs, exp = wl
+    pvk = pkg.PreparedVk(vk)
+    mask = (1 << torch.cuda.device_count()) - 1
+    assert pvk.verify_batch_multi(proofs, inputs, mask) == exp
+    assert pvk.verify_batch_multi(proofs, inputs, 1, flags=pkg.FLAG_RLC) == exp
+    with pytest.raises(pkg.Bn254Error):
+        pvk.verify_batch_multi(proofs, inputs, 1 << 40)
+    pvk.close()
+    # Groth16Verifier::verify mirror in a loop: prepares and frees a key (streams, events, tables) per call
+    for i in range(12):
+        assert pkg.Groth16Verifier.verify(proofs[256 * i:256 * i + 256], vk, [inputs[64 * i:64 * i + 32], inputs[64 * i + 32:64 * i + 64]]) == exp[i]
+
+
+def test_batch_just_above_65536(pkg, L):
+    """Regression size of the round-1 dwordx3 layout bug: n = 65 552."""
+    n = 65552
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540015, 2, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    assert pvk.verify_batch(proofs, inputs) == exp
+    assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exp
+    pvk.close()

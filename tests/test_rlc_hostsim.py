@@ -1,0 +1,126 @@
+"""Random-linear-combination batch mode (snark-bn254-verifier_amd/csrc/bn254_rlc.h) on the CPU: the same templated code the RLC kernels
+instantiate, run by tests/hostsim on plain arrays under the bound tracker, judged by the oracle's per-proof verdicts."""
+import ctypes as C
+import hashlib
+import random
+import struct
+
+import pytest
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def be(v):
+    return int(v).to_bytes(32, "big")
+
+
+def _chacha_block(key, counter, nonce):
+    def rotl(x, n):
+        return ((x << n) | (x >> (32 - n))) & 0xffffffff
+
+    def qr(s, a, b, c, d):
+        s[a] = (s[a] + s[b]) & 0xffffffff; s[d] = rotl(s[d] ^ s[a], 16)
+        s[c] = (s[c] + s[d]) & 0xffffffff; s[b] = rotl(s[b] ^ s[c], 12)
+        s[a] = (s[a] + s[b]) & 0xffffffff; s[d] = rotl(s[d] ^ s[a], 8)
+        s[c] = (s[c] + s[d]) & 0xffffffff; s[b] = rotl(s[b] ^ s[c], 7)
+
+    init = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + list(struct.unpack("<8I", key)) + [counter] + list(struct.unpack("<3I", nonce))
+    s = list(init)
+    for _ in range(10):
+        qr(s, 0, 4, 8, 12); qr(s, 1, 5, 9, 13); qr(s, 2, 6, 10, 14); qr(s, 3, 7, 11, 15)
+        qr(s, 0, 5, 10, 15); qr(s, 1, 6, 11, 12); qr(s, 2, 7, 8, 13); qr(s, 3, 4, 9, 14)
+    return [(a + b) & 0xffffffff for a, b in zip(s, init)]
+
+
+def test_chacha20_block_rfc8439(hostsim):
+    # RFC 8439 section 2.3.2 test vector (key 00..1f, counter 1, nonce 00 00 00 09 00 00 00 4a 00 00 00 00)
+    key = bytes(range(32))
+    nonce = bytes.fromhex("000000090000004a00000000")
+    ref = _chacha_block(key, 1, nonce)
+    assert ref[0] == 0xe4e7f110 and ref[1] == 0x15593bd1 and ref[2] == 0x1fdd0f50 and ref[3] == 0xc47120a3
+    out = (C.c_uint32 * 4)()
+    hostsim.hs_chacha_block4(out, key + nonce, 1)
+    assert list(out) == ref[:4]
+    rng = random.Random(5)
+    for _ in range(8):
+        k = bytes(rng.randrange(256) for _ in range(44)); c = rng.randrange(1 << 32)
+        hostsim.hs_chacha_block4(out, k, c)
+        assert list(out) == _chacha_block(k[:32], c, k[32:])[:4]
+
+
+def test_fr_products_and_sums(hostsim):
+    rng = random.Random(6)
+    o = (C.c_uint8 * 32)()
+    cases = [(0, 1), (R - 1, R - 1), ((1 << 256) - 1, R - 1), ((1 << 256) - 1, (1 << 128) - 1), (R, 5), (R + 7, 1)]
+    cases += [(rng.randrange(1 << 256), rng.randrange(R)) for _ in range(200)]
+    for x, k in cases:
+        hostsim.hs_fr8_mul_plain(o, be(x), be(k))
+        assert int.from_bytes(bytes(o), "big") == x * k % R
+    for _ in range(200):
+        a, b = rng.randrange(R), rng.randrange(R)
+        hostsim.hs_fr8_add(o, be(a), be(b))
+        assert int.from_bytes(bytes(o), "big") == (a + b) % R
+    hostsim.hs_fr8_add(o, be(R - 1), be(R - 1))
+    assert int.from_bytes(bytes(o), "big") == R - 2
+
+
+def test_g1_mul_u128(hostsim, O):
+    rng = random.Random(7)
+    g = O.g1_gen()
+    o = (C.c_uint8 * 64)()
+    pts = [g, O.g1_mul(g, rng.randrange(1, R))]
+    for p in pts:
+        for k in (1, 2, 3, 4, (1 << 128) - 1, 1 << 127, rng.randrange(1 << 128), rng.randrange(1 << 128)):
+            hostsim.hs_g1_mul_u128(o, p, k.to_bytes(16, "big"))
+            assert bytes(o) == O.g1_mul(p, k)
+    hostsim.hs_g1_mul_u128(o, g, (0).to_bytes(16, "big"))
+    assert bytes(o) == bytes(64)
+
+
+def _neg_g2(q):
+    c = [int.from_bytes(q[32 * i:32 * i + 32], "big") for i in range(4)]
+    return q[:64] + be((P - c[2]) % P) + be((P - c[3]) % P)
+
+
+def _key_points(pkg, vk, n_public):
+    """gnark reading of a synthetic key: alpha, K_i and the key-side G2 arguments g' = -gamma, d' = -delta, b' = beta."""
+    L = pkg.lib()
+    st = C.c_uint8()
+
+    def g1(b):
+        o = (C.c_uint8 * 64)(); assert L.bn254_g1_decompress(bytes(b), o, 0, C.byref(st)) == 0 and st.value == 1; return bytes(o)
+
+    def g2(b):
+        o = (C.c_uint8 * 128)(); assert L.bn254_g2_decompress(bytes(b), o, 1, 0, C.byref(st)) == 0 and st.value == 1; return bytes(o)
+
+    alpha = g1(vk[0:32]); beta = g2(vk[64:128]); gamma = g2(vk[128:192]); delta = g2(vk[224:288])
+    ks = b"".join(g1(vk[292 + 32 * i:324 + 32 * i]) for i in range(n_public + 1))
+    return alpha, ks, _neg_g2(gamma), _neg_g2(delta), beta
+
+
+@pytest.mark.parametrize("n,log2_group,bad", [(5, 8, []), (5, 8, [3]), (6, 1, [1])])
+def test_rlc_group_pipeline(hostsim, pkg, O, n, log2_group, bad):
+    """Valid proofs: every group's product is one.  A proof that the oracle rejects makes exactly its own group fail.  A lane marked
+    as a loader error is neutral (its group still passes)."""
+    n_public = 2
+    vk, proofs, inputs, expected = pkg.synth_groth16(0xB2540077, n_public, n, invalid_every=0, agree=True, threads=2)
+    proofs = bytearray(proofs); inputs = bytearray(inputs)
+    for i in bad:   # x_0 + 1: a well-formed proof of a false statement
+        v = int.from_bytes(inputs[64 * i:64 * i + 32], "big") + 1
+        inputs[64 * i:64 * i + 32] = be(v)
+    ref = O.groth16_verify_many(bytes(proofs), 256, vk, bytes(inputs), n_public, n, O.MODE_GNARK)
+    assert [s for s in ref] == [0 if i in bad else 1 for i in range(n)]
+    alpha, ks, qg, qd, qb = _key_points(pkg, vk, n_public)
+    key = hashlib.sha256(b"rlc-test-key").digest() + bytes(12)
+    groups = (C.c_uint8 * n)(); group_of = (C.c_uint32 * n)()
+    ng = hostsim.hs_rlc_pipeline(n, bytes(proofs), bytes(inputs), n_public, alpha, ks, qg, qd, qb, key, log2_group, 0, groups, group_of)
+    assert ng >= 1
+    bad_groups = {group_of[i] for i in bad}
+    assert [groups[g] for g in range(ng)] == [0 if g in bad_groups else 1 for g in range(ng)]
+    assert len(set(group_of[:n])) == ng
+    if bad:
+        # the same batch with the bad proofs masked out as loader errors: their lanes are neutral, all groups pass
+        mask = sum(1 << i for i in bad)
+        ng2 = hostsim.hs_rlc_pipeline(n, bytes(proofs), bytes(inputs), n_public, alpha, ks, qg, qd, qb, key, log2_group, mask, groups, group_of)
+        assert ng2 == ng and all(groups[g] == 1 for g in range(ng))
