@@ -24,6 +24,9 @@ def O():
 
 @pytest.fixture(scope="session")
 def pkg():
+    # torch first: it carries its own copy of the HIP runtime, and whichever copy a process loads first must stay the only one (the
+    # library links /opt/rocm's; loading that one before torch's leaves the process with two runtimes and no devices)
+    import torch  # noqa: F401
     return importlib.import_module("snark-bn254-verifier_amd")
 
 
