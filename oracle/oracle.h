@@ -180,6 +180,8 @@ int orc_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, 
  * and the 48-byte hash_to_field output of the first BSB22 commitment */
 int orc_plonk_pairing_inputs(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                              const uint8_t* inputs, size_t n_inputs, uint8_t* out384 /* P0 | P1 | Q0 | Q1, gnark uncompressed */);
+int orc_plonk_pairing_inputs_lam(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* inputs, size_t n_inputs,
+                                 const uint8_t* lambda32, uint8_t* out384);
 int orc_plonk_stage_digests(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                             const uint8_t* inputs, size_t n_inputs, uint8_t* out176);
 

@@ -176,6 +176,15 @@ def plonk_pairing_inputs(proof, vk, inputs):
     return st, [r[0:64], r[64:128]], [r[128:256], r[256:384]]
 
 
+def plonk_pairing_inputs_lam(proof, vk, inputs, lam):
+    """Same with an explicit KZG batching scalar."""
+    ib = b"".join(be32(i) for i in inputs)
+    o = _buf(384)
+    st = lib().orc_plonk_pairing_inputs_lam(proof, C.c_size_t(len(proof)), vk, C.c_size_t(len(vk)), ib, C.c_size_t(len(inputs)), be32(lam), o)
+    r = _b(o)
+    return st, [r[0:64], r[64:128]], [r[128:256], r[256:384]]
+
+
 def set_threads(n):
     lib().orc_set_threads(int(n))
 

@@ -586,6 +586,15 @@ int orc_plonk_pairing_inputs(const uint8_t* proof, size_t proof_len, const uint8
   plonk_pair_out = NULL;
   return st;
 }
+/* same with an explicit KZG batching scalar (tests/test_oracle_golden.py::test_kzg_batching_scalar_must_be_unpredictable) */
+int orc_plonk_pairing_inputs_lam(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* inputs, size_t n_inputs,
+                                 const uint8_t* lambda32, uint8_t* out384) {
+  memset(out384, 0, 384);
+  plonk_pair_out = out384;
+  int st = plonk_core(proof, proof_len, vk, vk_len, inputs, n_inputs, lambda32, NULL);
+  plonk_pair_out = NULL;
+  return st;
+}
 int orc_plonk_stage_digests(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* inputs, size_t n_inputs, uint8_t* out176) {
   memset(out176, 0, 176);
   return plonk_core(proof, proof_len, vk, vk_len, inputs, n_inputs, NULL, out176);

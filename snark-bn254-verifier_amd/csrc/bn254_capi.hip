@@ -609,7 +609,6 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   if (rc) return rc;
   const PlonkKey& key = pvk->key;
   const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key);
-  const FrM lambda = fr_ctx().from_u64(0x9e3779b97f4a7c15ull);  // the reference draws it at random (kzg.rs:149-154); any value works
   static const bool timing = getenv("BN254_PLONK_TIMING") != nullptr;   // stage durations on stderr (diagnostics)
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -621,9 +620,19 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     std::vector<uint8_t> flags(m * (size_t)(T1 > T2 ? T1 : T2), 0), st(m), inf(m);
     std::vector<uint32_t> words(m * 16);
     memset(terms.data(), 0, terms.size() * sizeof(MsmTerm));
+    // The KZG batching scalar of every proof: fresh, uniform and unpredictable to the prover, as the reference draws it
+    // (Fr::random(&mut OsRng), plonk/kzg.rs:149-154).  It MUST be secret until the proof is fixed: the two opening quotients are bound by
+    // no transcript, so a prover who knows lambda can shift them by (lambda D, -D) and cancel a wrong evaluation
+    // (tests/test_oracle_golden.py::test_kzg_batching_scalar_must_be_unpredictable).  48 bytes of getrandom(2) reduced mod r per proof.
+    std::vector<uint8_t> rnd(m * 48);
+    for (size_t got = 0; got < rnd.size();) {
+      ssize_t k = getrandom(rnd.data() + got, rnd.size() - got, 0);
+      if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
+      got += (size_t)k;
+    }
     // ---- stage 1 on the host threads
     plonk_parallel(m, [&](size_t i) {
-      work[i].lambda = lambda;
+      work[i].lambda = fr_ctx().from_be_reduce(rnd.data() + 48 * i, 48);
       work[i].status = plonk_stage1(key, proofs + (off + i) * proof_stride, proof_stride, public_inputs + (off + i) * n_public * 32, n_public, work[i], &terms[i * T1]);
     });
     auto t1_ = now();

@@ -173,3 +173,12 @@ def test_raw_proof_writer_reproduces_reference_fixtures(pkg, fixtures):
         assert pkg.proof_write_raw(raw[0:64], raw[64:192], raw[192:256]) == raw
         seen += 1
     assert seen == 4
+
+
+def test_no_constant_kzg_batching_scalar_in_the_product():
+    """The PlonK path draws its batching scalars from getrandom(2); no literal scalar may come back."""
+    import re
+    src = open(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", "bn254_capi.hip")).read()
+    body = src[src.index("int bn254_plonk_verify_batch("):src.index("int bn254_plonk_verify(")]
+    assert "getrandom(" in body and "from_be_reduce(rnd.data()" in body
+    assert not re.search(r"lambda\s*=\s*fr_ctx\(\)\.from_u64", src)

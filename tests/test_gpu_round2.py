@@ -155,3 +155,23 @@ def test_batch_just_above_65536(pkg, L):
     assert pvk.verify_batch(proofs, inputs) == exp
     assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exp
     pvk.close()
+
+
+def test_plonk_rejects_the_known_lambda_forgery(pkg, O, fixtures, L):
+    """The (H + lambda D, H' - D) forgery against round 1's published batching constant (tests/kzg_forgery.py): the oracle run with that
+    constant accepts it; the product, which now draws a fresh scalar per proof like the reference (plonk/kzg.rs:149-154), answers
+    PairingCheckFailed every time, alone and inside a batch, while the honest proof keeps verifying."""
+    from kzg_forgery import forge, KNOWN_LAMBDA
+    fx, vk = fixtures
+    f = fx["fibonacci_plonk"]
+    proof = bytes.fromhex(f["raw_proof"])
+    pis = [int(x) for x in f["public_inputs"]]
+    tampered, forged = forge(O, proof, vk, pis, KNOWN_LAMBDA)
+    assert O.plonk_verify(forged, vk, pis, lam=KNOWN_LAMBDA) == O.ACCEPT
+    ib = b"".join(be(x) for x in pis)
+    for _ in range(4):
+        assert pkg.PlonkVerifier.verify(forged, vk, pis) == 8
+    pvk = pkg.PreparedPlonkVk(vk)
+    st = pvk.verify_batch((proof + forged + tampered) * 20, ib * 60)
+    assert st == bytes([1, 8, 8]) * 20
+    pvk.close()

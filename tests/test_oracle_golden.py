@@ -56,6 +56,28 @@ def test_plonk_negative(O, fixtures):
     assert O.plonk_verify(bytes(proof[:500]), vk, pis) == O.ERR_MALFORMED
 
 
+def test_kzg_batching_scalar_must_be_unpredictable(O, fixtures):
+    """The reference draws the KZG batching scalar from OsRng (plonk/kzg.rs:149-154).  With a scalar the prover knows, a proof with a
+    wrong claimed evaluation is ACCEPTED after shifting the two opening quotients by (lambda D, -D); under any other scalar the same
+    bytes fail the pairing check.  (Round 1's product used a published constant; tests/test_gpu_round2.py runs this forgery against
+    the product.)"""
+    import random
+    from kzg_forgery import forge, KNOWN_LAMBDA, R
+    fx, vk = _plonk(fixtures)
+    rng = random.Random(99)
+    for name in ("fibonacci_plonk", "sha2_plonk"):
+        f = fx[name]
+        proof = bytes.fromhex(f["raw_proof"])
+        pis = [int(x) for x in f["public_inputs"]]
+        for lam in (KNOWN_LAMBDA, rng.randrange(1, R)):
+            tampered, forged = forge(O, proof, vk, pis, lam)
+            assert O.plonk_verify(tampered, vk, pis, lam=lam) == O.ERR_PAIRING_FAILED
+            assert O.plonk_verify(forged, vk, pis, lam=lam) == O.ACCEPT                     # the break: known lambda
+            for other in (lam + 1, rng.randrange(1, R), rng.randrange(1, R)):
+                assert O.plonk_verify(forged, vk, pis, lam=other % R) == O.ERR_PAIRING_FAILED   # fresh lambda: rejected
+            assert O.plonk_verify(proof, vk, pis, lam=lam) == O.ACCEPT
+
+
 def test_plonk_stage_goldens(O, fixtures):
     """SURVEY.md Appendix B.3 (fixture fibonacci_plonk)."""
     fx, vk = _plonk(fixtures)
