@@ -360,6 +360,8 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
   (void)device;
   static const int n_streams = [] { const char* e = getenv("BN254_STREAMS"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
   static const int log2_group = [] { const char* e = getenv("BN254_RLC_GROUP_LOG2"); int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+  // proofs per lane in the Miller loop (shared accumulator, one squaring of f per lane and step): 2^BN254_RLC_SHARE_LOG2, at most the group
+  static const int log2_share_env = [] { const char* e = getenv("BN254_RLC_SHARE_LOG2"); int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 3 ? 3 : v); }();
   uint32_t key[11];
   if (getrandom(key, sizeof key, 0) != (ssize_t)sizeof key) return set_err(BN254_E_HIP, "getrandom failed: no weights for the RLC mode");
   const size_t chunk = G16_MAX_BATCH;
@@ -390,7 +392,12 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
       RlcLaunchArgs ra;
       memcpy(ra.key, key, sizeof key);
       ra.counter_base = (uint32_t)(off + lo);
-      ra.plan = rlc_plan((uint32_t)a.n, log2_group);
+      // sharing needs enough lanes to fill the GPU; small parts keep one proof per lane
+      int log2_share = log2_share_env < log2_group ? log2_share_env : log2_group;
+      const char* ml = getenv("BN254_RLC_SHARE_MIN_LANES");
+      const size_t min_lanes = ml ? (size_t)atol(ml) : 65536;
+      while (log2_share > 0 && (a.n >> log2_share) < min_lanes) log2_share--;
+      ra.plan = rlc_plan((uint32_t)a.n, log2_group, log2_share);
       ra.grp_status = r.grp_status + grp_off; grp_off += ((size_t)ra.plan.groups + 255) / 256 * 256;
       ra.btab = r.btab; ra.rlc_tab = r.tab; ra.one = r.one;
       hipError_t e = bn254_launch_g16_rlc(a, ra, st);

@@ -549,6 +549,67 @@ struct DevWs2 {
     for (int l = 0; l < BN_NL; l++) __builtin_amdgcn_raw_buffer_store_b32(a.v[l], rsrc, voff_lo, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
   }
 };
+// accessor of the shared-accumulator Miller loop: the lane's own column (f) and the column of the current proof (sel(q): lane + q * m)
+struct DevWsM {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t row_bytes, voff0, lane, m, n, voff;
+  int32_t* lds;
+  __device__ __forceinline__ DevWsM(int32_t* base, uint32_t n_, uint32_t lane_, uint32_t m_, int32_t* lds_) : lane(lane_), m(m_), n(n_), lds(lds_) {
+    DevWs t(base, n_, lane_);
+    rsrc = t.rsrc; row_bytes = t.row_bytes; voff0 = lane_ < n_ ? lane_ * 4u : 0xfffffffcu; voff = voff0;
+  }
+  __device__ __forceinline__ void sel(int q) { const uint32_t i = lane + (uint32_t)q * m; voff = (lane < m && i < n) ? i * 4u : 0xfffffffcu; }
+  __device__ __forceinline__ void park(int slot, const Fp2& a) const {
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+  }
+  __device__ __forceinline__ Fp2 unpark(int slot) const {
+    Fp2 r;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x]; }
+    return r;
+  }
+  __device__ __forceinline__ Fp ldv(int e, uint32_t vo) const {
+    Fp r;
+    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) r.v[l] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
+    return r;
+  }
+  __device__ __forceinline__ void stv(int e, const Fp& a, uint32_t vo) const {
+    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) __builtin_amdgcn_raw_buffer_store_b32(a.v[l], rsrc, vo, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
+  }
+  __device__ __forceinline__ Fp ld(int e) const { return ldv(e, voff); }
+  __device__ __forceinline__ void st(int e, const Fp& a) const { stv(e, a, voff); }
+  __device__ __forceinline__ Fp ld0(int e) const { return ldv(e, voff0); }
+  __device__ __forceinline__ void st0(int e, const Fp& a) const { stv(e, a, voff0); }
+};
+// one Miller step of the G proofs of a lane with a shared accumulator (bn254_rlc.h::vm_miller_var_multi); lanes [0, m)
+template <bool DO_SQR>
+__global__ void __launch_bounds__(256, 2)
+k_rlc_miller_multi(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int kind, int G, uint32_t m) {
+  __shared__ int32_t park_lds[72 * 256];
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  uint32_t deadmask = 0;
+  const int g = __builtin_amdgcn_readfirstlane(G);
+  for (int q = 0; q < g; q++) {
+    const uint32_t i = j + (uint32_t)q * m;
+    const bool live = j < m && i < n && (status[i < n ? i : n - 1] & BN254_ST_PENDING) != 0;
+    if (!live) deadmask |= 1u << q;
+  }
+  if (__builtin_amdgcn_ballot_w64(j < m) == 0) return;
+  DevWsM w(ws, n, j < m ? j : 0xffffffffu, m, park_lds);
+  vm_miller_var_multi<DO_SQR>(w, __builtin_amdgcn_readfirstlane(kind), g, deadmask);
+}
+// f = 1 on the lanes that carry an accumulator; T = B on every pending proof (k_vm_init does both for the one-proof-per-lane layout)
+__global__ void __launch_bounds__(256, 2) k_rlc_init_f(int32_t* ws, uint32_t n, uint32_t m) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  DevWs w(ws, n, j < m ? j : DEAD_LANE);
+  w.st(VE_F, fp_one());
+  for (int e = 1; e < 12; e++) w.st(VE_F + e, fp_zero());
+}
 // per pending proof: weight r_i = ChaCha20(key, counter_base + i), A <- r A, C' <- r C, t_j = r x_j (bn254_rlc.h::vm_rlc_scale)
 __global__ void __launch_bounds__(256, 2)
 k_rlc_scale(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ inputs, int n_public, ChaChaKey key, uint32_t counter_base) {
@@ -561,22 +622,22 @@ k_rlc_scale(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, const u
 }
 // lanes that are no longer pending contribute the neutral element to their group
 __global__ void __launch_bounds__(256, 2)
-k_rlc_neutral(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int n_public) {
+k_rlc_neutral(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int n_public, int with_f) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const bool dead = i < n && (status[i] & BN254_ST_PENDING) == 0;
   if (__builtin_amdgcn_ballot_w64(dead) == 0) return;
   DevWs w(ws, n, dead ? i : DEAD_LANE);
-  vm_rlc_neutral(w, n_public);
+  vm_rlc_neutral(w, n_public, __builtin_amdgcn_readfirstlane(with_f) != 0);
 }
 // one fold round: lane j < cur - half takes lane j + half (bn254_rlc.h::vm_rlc_fold)
 __global__ void __launch_bounds__(256, 2)
-k_rlc_fold(int32_t* ws, uint32_t n, uint32_t cur, uint32_t half, int n_public) {
+k_rlc_fold(int32_t* ws, uint32_t n, uint32_t cur, uint32_t half, int n_public, int with_f) {
   __shared__ int32_t park_lds[72 * 256];
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   const bool act = j + half < cur;
   if (__builtin_amdgcn_ballot_w64(act) == 0) return;
   DevWs2 w(ws, n, act ? j : DEAD_LANE, act ? j + half : DEAD_LANE, park_lds);
-  vm_rlc_fold(w, n_public);
+  vm_rlc_fold(w, n_public, __builtin_amdgcn_readfirstlane(with_f) != 0);
 }
 // group stage, one lane per group: the G1 arguments of the three table-driven pairs (bn254_rlc.h::vm_rlc_group_points)
 __global__ void __launch_bounds__(256, 2)
@@ -589,6 +650,20 @@ k_rlc_group_points(int32_t* ws, uint32_t n, uint8_t* __restrict__ grp_status, ui
     return b < 2 ? msm_entry(rlc_tab, (size_t)(b * 32 + wi) * 255 + d) : msm_entry(msm_tab, (size_t)((b - 2) * 32 + wi) * 255 + d);
   });
   if (g < groups) grp_status[g] = (uint8_t)(BN254_ST_PENDING | ((fl & 1) ? BN254_ST_LINF : 0) | ((fl & 2) ? BN254_ST_LINF2 : 0) | ((fl & 4) ? BN254_ST_LINF3 : 0));
+}
+// group stage: one Miller step of the three table-driven pairs (bn254_rlc.h::vm_miller_step_fixed3)
+template <bool DO_SQR>
+__global__ void __launch_bounds__(256, 2)
+k_rlc_group_step(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e, const int32_t* __restrict__ entry0, const int32_t* __restrict__ entry1,
+                 const int32_t* __restrict__ entry2) {
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  FixedLine l0, l1, l2;
+  l0.m = uni_ld2(entry0); l0.c = uni_ld2(entry0 + 2 * BN_NL); l0.xc = uni_ld2(entry0 + 4 * BN_NL);
+  l1.m = uni_ld2(entry1); l1.c = uni_ld2(entry1 + 2 * BN_NL); l1.xc = uni_ld2(entry1 + 4 * BN_NL);
+  l2.m = uni_ld2(entry2); l2.c = uni_ld2(entry2 + 2 * BN_NL); l2.xc = uni_ld2(entry2 + 4 * BN_NL);
+  vm_miller_step_fixed3<DO_SQR>(w, e, l0, VE_LX, (st & BN254_ST_LINF) != 0, l1, VE_CX, (st & BN254_ST_LINF2) != 0, l2, VE_AX, (st & BN254_ST_LINF3) != 0);
 }
 // every pending proof takes its group's verdict: ACCEPT, or it stays pending (0x80) for the exact path
 __global__ void __launch_bounds__(256, 2)
@@ -788,13 +863,27 @@ hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, 
   LaunchOps ops{a.ws, n, a.status, grid, s, {nullptr, nullptr, nullptr}, nullptr};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
   hipLaunchKernelGGL(k_rlc_scale, dim3(grid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, a.inputs, a.n_public, key, r.counter_base);
-  vm_miller_program(ops, step_kinds_host(), false);
+  const uint8_t* kinds = step_kinds_host();
+  const int share = 1 << r.plan.pre;
+  if (share == 1) {
+    vm_miller_program(ops, kinds, false);
+  } else {
+    // shared accumulators: lane j < m walks proofs j, j + m, ..., j + (share - 1) m; one squaring of f per lane and step
+    const uint32_t m = r.plan.lanes;
+    const unsigned mgrid = grid_for(m);
+    hipLaunchKernelGGL(k_rlc_init_f, dim3(mgrid), dim3(256), 0, s, a.ws, n, m);
+    for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+      const int kind = kinds[st_];
+      if (kind == 0 && st_ != 0) hipLaunchKernelGGL(k_rlc_miller_multi<true>, dim3(mgrid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, kind, share, m);
+      else hipLaunchKernelGGL(k_rlc_miller_multi<false>, dim3(mgrid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, kind, share, m);
+    }
+  }
   BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
-  hipLaunchKernelGGL(k_rlc_neutral, dim3(grid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, a.n_public);
+  hipLaunchKernelGGL(k_rlc_neutral, dim3(grid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, a.n_public, share == 1 ? 1 : 0);
   uint32_t cur = n;
   for (int k = 0; k < r.plan.rounds; k++) {
     const uint32_t half = r.plan.half[k];
-    hipLaunchKernelGGL(k_rlc_fold, dim3(grid_for(cur - half)), dim3(256), 0, s, a.ws, n, cur, half, a.n_public);
+    hipLaunchKernelGGL(k_rlc_fold, dim3(grid_for(cur - half)), dim3(256), 0, s, a.ws, n, cur, half, a.n_public, k >= r.plan.pre ? 1 : 0);
     cur = half;
   }
   // group stage: lanes [0, groups) of the same workspace, their own status bytes
@@ -804,11 +893,10 @@ hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, 
   hipLaunchKernelGGL(k_rlc_group_points, dim3(ggrid), dim3(256), 0, s, a.ws, n, r.grp_status, groups, a.n_public, r.rlc_tab, a.msm_tab);
   LaunchOps gops{a.ws, n, r.grp_status, ggrid, s, {a.gtab, a.dtab, r.btab}, nullptr};
   gops.inf_mask[0] = BN254_ST_LINF; gops.inf_mask[1] = BN254_ST_LINF2; gops.inf_mask[2] = BN254_ST_LINF3;
-  const uint8_t* kinds = step_kinds_host();
   for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
-    if (kinds[st_] == 0 && st_ != 0) gops.f12_sqr(RLC_ACC);
-    gops.f12_mul_line_fixed2(RLC_ACC, st_, VE_LX, VE_CX);
-    gops.f12_mul_line_fixed(RLC_ACC, 2, st_, VE_AX);
+    const int32_t *t0 = a.gtab + (size_t)st_ * FIXED_LINE_DWORDS, *t1 = a.dtab + (size_t)st_ * FIXED_LINE_DWORDS, *t2 = r.btab + (size_t)st_ * FIXED_LINE_DWORDS;
+    if (kinds[st_] == 0 && st_ != 0) hipLaunchKernelGGL(k_rlc_group_step<true>, dim3(ggrid), dim3(256), 0, s, a.ws, n, (const uint8_t*)r.grp_status, (int)RLC_ACC, t0, t1, t2);
+    else hipLaunchKernelGGL(k_rlc_group_step<false>, dim3(ggrid), dim3(256), 0, s, a.ws, n, (const uint8_t*)r.grp_status, (int)RLC_ACC, t0, t1, t2);
   }
   gops.f12_mul(VE_F, VE_F, RLC_ACC);
   vm_final_exp_program(gops);

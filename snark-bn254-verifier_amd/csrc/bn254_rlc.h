@@ -161,18 +161,137 @@ BN_HD void vm_rlc_scale(W& w, const uint32_t r[4], int n_public, const LX& load_
     w.st(RLC_T + 1 + j, fr8_to_slot(fr8_mul_plain(x, rr)));
   }
 }
+// ---- one Miller step of G variable pairs SHARING the accumulator f (one lane walks G proofs) -------------------------------------------------
+// f <- [f^2] * prod_q line_q(A_q): the squaring is paid once per lane instead of once per proof.  The accessor addresses the current
+// proof's column (w.sel(q): T_q, B_q, A_q; proof q of lane j sits m lanes further per q) and the lane's own column for f (w.ld0 / w.st0).
+// Between the stages f is in flight exactly as in bn254_vm.h::vm_miller_step (k0..k3 parked, k4, k5 in registers).  deadmask bit q: proof q of
+// this lane takes no part (loader error, or it does not exist): its line is replaced by 1 by keeping f, so arbitrary bytes cannot reach f.
+// kind: 0 doubling, 1..4 addition of +B, -B, psi(B), -psi^2(B).
+template <bool DO_SQR, class W>
+BN_HD void vm_miller_var_multi(W& w, int kind, int G, uint32_t deadmask) {
+  Fp2 f4, f5;
+  {
+    Fp2 k0, k1, k2, k3, k4, k5;
+    k0.c0 = w.ld0(VE_F); k0.c1 = w.ld0(VE_F + 1); k1.c0 = w.ld0(VE_F + 2); k1.c1 = w.ld0(VE_F + 3); k2.c0 = w.ld0(VE_F + 4); k2.c1 = w.ld0(VE_F + 5);
+    k3.c0 = w.ld0(VE_F + 6); k3.c1 = w.ld0(VE_F + 7); k4.c0 = w.ld0(VE_F + 8); k4.c1 = w.ld0(VE_F + 9); k5.c0 = w.ld0(VE_F + 10); k5.c1 = w.ld0(VE_F + 11);
+    if constexpr (DO_SQR) {
+      Fp2 x3 = fp2_mul_xi(k3), x4 = fp2_mul_xi(k4), x5 = fp2_mul_xi(k5);
+      w.park(0, fp2_dotp(pp(k0, k0), pp2(k1, x5), pp2(k2, x4), pp(k3, x3)));
+      w.park(1, fp2_dotp(pp2(k0, k1), pp2(k2, x5), pp2(k3, x4)));
+      w.park(2, fp2_dotp(pp2(k0, k2), pp(k1, k1), pp2(k3, x5), pp(k4, x4)));
+      w.park(3, fp2_dotp(pp2(k0, k3), pp2(k1, k2), pp2(k4, x5)));
+      f4 = fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5));
+      f5 = fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3));
+    } else {
+      w.park(0, k0); w.park(1, k1); w.park(2, k2); w.park(3, k3); f4 = k4; f5 = k5;
+    }
+  }
+  for (int q = 0; q < G; q++) {
+    w.sel(q);
+    const bool dead = ((deadmask >> q) & 1u) != 0;
+    G2Line l;
+    {
+      G2Proj t; t.x = vld2(w, VE_T); t.y = vld2(w, VE_T + 2); t.z = vld2(w, VE_T + 4);
+      if (kind == 0) {
+        l = g2_double_step(t);
+      } else {
+        G2Aff b; b.x = vld2(w, VE_B); b.y = vld2(w, VE_B + 2);
+        if (kind == 2) b = g2_neg(b);
+        else if (kind == 3) b = g2_psi_affine(b);
+        else if (kind == 4) b = g2_neg(g2_psi2_affine(b));
+        l = g2_add_step(t, b);
+      }
+      vst2(w, VE_T, t.x); vst2(w, VE_T + 2, t.y); vst2(w, VE_T + 4, t.z);
+    }
+    BN_SCHED_FENCE();
+    Fp px = w.ld(VE_AX), py = w.ld(VE_AY);
+    Fp2 d0 = fp2_mul_fp(l.r0, py), d3 = fp2_mul_fp(l.r1, px), d4 = l.r2;
+    Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
+    BN_SCHED_FENCE();
+    Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3), k4 = f4, k5 = f5;
+    w.park(0, fp2_select(dead, k0, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3))));
+    w.park(1, fp2_select(dead, k1, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4))));
+    w.park(2, fp2_select(dead, k2, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5))));
+    w.park(3, fp2_select(dead, k3, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0))));
+    Fp2 n4 = fp2_select(dead, k4, fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1)));
+    f5 = fp2_select(dead, k5, fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2)));
+    f4 = n4;
+  }
+  {
+    Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3);
+    w.st0(VE_F, k0.c0); w.st0(VE_F + 1, k0.c1); w.st0(VE_F + 2, k1.c0); w.st0(VE_F + 3, k1.c1); w.st0(VE_F + 4, k2.c0); w.st0(VE_F + 5, k2.c1);
+    w.st0(VE_F + 6, k3.c0); w.st0(VE_F + 7, k3.c1); w.st0(VE_F + 8, f4.c0); w.st0(VE_F + 9, f4.c1); w.st0(VE_F + 10, f5.c0); w.st0(VE_F + 11, f5.c1);
+  }
+}
+
+// ---- one Miller step of THREE table-driven pairs in one operation (group stage): [f <- f^2,] f <- f * l0(P0) * l1(P1) * l2(P2) -----------------
+// Same in-flight scheme as bn254_vm.h::vm_miller_step: k0..k3 parked, k4 / k5 in registers, only the last product goes back to the workspace.
+template <bool DO_SQR, class W>
+BN_HD void vm_miller_step_fixed3(W& w, int e, const FixedLine& l0, int e_p0, bool inf0, const FixedLine& l1, int e_p1, bool inf1,
+                                 const FixedLine& l2, int e_p2, bool inf2) {
+  Fp2 f4, f5;
+  {
+    Fp2 k0 = vld2(w, e), k1 = vld2(w, e + 2), k2 = vld2(w, e + 4), k3 = vld2(w, e + 6), k4 = vld2(w, e + 8), k5 = vld2(w, e + 10);
+    if constexpr (DO_SQR) {
+      Fp2 x3 = fp2_mul_xi(k3), x4 = fp2_mul_xi(k4), x5 = fp2_mul_xi(k5);
+      w.park(0, fp2_dotp(pp(k0, k0), pp2(k1, x5), pp2(k2, x4), pp(k3, x3)));
+      w.park(1, fp2_dotp(pp2(k0, k1), pp2(k2, x5), pp2(k3, x4)));
+      w.park(2, fp2_dotp(pp2(k0, k2), pp(k1, k1), pp2(k3, x5), pp(k4, x4)));
+      w.park(3, fp2_dotp(pp2(k0, k3), pp2(k1, k2), pp2(k4, x5)));
+      f4 = fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5));
+      f5 = fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3));
+    } else {
+      w.park(0, k0); w.park(1, k1); w.park(2, k2); w.park(3, k3); f4 = k4; f5 = k5;
+    }
+  }
+  for (int t = 0; t < 2; t++) {   // the first two lines: plain dot products, result stays in flight
+    const FixedLine& l = t == 0 ? l0 : l1;
+    const bool inf = t == 0 ? inf0 : inf1;
+    const int e_p = t == 0 ? e_p0 : e_p1;
+    BN_SCHED_FENCE();
+    Fp px = w.ld(e_p), d0 = w.ld(e_p + 1);
+    Fp2 d3 = fp2_mul_fp(l.m, px);
+    Fp2 x3 = fp2_mul_xi(d3);
+    const Fp2 &d4 = l.c, &x4 = l.xc;
+    Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3), k4 = f4, k5 = f5;
+    w.park(0, fp2_select(inf, k0, fp2_dot_line(d0, k0, x3, k5, x4, k3)));
+    w.park(1, fp2_select(inf, k1, fp2_dot_line(d0, k1, d3, k0, x4, k4)));
+    w.park(2, fp2_select(inf, k2, fp2_dot_line(d0, k2, d3, k1, x4, k5)));
+    w.park(3, fp2_select(inf, k3, fp2_dot_line(d0, k3, d3, k2, d4, k0)));
+    f4 = fp2_select(inf, k4, fp2_dot_line(d0, k4, d3, k3, d4, k1));
+    f5 = fp2_select(inf, k5, fp2_dot_line(d0, k5, d3, k4, d4, k2));
+  }
+  {
+    BN_SCHED_FENCE();
+    Fp px = w.ld(e_p2), d0 = w.ld(e_p2 + 1);
+    Fp2 d3 = fp2_mul_fp(l2.m, px);
+    Fp2 x3 = fp2_mul_xi(d3);
+    const Fp2 &d4 = l2.c, &x4 = l2.xc;
+    Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3);
+    const Fp2 &k4 = f4, &k5 = f5;
+    vst2(w, e, fp2_select(inf2, k0, fp2_dotk(kfp(k0, d0), kp(x3, k5), kp(x4, k3))));
+    vst2(w, e + 2, fp2_select(inf2, k1, fp2_dotk(kfp(k1, d0), kp(d3, k0), kp(x4, k4))));
+    vst2(w, e + 4, fp2_select(inf2, k2, fp2_dotk(kfp(k2, d0), kp(d3, k1), kp(x4, k5))));
+    vst2(w, e + 6, fp2_select(inf2, k3, fp2_dotk(kfp(k3, d0), kp(d3, k2), kp(d4, k0))));
+    vst2(w, e + 8, fp2_select(inf2, k4, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1))));
+    vst2(w, e + 10, fp2_select(inf2, k5, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2))));
+  }
+}
+
 // a lane that contributes nothing to its group (loader error, r-torsion failure, wrong input count): f = 1, C' = O, t = 0
 template <class W>
-BN_HD void vm_rlc_neutral(W& w, int n_public) {
-  w.st(VE_F, fp_one());
-  for (int e = 1; e < 12; e++) w.st(VE_F + e, fp_zero());
+BN_HD void vm_rlc_neutral(W& w, int n_public, bool with_f = true) {
+  if (with_f) {
+    w.st(VE_F, fp_one());
+    for (int e = 1; e < 12; e++) w.st(VE_F + e, fp_zero());
+  }
   w.st(RLC_C, fp_zero()); w.st(RLC_C + 1, fp_one()); w.st(RLC_C + 2, fp_zero());
   for (int j = 0; j <= n_public; j++) w.st(RLC_T + j, fr8_to_slot(fr8_zero()));
 }
 // fold the partner lane (element ids + RLC_HI) into this one: f *= f', C' += C'', t_j += t_j'
 template <class W>
-BN_HD void vm_rlc_fold(W& w, int n_public) {
-  vm_f12_mul(w, VE_F, VE_F, RLC_HI + VE_F, false);
+BN_HD void vm_rlc_fold(W& w, int n_public, bool with_f = true) {
+  if (with_f) vm_f12_mul(w, VE_F, VE_F, RLC_HI + VE_F, false);
   {
     G1Proj a, b;
     a.x = w.ld(RLC_C); a.y = w.ld(RLC_C + 1); a.z = w.ld(RLC_C + 2);

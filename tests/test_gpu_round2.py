@@ -45,6 +45,23 @@ def test_rlc_statuses_identical_to_exact(pkg, O, wl, L):
         pvk.close()
 
 
+def test_rlc_shared_accumulator_layout(pkg, O, wl, L):
+    """The Miller loop of the RLC mode with 2 and 4 proofs per lane (one squaring of f per lane and step): forced on a small batch
+    (by default it is used from 2^19 proofs per launch), same status bytes as the exact path."""
+    vk, proofs, inputs, exp = wl
+    pvk = pkg.PreparedVk(vk)
+    old = {k: os.environ.get(k) for k in ("BN254_RLC_SHARE_MIN_LANES",)}
+    try:
+        os.environ["BN254_RLC_SHARE_MIN_LANES"] = "1"
+        for n in (len(exp), 1000, 257, 67):
+            assert pvk.verify_batch(proofs[:256 * n], inputs[:64 * n], n, flags=pkg.FLAG_RLC) == exp[:n], n
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    pvk.close()
+
+
 def test_rlc_all_valid_all_invalid_and_sizes(pkg, O, L):
     vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540012, 2, 1500, invalid_every=0, agree=True, threads=16)
     pvk = pkg.PreparedVk(vk)

@@ -99,10 +99,11 @@ def _key_points(pkg, vk, n_public):
     return alpha, ks, _neg_g2(gamma), _neg_g2(delta), beta
 
 
-@pytest.mark.parametrize("n,log2_group,bad", [(5, 8, []), (5, 8, [3]), (6, 1, [1])])
-def test_rlc_group_pipeline(hostsim, pkg, O, n, log2_group, bad):
+@pytest.mark.parametrize("n,log2_group,bad,log2_share", [(5, 8, [], 0), (5, 8, [3], 0), (6, 1, [1], 0), (7, 8, [], 2), (7, 2, [5], 1), (6, 8, [2], 2)])
+def test_rlc_group_pipeline(hostsim, pkg, O, n, log2_group, bad, log2_share):
     """Valid proofs: every group's product is one.  A proof that the oracle rejects makes exactly its own group fail.  A lane marked
-    as a loader error is neutral (its group still passes)."""
+    as a loader error is neutral (its group still passes).  log2_share > 0: the shared-accumulator Miller loop (one lane walks
+    2^log2_share proofs, one squaring of f per lane and step)."""
     n_public = 2
     vk, proofs, inputs, expected = pkg.synth_groth16(0xB2540077, n_public, n, invalid_every=0, agree=True, threads=2)
     proofs = bytearray(proofs); inputs = bytearray(inputs)
@@ -114,7 +115,7 @@ def test_rlc_group_pipeline(hostsim, pkg, O, n, log2_group, bad):
     alpha, ks, qg, qd, qb = _key_points(pkg, vk, n_public)
     key = hashlib.sha256(b"rlc-test-key").digest() + bytes(12)
     groups = (C.c_uint8 * n)(); group_of = (C.c_uint32 * n)()
-    ng = hostsim.hs_rlc_pipeline(n, bytes(proofs), bytes(inputs), n_public, alpha, ks, qg, qd, qb, key, log2_group, 0, groups, group_of)
+    ng = hostsim.hs_rlc_pipeline(n, bytes(proofs), bytes(inputs), n_public, alpha, ks, qg, qd, qb, key, log2_group, 0, groups, group_of, log2_share)
     assert ng >= 1
     bad_groups = {group_of[i] for i in bad}
     assert [groups[g] for g in range(ng)] == [0 if g in bad_groups else 1 for g in range(ng)]
@@ -122,5 +123,5 @@ def test_rlc_group_pipeline(hostsim, pkg, O, n, log2_group, bad):
     if bad:
         # the same batch with the bad proofs masked out as loader errors: their lanes are neutral, all groups pass
         mask = sum(1 << i for i in bad)
-        ng2 = hostsim.hs_rlc_pipeline(n, bytes(proofs), bytes(inputs), n_public, alpha, ks, qg, qd, qb, key, log2_group, mask, groups, group_of)
+        ng2 = hostsim.hs_rlc_pipeline(n, bytes(proofs), bytes(inputs), n_public, alpha, ks, qg, qd, qb, key, log2_group, mask, groups, group_of, log2_share)
         assert ng2 == ng and all(groups[g] == 1 for g in range(ng))
