@@ -24,6 +24,10 @@
 #define G16_MAX_BATCH 1048576  // proofs per chunk of a larger batch (one workspace)
 #define G16_MAX_LAUNCH 786432  // proofs per kernel launch: the workspace is addressed with 32-bit buffer offsets, 130 * 36 * n < 2^32
 
+// every workspace byte offset (SGPR row offset + VGPR lane offset) must fit the 32-bit offset arithmetic of the buffer instructions, and the
+// out-of-range lane offset 0xfffffffc must stay above every valid one so that the descriptor's bounds check (num_records = the launch's
+// workspace bytes) drops the dead lanes' accesses
+static_assert((unsigned long long)G16_MAX_LAUNCH * G16_WS_BYTES_PER_PROOF < 0xfffffffcull, "workspace of one launch exceeds 32-bit buffer offsets");
 // workspace elements the PlonK path writes its two G1 points to (bn254_vm.h: VE_LX, VE_CX)
 #define VE_LX_ELEM 8
 #define VE_CX_ELEM 6
