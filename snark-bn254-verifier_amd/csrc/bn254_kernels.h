@@ -86,6 +86,14 @@ hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
                                        int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
+// cooperative layout for small batches (bn254_coop.hip): six lanes per proof, the whole Miller loop / final exponentiation in one launch
+#define COOP_T_ELEM 46          // = VE_S2: where the cooperative Miller loop leaves the running G2 point for k_g16_subgroup
+#define COOP_MAX_PROOFS 10240   // above this the one-proof-per-lane kernels fill the GPU better
+hipError_t bn254_coop_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
+                                 int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int fuse_final_exp, hipStream_t s);
+hipError_t bn254_coop_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
+hipError_t bn254_coop_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
+                                   int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

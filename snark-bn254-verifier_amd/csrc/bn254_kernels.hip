@@ -492,10 +492,10 @@ k_g1_sum_affine(const int32_t* __restrict__ part, int n_terms, uint32_t n, uint3
 // k_g16_subgroup
 // =====================================================================================================================
 __global__ void __launch_bounds__(256, 2)
-k_g16_subgroup(uint32_t n, int32_t* ws, uint8_t* __restrict__ status, int inputs_match_key) {
+k_g16_subgroup(uint32_t n, int32_t* ws, uint8_t* __restrict__ status, int inputs_match_key, int e_t) {
   // runs AFTER the Miller loop: the r-torsion test of B reads the loop's final G2 point (bn254_vm.h::vm_g2_ate_check)
   VM_KERNEL_PROLOGUE();
-  bool ok = vm_g2_ate_check(w, VE_T, VE_B);
+  bool ok = vm_g2_ate_check(w, e_t, VE_B);
   if (i < n && (st & BN254_ST_PENDING)) {
     uint8_t out;
     if (!ok) out = BN254_ST_NOT_IN_SUBGROUP;
@@ -804,7 +804,10 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   uint32_t n = (uint32_t)a.n;
   if (ev) (void)hipEventRecord(ev[0], s);
   const bool wide = a.msm_part != nullptr && a.inputs_match_key && a.n_public > G16_WIDE_MSM_MIN_INPUTS;
-  BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, wide ? 1 : 0);
+  static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
+  const bool coop = coop_on && a.n <= COOP_MAX_PROOFS && !wide && a.n_public <= G16_WIDE_MSM_MIN_INPUTS;
+  // cooperative path: the public-input MSM moves into the cooperative kernel (six lanes per proof, L kept projective), so k_g16_prepare stops after C
+  BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, (wide || coop) ? 1 : 0);
   if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
   if (wide) {
     // inputs of one proof spread over `chunks` lanes, proofs in slices that fit the partial-sum buffer
@@ -814,6 +817,17 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     BN_LAUNCH(KID_MSM_REDUCE, k_g16_msm_reduce, (const int32_t*)a.msm_part, chunks, n, a.ws, a.status, a.k0);
   }
   if (ev) (void)hipEventRecord(ev[1], s);
+  if (coop) {
+    // small batch: cooperative layout (bn254_coop.hip): public-input MSM, Miller loop of the three pairs and final exponentiation in ONE launch
+    hipError_t e = bn254_coop_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, 1, s);
+    if (e != hipSuccess) return e;
+    if (ev) { (void)hipEventRecord(ev[2], s); }
+    BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)COOP_T_ELEM);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, a.status, a.target, BN254_ST_REJECT);
+    if (ev) (void)hipEventRecord(ev[4], s);
+    return hipGetLastError();
+  }
   LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab, nullptr}, prof};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
   if (a.split_streams[0] && a.split_streams[1] && a.n <= G16_SPLIT_MAX_PROOFS) {
@@ -841,7 +855,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   }
   if (ev) (void)hipEventRecord(ev[2], s);
   // r-torsion test of B from the loop's final point; resolves the deferred statuses (C errors, input count)
-  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
+  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)VE_T);
   if (ev) (void)hipEventRecord(ev[3], s);
   vm_final_exp_program(ops);
   BN_LAUNCH(KID_COMPARE, k_g16_compare, a.ws, n, a.status, a.target, BN254_ST_REJECT);
@@ -878,7 +892,7 @@ hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, 
       else hipLaunchKernelGGL(k_rlc_miller_multi<false>, dim3(mgrid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, kind, share, m);
     }
   }
-  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key);
+  BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)VE_T);
   hipLaunchKernelGGL(k_rlc_neutral, dim3(grid), dim3(256), 0, s, a.ws, n, (const uint8_t*)a.status, a.n_public, share == 1 ? 1 : 0);
   uint32_t cur = n;
   for (int k = 0; k < r.plan.rounds; k++) {
@@ -979,6 +993,14 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   G16Prof* prof = nullptr;
   LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1, nullptr}, nullptr};
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
+  static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
+  if (coop_on && n <= COOP_MAX_PROOFS) {
+    // small batch: the cooperative layout (bn254_coop.hip), Miller loop of the two pairs and final exponentiation in ONE launch
+    hipError_t e = bn254_coop_miller_fixed(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
+    if (e != hipSuccess) return e;
+    BN_LAUNCH(KID_COMPARE, k_g16_compare, ws, nn, status, target_one, reject_code);
+    return hipGetLastError();
+  }
   BN_LAUNCH(KID_VM_INIT, k_vm_init, ws, nn, (const uint8_t*)status);
   const uint8_t* kinds = step_kinds_host();
   if (aux && n <= G16_SPLIT_MAX_PROOFS) {
