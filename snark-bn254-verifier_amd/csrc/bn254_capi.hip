@@ -150,59 +150,88 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 }
 
 // ---------------------------------------------------------------- PlonK (BASELINE configs[3])
+// One PlonkCtx = one sub-batch in flight: its own stream, device buffers and pinned host staging.  A batch is cut into sub-batches that worker
+// threads drive concurrently, so the host stages of one sub-batch (transcripts, Fr arithmetic) overlap the GPU stages of the others; every
+// wait is stream-scoped.
+#define PLONK_WORKERS 4
+#define PLONK_MAX_LAUNCH 65536
+struct PlonkCtx {
+  size_t cap = 0;                      // proofs the buffers below hold
+  hipStream_t stream = nullptr, aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int32_t *ws = nullptr, *part = nullptr;
+  MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
+  // pinned host staging
+  MsmTerm* h_terms = nullptr; uint8_t *h_flags = nullptr, *h_status = nullptr, *h_inf = nullptr; uint32_t* h_words = nullptr;
+};
 struct PlonkDev {
   bool ready = false;
   int32_t *tab0 = nullptr, *tab1 = nullptr, *one = nullptr;
-  size_t cap = 0;                      // proofs the buffers below hold
-  int32_t *ws = nullptr, *part = nullptr;
-  MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
-  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // latency mode of the pairing check
+  PlonkCtx ctx[PLONK_WORKERS];
 };
 struct bn254_plonk_pvk {
   PlonkKey key;
   std::vector<int32_t> tab0, tab1, one;
-  mutable std::mutex mu;
+  mutable std::mutex mu;               // one batch per key at a time (its sub-batches run concurrently inside)
   mutable std::map<int, PlonkDev> dev;
 };
-#define PLONK_MAX_LAUNCH 65536
-static void plonk_dev_free(PlonkDev& d) {
-  void* ptrs[] = {d.tab0, d.tab1, d.one, d.ws, d.part, d.terms, d.flags, d.words, d.inf, d.status};
+static void plonk_ctx_free(PlonkCtx& c) {
+  void* ptrs[] = {c.ws, c.part, c.terms, c.flags, c.words, c.inf, c.status};
   for (auto q : ptrs) if (q) (void)hipFree(q);
-  if (d.aux) (void)hipStreamDestroy(d.aux);
-  if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
-  if (d.ev_join) (void)hipEventDestroy(d.ev_join);
-  d = PlonkDev();
+  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words};
+  for (auto q : hp) if (q) (void)hipHostFree(q);
+  if (c.stream) (void)hipStreamDestroy(c.stream);
+  if (c.aux) (void)hipStreamDestroy(c.aux);
+  if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+  if (c.ev_join) (void)hipEventDestroy(c.ev_join);
+  c = PlonkCtx();
 }
-static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, size_t n, PlonkDev** out) {
+static void plonk_dev_free(PlonkDev& d) {
+  void* ptrs[] = {d.tab0, d.tab1, d.one};
+  for (auto q : ptrs) if (q) (void)hipFree(q);
+  for (auto& c : d.ctx) plonk_ctx_free(c);
+  d.ready = false; d.tab0 = d.tab1 = d.one = nullptr;
+}
+static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** out) {
   int rc = check_device(device);
   if (rc) return rc;
   PlonkDev& d = pvk->dev[device];
   if (!d.ready) {
     if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
-    HIPCK(hipStreamCreateWithFlags(&d.aux, hipStreamNonBlocking));
-    HIPCK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
     d.ready = true;
-  }
-  size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
-  if (need > d.cap) {
-    void* ptrs[] = {d.ws, d.part, d.terms, d.flags, d.words, d.inf, d.status};
-    for (auto q : ptrs) if (q) (void)hipFree(q);
-    d.ws = d.part = nullptr; d.terms = nullptr; d.flags = nullptr; d.words = nullptr; d.inf = d.status = nullptr; d.cap = 0;
-    const size_t tmax = (size_t)plonk_stage2_terms(pvk->key) > (size_t)plonk_stage1_terms(pvk->key) ? plonk_stage2_terms(pvk->key) : plonk_stage1_terms(pvk->key);
-    HIPCK(hipMalloc((void**)&d.ws, need * (size_t)G16_WS_BYTES_PER_PROOF));
-    HIPCK(hipMalloc((void**)&d.part, need * tmax * 27 * sizeof(int32_t)));
-    HIPCK(hipMalloc((void**)&d.terms, need * tmax * sizeof(MsmTerm)));
-    HIPCK(hipMalloc((void**)&d.flags, need * tmax));
-    HIPCK(hipMalloc((void**)&d.words, need * 16 * sizeof(uint32_t)));
-    HIPCK(hipMalloc((void**)&d.inf, need));
-    HIPCK(hipMalloc((void**)&d.status, need));
-    d.cap = need;
   }
   *out = &d;
   return BN254_OK;
 }
-template <class F> static void plonk_parallel(size_t n, F&& f) {
-  unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
+static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
+  if (!c.stream) {
+    HIPCK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+  }
+  size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
+  if (need <= c.cap) return BN254_OK;
+  void* ptrs[] = {c.ws, c.part, c.terms, c.flags, c.words, c.inf, c.status};
+  for (auto q : ptrs) if (q) (void)hipFree(q);
+  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words};
+  for (auto q : hp) if (q) (void)hipHostFree(q);
+  c.cap = 0;
+  const size_t tmax = (size_t)plonk_stage2_terms(pvk->key) + 2 > (size_t)plonk_stage1_terms(pvk->key) ? plonk_stage2_terms(pvk->key) + 2 : plonk_stage1_terms(pvk->key);
+  HIPCK(hipMalloc((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF));
+  HIPCK(hipMalloc((void**)&c.part, need * tmax * 27 * sizeof(int32_t)));
+  HIPCK(hipMalloc((void**)&c.terms, need * tmax * sizeof(MsmTerm)));
+  HIPCK(hipMalloc((void**)&c.flags, need * tmax));
+  HIPCK(hipMalloc((void**)&c.words, need * 16 * sizeof(uint32_t)));
+  HIPCK(hipMalloc((void**)&c.inf, need));
+  HIPCK(hipMalloc((void**)&c.status, need));
+  HIPCK(hipHostMalloc((void**)&c.h_terms, need * tmax * sizeof(MsmTerm), hipHostMallocDefault));
+  HIPCK(hipHostMalloc((void**)&c.h_flags, need * tmax, hipHostMallocDefault));
+  HIPCK(hipHostMalloc((void**)&c.h_status, need, hipHostMallocDefault));
+  HIPCK(hipHostMalloc((void**)&c.h_inf, need, hipHostMallocDefault));
+  HIPCK(hipHostMalloc((void**)&c.h_words, need * 16 * sizeof(uint32_t), hipHostMallocDefault));
+  c.cap = need;
+  return BN254_OK;
+}
+template <class F> static void plonk_parallel(size_t n, unsigned hw, F&& f) {
+  if (hw == 0) hw = 1;
   if (n < 64) hw = 1;
   if (hw == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
   std::vector<std::thread> th;
@@ -601,10 +630,78 @@ int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** o
 }
 void bn254_plonk_vk_free(bn254_plonk_pvk* pvk) {
   if (!pvk) return;
-  for (auto& kv : pvk->dev) { if (hipSetDevice(kv.first) != hipSuccess) continue; plonk_dev_free(kv.second); }
+  for (auto& kv : pvk->dev) { if (hipSetDevice(kv.first) != hipSuccess) continue; (void)hipDeviceSynchronize(); plonk_dev_free(kv.second); }
   delete pvk;
 }
 size_t bn254_plonk_vk_num_public(const bn254_plonk_pvk* pvk) { return pvk ? (size_t)pvk->key.nb_public : 0; }
+
+// one sub-batch [0, m) on its context: stage 1 (host) -> digest MSM (GPU) -> stage 2 (host) -> folding MSMs + pairing check (GPU) -> statuses
+static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c, int device, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                     size_t n_public, size_t m, uint8_t* status, unsigned host_threads) {
+  HIPCK(hipSetDevice(device));
+  const PlonkKey& key = pvk->key;
+  const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key);
+  static const bool timing = getenv("BN254_PLONK_TIMING") != nullptr;   // stage durations on stderr (diagnostics)
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto t0 = now();
+  std::vector<PlonkWork> work(m);
+  memset(c.h_terms, 0, m * (size_t)T1 * sizeof(MsmTerm));
+  // The KZG batching scalar of every proof: fresh, uniform and unpredictable to the prover, as the reference draws it
+  // (Fr::random(&mut OsRng), plonk/kzg.rs:149-154).  It MUST be secret until the proof is fixed: the two opening quotients are bound by
+  // no transcript, so a prover who knows lambda can shift them by (lambda D, -D) and cancel a wrong evaluation
+  // (tests/test_oracle_golden.py::test_kzg_batching_scalar_must_be_unpredictable).  48 bytes of getrandom(2) reduced mod r per proof.
+  std::vector<uint8_t> rnd(m * 48);
+  for (size_t got = 0; got < rnd.size();) {
+    ssize_t k = getrandom(rnd.data() + got, rnd.size() - got, 0);
+    if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
+    got += (size_t)k;
+  }
+  // ---- stage 1 on the host threads
+  plonk_parallel(m, host_threads, [&](size_t i) {
+    work[i].lambda = fr_ctx().from_be_reduce(rnd.data() + 48 * i, 48);
+    work[i].status = plonk_stage1(key, proofs + i * proof_stride, proof_stride, public_inputs + i * n_public * 32, n_public, work[i], &c.h_terms[i * T1]);
+  });
+  auto t1_ = now();
+  // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
+  HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemsetAsync(c.flags, 0, m * (size_t)T1, c.stream));
+  hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+  HIPCK(hipMemcpyAsync(c.h_words, c.words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync(c.h_inf, c.inf, m, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  auto t2_ = now();
+  // ---- stage 2 on the host threads: the terms of P0 (T2 of them) and of P1 (2) side by side, so that ONE launch does all scalar multiplications
+  const int TT = T2 + 2;
+  memset(c.h_terms, 0, m * (size_t)TT * sizeof(MsmTerm));
+  memset(c.h_flags, 0, m * (size_t)TT);
+  plonk_parallel(m, host_threads, [&](size_t i) {
+    if (work[i].status == PL_OK) {
+      work[i].pr.raw = proofs + i * proof_stride;
+      plonk_stage2(key, proofs + i * proof_stride, work[i], &c.h_words[i * 16], c.h_inf[i] != 0, &c.h_terms[i * TT], &c.h_flags[i * TT], &c.h_terms[i * TT + T2]);
+      c.h_status[i] = BN254_ST_PENDING;
+    } else {
+      c.h_status[i] = (uint8_t)work[i].status;
+    }
+  });
+  auto t3_ = now();
+  // ---- P0, P1 and the pairing check on the GPU: everything on the context's stream, no host wait in between
+  HIPCK(hipMemcpyAsync(c.status, c.h_status, m, hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * TT * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)TT, hipMemcpyHostToDevice, c.stream));
+  e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+  e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
+  HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  memcpy(status, c.h_status, m);
+  if (timing) fprintf(stderr, "plonk sub-batch %zu: stage1 %.2f ms, msm1 %.2f ms, stage2 %.2f ms, msm2+pairing %.2f ms\n", m, ms(t0, t1_), ms(t1_, t2_), ms(t2_, t3_), ms(t3_, now()));
+  return BN254_OK;
+}
 
 int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                              size_t n_public, size_t n, uint8_t* status, int device) {
@@ -612,76 +709,32 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   if (n == 0) return BN254_OK;
   std::lock_guard<std::mutex> lk(pvk->mu);
   PlonkDev* d;
-  int rc = plonk_ensure_dev(pvk, device, n, &d);
+  int rc = plonk_ensure_dev(pvk, device, &d);
   if (rc) return rc;
-  const PlonkKey& key = pvk->key;
-  const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key);
-  static const bool timing = getenv("BN254_PLONK_TIMING") != nullptr;   // stage durations on stderr (diagnostics)
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  for (size_t off = 0; off < n; off += PLONK_MAX_LAUNCH) {
-    const size_t m = n - off < (size_t)PLONK_MAX_LAUNCH ? n - off : (size_t)PLONK_MAX_LAUNCH;
-    auto t0 = now();
-    std::vector<PlonkWork> work(m);
-    std::vector<MsmTerm> terms(m * (size_t)(T1 > T2 ? T1 : T2));
-    std::vector<uint8_t> flags(m * (size_t)(T1 > T2 ? T1 : T2), 0), st(m), inf(m);
-    std::vector<uint32_t> words(m * 16);
-    memset(terms.data(), 0, terms.size() * sizeof(MsmTerm));
-    // The KZG batching scalar of every proof: fresh, uniform and unpredictable to the prover, as the reference draws it
-    // (Fr::random(&mut OsRng), plonk/kzg.rs:149-154).  It MUST be secret until the proof is fixed: the two opening quotients are bound by
-    // no transcript, so a prover who knows lambda can shift them by (lambda D, -D) and cancel a wrong evaluation
-    // (tests/test_oracle_golden.py::test_kzg_batching_scalar_must_be_unpredictable).  48 bytes of getrandom(2) reduced mod r per proof.
-    std::vector<uint8_t> rnd(m * 48);
-    for (size_t got = 0; got < rnd.size();) {
-      ssize_t k = getrandom(rnd.data() + got, rnd.size() - got, 0);
-      if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
-      got += (size_t)k;
+  // sub-batches: at least 512 proofs each, at most PLONK_WORKERS in flight, each at most PLONK_MAX_LAUNCH proofs per pass
+  unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
+  static const int max_workers = [] { const char* e = getenv("BN254_PLONK_WORKERS"); int v = e ? atoi(e) : PLONK_WORKERS; return v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v); }();
+  // below ~16 k proofs every GPU stage is latency-bound (one wave generation): sub-batches would only repeat those latencies side by side
+  int workers = (int)(n / 8192); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
+  const size_t per = (n + workers - 1) / workers;
+  for (int w = 0; w < workers; w++) { size_t m = per < (size_t)PLONK_MAX_LAUNCH ? per : (size_t)PLONK_MAX_LAUNCH; if ((rc = plonk_ensure_ctx(pvk, d->ctx[w], m))) return rc; }
+  std::vector<int> rcs(workers, BN254_OK); std::vector<std::string> errs(workers);
+  auto body = [&](int w) {
+    const size_t lo = (size_t)w * per, hi = lo + per < n ? lo + per : n;
+    for (size_t off = lo; off < hi; off += PLONK_MAX_LAUNCH) {
+      const size_t m = hi - off < (size_t)PLONK_MAX_LAUNCH ? hi - off : (size_t)PLONK_MAX_LAUNCH;
+      int r = plonk_run(pvk, d, d->ctx[w], device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
+                        (hw + workers - 1) / workers);
+      if (r) { rcs[w] = r; errs[w] = g_err; return; }
     }
-    // ---- stage 1 on the host threads
-    plonk_parallel(m, [&](size_t i) {
-      work[i].lambda = fr_ctx().from_be_reduce(rnd.data() + 48 * i, 48);
-      work[i].status = plonk_stage1(key, proofs + (off + i) * proof_stride, proof_stride, public_inputs + (off + i) * n_public * 32, n_public, work[i], &terms[i * T1]);
-    });
-    auto t1_ = now();
-    // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
-    HIPCK(hipMemcpy(d->terms, terms.data(), m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice));
-    HIPCK(hipMemset(d->flags, 0, m * (size_t)T1));
-    hipError_t e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, T1, d->part, d->words, d->inf, nullptr, nullptr, 0, 0, nullptr);
-    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
-    HIPCK(hipDeviceSynchronize());
-    HIPCK(hipMemcpy(words.data(), d->words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIPCK(hipMemcpy(inf.data(), d->inf, m, hipMemcpyDeviceToHost));
-    auto t2_ = now();
-    // ---- stage 2 on the host threads
-    std::vector<MsmTerm> t1(m * 2);
-    memset(t1.data(), 0, t1.size() * sizeof(MsmTerm));
-    memset(terms.data(), 0, terms.size() * sizeof(MsmTerm));
-    plonk_parallel(m, [&](size_t i) {
-      if (work[i].status == PL_OK) {
-        work[i].pr.raw = proofs + (off + i) * proof_stride;
-        plonk_stage2(key, proofs + (off + i) * proof_stride, work[i], &words[i * 16], inf[i] != 0, &terms[i * T2], &flags[i * T2], &t1[i * 2]);
-        st[i] = BN254_ST_PENDING;
-      } else {
-        st[i] = (uint8_t)work[i].status;
-      }
-    });
-    auto t3_ = now();
-    // ---- P0, P1 and the pairing check on the GPU
-    HIPCK(hipMemcpy(d->status, st.data(), m, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(d->terms, terms.data(), m * T2 * sizeof(MsmTerm), hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(d->flags, flags.data(), m * (size_t)T2, hipMemcpyHostToDevice));
-    e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, T2, d->part, nullptr, nullptr, d->ws, d->status, VE_LX_ELEM, BN254_ST_LINF, nullptr);
-    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
-    HIPCK(hipDeviceSynchronize());   // d->terms is reused below
-    HIPCK(hipMemcpy(d->terms, t1.data(), m * 2 * sizeof(MsmTerm), hipMemcpyHostToDevice));
-    HIPCK(hipMemset(d->flags, 0, m * 2));
-    e = bn254_launch_g1_msm((const int32_t*)d->terms, d->flags, m, 2, d->part, nullptr, nullptr, d->ws, d->status, VE_CX_ELEM, BN254_ST_LINF2, nullptr);
-    if (e == hipSuccess) e = bn254_launch_pairing2_fixed(d->ws, d->status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, nullptr, d->aux, d->ev_fork, d->ev_join);
-    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
-    HIPCK(hipDeviceSynchronize());
-    HIPCK(hipMemcpy(status + off, d->status, m, hipMemcpyDeviceToHost));
-    if (timing) fprintf(stderr, "plonk batch %zu: stage1 %.2f ms, msm1 %.2f ms, stage2 %.2f ms, msm2+pairing %.2f ms\n", m, ms(t0, t1_), ms(t1_, t2_), ms(t2_, t3_), ms(t3_, now()));
+  };
+  if (workers == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (int w = 0; w < workers; w++) th.emplace_back(body, w);
+    for (auto& t : th) t.join();
   }
+  for (int w = 0; w < workers; w++) if (rcs[w]) return set_err(rcs[w], errs[w]);
   return BN254_OK;
 }
 

@@ -17,6 +17,7 @@
 // Lock-step: a wavefront executes its LDS instructions in order, so a value written by every lane and then read by other lanes of the same
 // wavefront needs no barrier; every operation reads all of its inputs before it writes its output slot (in-place operations are safe).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "bn254_vm.h"
 #include "bn254_kernels.h"
 
@@ -439,6 +440,8 @@ static inline unsigned co_grid(size_t n, int waves_per_block) { return (unsigned
 // device copy of the step-kind table (88 bytes), created on first use per device
 static const uint8_t* co_kinds_dev(hipStream_t s) {
   static uint8_t* dev[64] = {nullptr};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   int d = 0; (void)hipGetDevice(&d);
   if (d < 0 || d >= 64) return nullptr;
   if (!dev[d]) {

@@ -457,12 +457,12 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
 // flag byte (1 = identity) per item, for the host.  Otherwise the point goes to workspace elements (e_x, e_x + 1) as (x, y) or
 // (0, 1) for the identity, whose flag bit `inf_bit` is OR-ed into the (pending) status byte.
 __global__ void __launch_bounds__(256, 2)
-k_g1_sum_affine(const int32_t* __restrict__ part, int n_terms, uint32_t n, uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf,
+k_g1_sum_affine(const int32_t* __restrict__ part, int first, int n_terms, uint32_t n, uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf,
                 int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t ii = i < n ? i : n - 1;
   G1Proj L = g1_identity();
-  for (int c = 0; c < n_terms; c++) {
+  for (int c = first; c < first + n_terms; c++) {
     const int32_t* o = part + (size_t)c * 27 * n + ii;
     G1Proj q;
 #pragma unroll
@@ -981,7 +981,17 @@ hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
   unsigned g1 = (unsigned)((n * (size_t)n_terms + 255) / 256);
   hipLaunchKernelGGL(k_g1_scalar_mul, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, n_terms, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
+  return hipGetLastError();
+}
+// the two halves of the above separately: ONE scalar-multiplication launch can feed several sums (PlonK: P0 and P1 of the KZG check)
+hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, hipStream_t s) {
+  unsigned g1 = (unsigned)((n * (size_t)n_terms + 255) / 256);
+  hipLaunchKernelGGL(k_g1_scalar_mul, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
+  return hipGetLastError();
+}
+hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, part, first, count, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status, e_x, inf_bit);
   return hipGetLastError();
 }
 // prod_t e(P_t, Q_t) == 1 for two key-side G2 points (line tables tab0, tab1) and per-item G1 points already in the workspace
