@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch-log2", type=int, default=20, help="proofs per GPU = 2^this (default: BASELINE 2^20)")
     ap.add_argument("--n-public", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="proofs timed on the host per cpu_baseline row")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="proofs timed on the host per cpu_baseline row")
     ap.add_argument("--rlc", action="store_true", help="time the random-linear-combination batch mode instead of the exact path")
     ap.add_argument("--host-buffers", action="store_true", help="also time the host-buffer entry (PCIe-inclusive), reported beside `value`")
     return ap.parse_args(argv)
@@ -237,6 +237,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
             dom = max(prof, key=lambda k: prof[k][1])
             out["roofline"] = _valu_roofline(dom, prof[dom], per_launch)
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
+            out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown)
         emit(json.dumps(out))
     return out
 
@@ -285,6 +286,23 @@ def _valu_whole_path(breakdown, proofs_per_s_per_gpu):
     ach = mads * proofs_per_s_per_gpu
     return {"mads_per_proof": mads, "achieved": ach / 1e12, "peak": VALU_PEAK_MAD_PER_S / 1e12, "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S,
             "kernels_without_count": missing}
+
+
+def _traffic_whole_path(breakdown):
+    """HBM bytes per proof over the whole path: per kernel kind, counter bytes per proof and launch (profiles/pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) x its launches per batch."""
+    t = _load_json("pmc_traffic.json")
+    if not t:
+        return None
+    total, missing = 0.0, []
+    for k, (cnt, _ms) in breakdown.items():
+        e = t.get(k)
+        if e is None:
+            missing.append(k)
+            continue
+        total += cnt * (e["read_bytes_per_proof"] + e["write_bytes_per_proof"])
+    return {"counter_bytes_per_proof": total, "algorithmic_bytes_per_proof": ALGO_BYTES_PER_PROOF, "ratio": total / ALGO_BYTES_PER_PROOF,
+            "kernels_without_counters": missing}
 
 
 def _cpu_baseline(args, vk, proofs, inputs, expected):

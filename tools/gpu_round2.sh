@@ -1,0 +1,37 @@
+#!/bin/bash
+# round 2, one GPU call: parity tests, smoke, bench (+ host buffers), rocprofv3 kernel trace of the bench command, PMC passes, the secondary
+# configurations (RLC mode, small batches, PlonK, 1024 public inputs).  Outputs under gpurun_out/r02/; tools/summarize_profiles.py r02_final gpurun_out/r02
+set -o pipefail
+R=$PWD; O=$R/gpurun_out/r02
+rm -rf $O; mkdir -p $O
+fail() { echo "FAILED: $1"; tail -20 $2; exit 1; }
+python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1 || fail pytest $O/pytest_gpu.log
+tail -3 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 || fail smoke $O/smoke.log
+tail -1 $O/smoke.log
+python bench.py --host-buffers > $O/bench.json 2> $O/bench.err || fail bench $O/bench.err
+cut -c1-400 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err || fail rocprof $O/prof.err
+echo "kernel trace done"
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  BN254_STREAMS=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch-log2 18 > $O/pmc_$tag.json 2> $O/pmc_$tag.err || fail "pmc $tag" $O/pmc_$tag.err
+  echo "pmc $tag done"
+done
+cd $R
+# the kernel traces are large: keep the per-kernel statistics, drop traces above 30 MB
+find $O -name "*kernel_trace.csv" -size +30M -delete
+python tools/bench_rlc.py --batch-log2 20 --steps 3 --invalid-every 0,256,16 > $O/rlc.txt 2> $O/rlc.err || fail rlc $O/rlc.err
+cat $O/rlc.txt
+python tools/bench_small.py > $O/small_coop.txt 2> $O/small_coop.err || fail small $O/small_coop.err
+BN254_COOP=0 python tools/bench_small.py > $O/small_lane.txt 2> $O/small_lane.err || fail small_lane $O/small_lane.err
+grep 4096 $O/small_coop.txt $O/small_lane.txt
+BN254_PLONK_TIMING=1 python tools/bench_plonk.py > $O/plonk.json 2> $O/plonk.err || fail plonk $O/plonk.err
+cut -c1-200 $O/plonk.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk -o run -- python3 $R/tools/bench_plonk.py --steps 3 > $O/prof_plonk.json 2> $O/prof_plonk.err || fail "rocprof plonk" $O/prof_plonk.err
+cd $R
+python bench.py --n-public 1024 --batch-log2 12 --steps 5 --warmup 1 --cpu-sample 128 > $O/cfg5.json 2> $O/cfg5.err || fail cfg5 $O/cfg5.err
+cut -c1-200 $O/cfg5.json
+echo "round 2 GPU script done"

@@ -4,6 +4,7 @@ usage: python tools/summarize_profiles.py r01_final"""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"      # directory (under the repo root) that holds prof/ and pmc_*/
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 
@@ -16,7 +17,7 @@ def short(name):
 
 
 # ---- kernel trace: per-kernel calls / total / average (ns) from the raw trace (the --stats file carries the same numbers)
-tr = glob.glob(os.path.join(root, "gpurun_out/prof/**/*kernel_trace.csv"), recursive=True)[0]
+tr = glob.glob(os.path.join(root, src + "/prof/**/*kernel_trace.csv"), recursive=True)[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(tr)):
     agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -26,11 +27,11 @@ with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
     f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         f.write("%s,%d,%.3f,%.2f,%.2f,%.2f,%.2f\n" % (k, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3, 100.0 * sum(v) / tot))
-st = glob.glob(os.path.join(root, "gpurun_out/prof/**/*kernel_stats.csv"), recursive=True)
+st = glob.glob(os.path.join(root, src + "/prof/**/*kernel_stats.csv"), recursive=True)
 if st:
     shutil.copy(st[0], os.path.join(out, tag + "_rocprof_kernel_stats_raw.csv"))
 for name in ("bench.json", "prof_bench.json"):
-    p = os.path.join(root, "gpurun_out", name)
+    p = os.path.join(root, src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
 
@@ -51,9 +52,9 @@ def load(pattern):
     return a, cnt
 
 
-sq, cnt = load("gpurun_out/pmc_SQ_WAVE_CYCLES/**/*counter_collection.csv")
-fs, _ = load("gpurun_out/pmc_FETCH_SIZE/**/*counter_collection.csv")
-ws, _ = load("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv")
+sq, cnt = load(src + "/pmc_SQ_WAVE_CYCLES/**/*counter_collection.csv")
+fs, _ = load(src + "/pmc_FETCH_SIZE/**/*counter_collection.csv")
+ws, _ = load(src + "/pmc_WRITE_SIZE/**/*counter_collection.csv")
 n = 1 << 18
 traffic = {"_note": "HBM bytes per proof and launch of each kernel kind from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, batch 2^18, "
                     "one stream, bench.py --steps 1 --warmup 0); FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md prescribes for gfx950 (checked on "
