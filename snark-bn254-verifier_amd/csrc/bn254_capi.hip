@@ -836,21 +836,24 @@ int bn254_sp1_fixture_parse(const uint8_t* buf, size_t len, int* variant, uint8_
 }
 
 // ---------------------------------------------------------------- device-arithmetic probes (tests)
+struct DevBuf {   // frees on every exit path
+  uint8_t* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
 static int run_probe(size_t in_a, size_t in_b, size_t out_sz, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int device,
                      hipError_t (*launch)(const uint8_t*, const uint8_t*, uint8_t*, size_t)) {
   int rc = check_device(device);
   if (rc) return rc;
   if (n == 0) return BN254_OK;
-  uint8_t *da = nullptr, *db = nullptr, *dout = nullptr;
-  HIPCK(hipMalloc((void**)&da, in_a * n));
-  HIPCK(hipMemcpy(da, a, in_a * n, hipMemcpyHostToDevice));
-  if (in_b && b) { HIPCK(hipMalloc((void**)&db, in_b * n)); HIPCK(hipMemcpy(db, b, in_b * n, hipMemcpyHostToDevice)); }
-  HIPCK(hipMalloc((void**)&dout, out_sz * n));
-  hipError_t e = launch(da, db, dout, n);
+  DevBuf da, db, dout;
+  HIPCK(hipMalloc((void**)&da.p, in_a * n));
+  HIPCK(hipMemcpy(da.p, a, in_a * n, hipMemcpyHostToDevice));
+  if (in_b && b) { HIPCK(hipMalloc((void**)&db.p, in_b * n)); HIPCK(hipMemcpy(db.p, b, in_b * n, hipMemcpyHostToDevice)); }
+  HIPCK(hipMalloc((void**)&dout.p, out_sz * n));
+  hipError_t e = launch(da.p, db.p, dout.p, n);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("probe launch: ") + hipGetErrorString(e));
   HIPCK(hipDeviceSynchronize());
-  HIPCK(hipMemcpy(o, dout, out_sz * n, hipMemcpyDeviceToHost));
-  (void)hipFree(da); if (db) (void)hipFree(db); (void)hipFree(dout);
+  HIPCK(hipMemcpy(o, dout.p, out_sz * n, hipMemcpyDeviceToHost));
   return BN254_OK;
 }
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {

@@ -389,10 +389,13 @@ __device__ __noinline__ G1Proj co_public_input_msm(const Coop& co, const uint8_t
 __global__ void __launch_bounds__(64)
 k_coop_miller_g16(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ kinds, const int32_t* __restrict__ tab0,
                   const int32_t* __restrict__ tab1, const uint8_t* __restrict__ inputs, int n_public, int inputs_match_key,
-                  const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0, int fuse_final_exp) {
+                  const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0, int l_from_ws, int fuse_final_exp) {
   CO_PROLOGUE();
   const int F = CO_SLOT(VE_F);
-  const G1Proj Lp = co_public_input_msm(co, inputs + (size_t)pc * (size_t)n_public * 32, n_public, inputs_match_key != 0, msm_tab, k0);
+  // keys with many public inputs: L was computed by the wide MSM kernels (affine, in the workspace, identity flag in the status byte)
+  G1Proj Lp;
+  if (l_from_ws) { Lp.x = co_ws_ld(ws, n, pc, VE_LX); Lp.y = co_ws_ld(ws, n, pc, VE_LY); Lp.z = (st & BN254_ST_LINF) ? fp_zero() : fp_one(); }
+  else Lp = co_public_input_msm(co, inputs + (size_t)pc * (size_t)n_public * 32, n_public, inputs_match_key != 0, msm_tab, k0);
   const bool l_inf = fp_is_zero(Lp.z);
   const Fp xl = Lp.x, yl = fp_select(l_inf, fp_one(), Lp.y), zl = Lp.z;
   { Fp2 one = c == 0 ? fp2_one() : fp2_zero(); co.put(F, one); }
@@ -470,12 +473,12 @@ hipError_t bn254_coop_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n
   return hipGetLastError();
 }
 hipError_t bn254_coop_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
-                                 int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int fuse_final_exp, hipStream_t s) {
+                                 int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s) {
   const uint8_t* kinds = co_kinds_dev(s);
   if (!kinds) return hipErrorOutOfMemory;
   const size_t lds = (size_t)CO_WAVE_DWORDS * 4;
   (void)hipFuncSetAttribute((const void*)k_coop_miller_g16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_coop_miller_g16, dim3(co_grid(n, 1)), dim3(64), lds, s, ws, (uint32_t)n, (const uint8_t*)status, kinds, tab0, tab1, inputs, n_public,
-                     inputs_match_key, msm_tab, k0, fuse_final_exp);
+                     inputs_match_key, msm_tab, k0, l_from_ws, fuse_final_exp);
   return hipGetLastError();
 }

@@ -805,8 +805,10 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[0], s);
   const bool wide = a.msm_part != nullptr && a.inputs_match_key && a.n_public > G16_WIDE_MSM_MIN_INPUTS;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
-  const bool coop = coop_on && a.n <= COOP_MAX_PROOFS && !wide && a.n_public <= G16_WIDE_MSM_MIN_INPUTS;
-  // cooperative path: the public-input MSM moves into the cooperative kernel (six lanes per proof, L kept projective), so k_g16_prepare stops after C
+  // cooperative path (small batches): the public-input MSM moves into the cooperative kernel (six lanes per proof, L kept projective), so
+  // k_g16_prepare stops after C; keys with many inputs keep their wide MSM kernels and hand L over through the workspace.  A key with more
+  // than G16_WIDE_MSM_MIN_INPUTS inputs but no partial-sum buffer (wrong input count) takes the one-proof-per-lane path.
+  const bool coop = coop_on && a.n <= COOP_MAX_PROOFS && (wide || a.n_public <= G16_WIDE_MSM_MIN_INPUTS);
   BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, (wide || coop) ? 1 : 0);
   if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
   if (wide) {
@@ -819,7 +821,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[1], s);
   if (coop) {
     // small batch: cooperative layout (bn254_coop.hip): public-input MSM, Miller loop of the three pairs and final exponentiation in ONE launch
-    hipError_t e = bn254_coop_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, 1, s);
+    hipError_t e = bn254_coop_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s);
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[2], s); }
     BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)COOP_T_ELEM);
