@@ -179,6 +179,6 @@ def test_no_constant_kzg_batching_scalar_in_the_product():
     """The PlonK path draws its batching scalars from getrandom(2); no literal scalar may come back."""
     import re
     src = open(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", "bn254_capi.hip")).read()
-    body = src[src.index("int bn254_plonk_verify_batch("):src.index("int bn254_plonk_verify(")]
+    body = src[src.index("static int plonk_run("):src.index("int bn254_plonk_verify(const uint8_t* proof")]
     assert "getrandom(" in body and "from_be_reduce(rnd.data()" in body
     assert not re.search(r"lambda\s*=\s*fr_ctx\(\)\.from_u64", src)
