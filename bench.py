@@ -162,9 +162,11 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         t_b = v.timer()
         return full, (t_a, t_b)
 
+    grouped = dist.is_available() and dist.is_initialized()
+
     def fence():
         v.sync()
-        if world > 1:
+        if grouped:
             dist.barrier()
         v.sync()
 
@@ -196,7 +198,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
             phase_ms.setdefault(k, []).append(x)
     fence()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=full.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -366,7 +368,10 @@ def main(argv=None):
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run the RCCL group is formed even for one rank, so that the collective path (all_gather of the status bytes,
+    # max-reduction of the elapsed time, barriers) is the one that runs
+    use_dist = world > 1 or "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     pkg = importlib.import_module("snark-bn254-verifier_amd")
@@ -390,7 +395,7 @@ def main(argv=None):
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = _cpu_baseline(args, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

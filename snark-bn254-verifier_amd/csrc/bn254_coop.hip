@@ -23,6 +23,7 @@
 
 namespace bn254 {
 
+static_assert(COOP_T_ELEM == VE_S2, "COOP_T_ELEM must name a workspace slot that neither VE_T nor the result slot VE_S0 overlays");
 #define CO_STRIDE 20
 // slots: the Fp12 elements of bn254_vm.h (VE_F, VE_S0.., VE_P3.., 12 Fp apart from VE_F on) + scratch images
 #define CO_SLOT(e) (((e) - VE_F) / 12)   // VE_F 0, VE_S0 1, S1 2, S2 3, S3 4, S4 5, P3 6, (TMPA/TMPB 7), P5 8, P7 9

@@ -57,7 +57,7 @@ struct G16LaunchArgs {
 // kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
 enum {
   KID_PREPARE, KID_SUBGROUP, KID_VM_INIT, KID_F12_SQR, KID_MUL_LINE_FIXED, KID_F12_MUL,
-  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_F12_COPY, KID_CYCLO_SQR_N, KID_MILLER_DBL_VAR, KID_MILLER_ADD_VAR, KID_MSM_PARTIAL, KID_MSM_REDUCE, KID_MUL_LINE_FIXED2, KID_MILLER_SQR_DBL_VAR, KID_MILLER_STEP_DBL, KID_MILLER_STEP_ADD, KID_COUNT
+  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_F12_COPY, KID_CYCLO_SQR_N, KID_MILLER_DBL_VAR, KID_MILLER_ADD_VAR, KID_MSM_PARTIAL, KID_MSM_REDUCE, KID_MUL_LINE_FIXED2, KID_MILLER_SQR_DBL_VAR, KID_MILLER_STEP_DBL, KID_MILLER_STEP_ADD, KID_COOP_G16, KID_COUNT
 };
 extern const char* const bn254_kernel_kind_names[KID_COUNT];
 // optional per-launch timing: every launch whose kind is in `mask` is bracketed by two events from the pool

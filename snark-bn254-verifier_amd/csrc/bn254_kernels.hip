@@ -751,7 +751,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var", "k_miller_step_dbl", "k_miller_step_add"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var", "k_miller_step_dbl", "k_miller_step_add", "k_coop_miller_g16"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -821,7 +821,8 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (ev) (void)hipEventRecord(ev[1], s);
   if (coop) {
     // small batch: cooperative layout (bn254_coop.hip): public-input MSM, Miller loop of the three pairs and final exponentiation in ONE launch
-    hipError_t e = bn254_coop_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s);
+    hipError_t e;
+    { ProfScope ps_(prof, KID_COOP_G16, s); e = bn254_coop_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s); }
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[2], s); }
     BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)COOP_T_ELEM);

@@ -14,7 +14,7 @@ def shard_bounds(n, world, rank):
 
 def gather_status(local_status, n, world):
     """local_status: uint8 tensor of this rank's shard (device of the backend). Returns the full n-byte vector on every rank."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local_status
     cap = (n + world - 1) // world
     padded = torch.zeros(cap, dtype=torch.uint8, device=local_status.device)
