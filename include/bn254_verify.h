@@ -70,7 +70,7 @@ enum { BN254_VK_REFERENCE = 0, BN254_VK_GNARK = 1 };
  *     typed API a range-checked Fr would fail at construction, before verify() is entered, so the strict error takes precedence
  *     over every proof error.
  * BN254_FLAG_RLC  random-linear-combination batch mode (the reference batches the same way inside KZG,
- *     plonk/kzg.rs:149-187): proofs are checked in groups with fresh 128-bit random weights r_i,
+ *     plonk/kzg.rs:149-187): proofs are checked in groups with fresh random weights r_i (128 bits of entropy each),
  *         prod_i e(r_i A_i, B_i) * e(sum r_i L_i, gamma') * e(sum r_i C_i, delta') * e(-(sum r_i) alpha, beta') == 1,
  *     one variable-argument Miller loop per proof and one final exponentiation per group; proofs of a group that fails are
  *     re-verified by the exact path, so the status bytes are those of the exact path except with probability <= 2^-120 per batch

@@ -2,7 +2,7 @@
 //
 // Exact check per proof i (groth16/verify.rs:73-77, key-side G2 arguments g', d', b' as prepared by bn254_host.hpp):
 //     e(A_i, B_i) e(L_i, g') e(C_i, d') == e(alpha, b')
-// Batched with independent random 128-bit weights r_i (the reference batches its KZG openings the same way, plonk/kzg.rs:149-187):
+// Batched with independent random weights r_i of 128 bits of entropy (GLV form, below) (the reference batches its KZG openings the same way, plonk/kzg.rs:149-187):
 //     prod_i e(r_i A_i, B_i)  *  e(sum_i r_i L_i, g')  *  e(sum_i r_i C_i, d')  *  e((sum_i r_i)(-alpha), b')  ==  1
 // and, because L_i = K_0 + sum_j x_ij K_j,   sum_i r_i L_i = (sum_i r_i) K_0 + sum_j (sum_i r_i x_ij) K_j :  the public-input MSM is
 // done ONCE PER GROUP with scalars accumulated in Fr.  Per proof that leaves: two 128-bit G1 scalar multiplications (A, C), one
@@ -119,21 +119,44 @@ BN_HD Fr8 fr8_from_slot(const Fp& a) {
   return r;
 }
 
-// ---- k * P for a 128-bit k: fixed 2-bit windows over the complete formulas (data-independent control flow) -------------------------------------------
-BN_HD G1Proj g1_mul_u128(const G1Aff& P, const uint32_t k[4]) {
-  G1Proj P1 = g1_from_affine(P), P2 = g1_dbl(P1), P3 = g1_add_mixed(P2, P);
+// ---- the weights and their scalar multiplications: GLV form ------------------------------------------------------------------------------------------------
+// BN254's G1 has the endomorphism phi(x, y) = (beta x, y) = [lambda](x, y), beta^3 = 1 in Fp, lambda^2 + lambda + 1 = 0 in Fr.  A weight is
+//     r_i = k1 + k2 * lambda  (mod r),   k1, k2 uniform 64-bit values  (the 128 bits of the ChaCha20 block),
+// so r_i P = k1 P + k2 phi(P) costs 64 doublings and 64 additions instead of 128 + 64.  The map (k1, k2) -> r_i is injective (a collision would
+// be a vector of the GLV lattice shorter than 2^65, and its shortest vectors are ~ 2^127 long), so the weight takes 2^128 distinct values mod r:
+// a forged proof passes its group's check with probability <= 2^-128, as with a plain 128-bit weight.
+BN_FP_CONST(BN_GLV_BETA, {171145621, -175301341, -123954279, -218476986, -127948067, 24572270, 250450874, -198635200, 789247});   /* beta, Montgomery form */
+BN_HD uint32_t bn_glv_lambda_word(int i) {  // lambda = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+  switch (i) {
+    case 0: return 0xb99c90ddu; case 1: return 0x8b17ea66u; case 2: return 0x8d8daaa7u; case 3: return 0x5bfc4108u;
+    case 4: return 0x41a91758u; case 5: return 0xb3c4d79du; default: return 0u;
+  }
+}
+// the weight as an element of Fr (canonical words): k1 + k2 lambda mod r
+BN_HD Fr8 rlc_weight(const uint32_t k[4]) {
+  Fr8 k2 = fr8_zero(), lam, k1 = fr8_zero();
+  k1.w[0] = k[0]; k1.w[1] = k[1]; k2.w[0] = k[2]; k2.w[1] = k[3];
+#pragma unroll
+  for (int i = 0; i < 8; i++) lam.w[i] = bn_glv_lambda_word(i);
+  return fr8_add(fr8_mul_plain(k2, lam), k1);
+}
+// (k1 + k2 lambda) P: joint double-and-add over the 64 bit positions with the table {P, phi(P), P + phi(P)}, complete formulas, data-independent
+// control flow
+BN_HD G1Proj g1_mul_glv(const G1Aff& P, const uint32_t k[4]) {
+  G1Aff Pe; Pe.x = fp_mul(P.x, fp_from_limbs(BN_GLV_BETA)); Pe.y = P.y;
+  const G1Proj T1 = g1_from_affine(P), T2 = g1_from_affine(Pe), T3 = g1_add_mixed(T1, Pe);
   G1Proj acc = g1_identity();
-  uint32_t sw[4] = {k[0], k[1], k[2], k[3]};
+  uint32_t a0 = k[0], a1 = k[1], b0 = k[2], b1 = k[3];
   for (int b = 0; b < 64; b++) {
-    const uint32_t dig = sw[3] >> 30;
-    sw[3] = (sw[3] << 2) | (sw[2] >> 30); sw[2] = (sw[2] << 2) | (sw[1] >> 30); sw[1] = (sw[1] << 2) | (sw[0] >> 30); sw[0] <<= 2;
-    acc = g1_dbl(g1_dbl(acc));
+    const uint32_t d1 = a1 >> 31, d2 = b1 >> 31;
+    a1 = (a1 << 1) | (a0 >> 31); a0 <<= 1; b1 = (b1 << 1) | (b0 >> 31); b0 <<= 1;
+    acc = g1_dbl(acc);
     G1Proj q;
-    q.x = fp_select(dig == 3, P3.x, fp_select(dig == 2, P2.x, P1.x));
-    q.y = fp_select(dig == 3, P3.y, fp_select(dig == 2, P2.y, P1.y));
-    q.z = fp_select(dig == 3, P3.z, fp_select(dig == 2, P2.z, P1.z));
+    q.x = fp_select(d2 != 0, fp_select(d1 != 0, T3.x, T2.x), T1.x);
+    q.y = fp_select(d2 != 0, fp_select(d1 != 0, T3.y, T2.y), T1.y);
+    q.z = fp_select(d2 != 0, fp_select(d1 != 0, T3.z, T2.z), T1.z);
     G1Proj c = g1_add(acc, q);
-    const bool take = dig != 0;
+    const bool take = (d1 | d2) != 0;
     acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
   }
   return acc;
@@ -145,16 +168,15 @@ template <class W, class LX>
 BN_HD void vm_rlc_scale(W& w, const uint32_t r[4], int n_public, const LX& load_input) {
   {
     G1Aff A; A.x = w.ld(VE_AX); A.y = w.ld(VE_AY);
-    G1Aff Ar = g1_to_affine(g1_mul_u128(A, r));   // A has order r (on the curve, cofactor 1) and 0 < r_i < 2^128: never the identity
+    G1Aff Ar = g1_to_affine(g1_mul_glv(A, r));    // A has order r (on the curve, cofactor 1): the identity only for the weight 0 (probability 2^-128)
     w.st(VE_AX, Ar.x); w.st(VE_AY, Ar.y);
   }
   {
     G1Aff Cc; Cc.x = w.ld(VE_CX); Cc.y = w.ld(VE_CY);
-    G1Proj Cr = g1_mul_u128(Cc, r);
+    G1Proj Cr = g1_mul_glv(Cc, r);
     w.st(RLC_C, fp_reduce(Cr.x)); w.st(RLC_C + 1, fp_reduce(Cr.y)); w.st(RLC_C + 2, fp_reduce(Cr.z));
   }
-  Fr8 rr = fr8_zero();
-  rr.w[0] = r[0]; rr.w[1] = r[1]; rr.w[2] = r[2]; rr.w[3] = r[3];
+  const Fr8 rr = rlc_weight(r);
   w.st(RLC_T, fr8_to_slot(rr));
   for (int j = 0; j < n_public; j++) {
     Fr8 x; load_input(j, x.w);

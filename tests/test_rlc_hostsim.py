@@ -65,17 +65,25 @@ def test_fr_products_and_sums(hostsim):
     assert int.from_bytes(bytes(o), "big") == R - 2
 
 
-def test_g1_mul_u128(hostsim, O):
+LAMBDA = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+
+
+def test_glv_weights(hostsim, O):
+    """r_i = k1 + k2 lambda: the Fr value the Fr products use, and (k1 + k2 lambda) P by the joint double-and-add over {P, phi(P), P + phi(P)}."""
+    assert (LAMBDA * LAMBDA + LAMBDA + 1) % R == 0
     rng = random.Random(7)
     g = O.g1_gen()
-    o = (C.c_uint8 * 64)()
+    o = (C.c_uint8 * 64)(); wv = (C.c_uint8 * 32)()
     pts = [g, O.g1_mul(g, rng.randrange(1, R))]
     for p in pts:
-        for k in (1, 2, 3, 4, (1 << 128) - 1, 1 << 127, rng.randrange(1 << 128), rng.randrange(1 << 128)):
-            hostsim.hs_g1_mul_u128(o, p, k.to_bytes(16, "big"))
-            assert bytes(o) == O.g1_mul(p, k)
-    hostsim.hs_g1_mul_u128(o, g, (0).to_bytes(16, "big"))
-    assert bytes(o) == bytes(64)
+        for k1, k2 in ((1, 0), (0, 1), (1, 1), (2, 3), ((1 << 64) - 1, (1 << 64) - 1), (1 << 63, 0), (0, 1 << 63),
+                       (rng.randrange(1 << 64), rng.randrange(1 << 64)), (rng.randrange(1 << 64), rng.randrange(1 << 64))):
+            hostsim.hs_g1_mul_glv(o, wv, p, k2.to_bytes(8, "big") + k1.to_bytes(8, "big"))
+            w = (k1 + k2 * LAMBDA) % R
+            assert int.from_bytes(bytes(wv), "big") == w
+            assert bytes(o) == O.g1_mul(p, w)
+    hostsim.hs_g1_mul_glv(o, wv, g, bytes(16))
+    assert bytes(o) == bytes(64) and bytes(wv) == bytes(32)
 
 
 def _neg_g2(q):
