@@ -73,7 +73,7 @@ __constant__ int8_t CO_SQ_A[6][4] = {{0, 1, 2, 3}, {0, 2, 3, 0}, {0, 1, 3, 4}, {
 __constant__ int8_t CO_SQ_B[6][4] = {{0, 5, 4, 3}, {1, 5, 4, 0}, {2, 1, 5, 4}, {3, 2, 5, 0}, {4, 3, 2, 5}, {5, 4, 3, 0}};
 __constant__ int8_t CO_SQ_X[6][4] = {{0, 1, 1, 1}, {0, 1, 1, 0}, {0, 0, 1, 1}, {0, 0, 1, 0}, {0, 0, 0, 1}, {0, 0, 0, 0}};
 __constant__ int8_t CO_SQ_W[6][4] = {{1, 2, 2, 1}, {2, 2, 2, 0}, {2, 1, 2, 1}, {2, 2, 2, 0}, {2, 2, 1, 1}, {2, 2, 2, 0}};
-__device__ __noinline__ void co_sqr(const Coop& co, int s) {
+__device__ __forceinline__ void co_sqr(const Coop& co, int s) {
   const Fp2 k = co.own(s);
   co.put(CO_X, fp2_mul_xi(k));
   const uint32_t c = co.c;
@@ -93,13 +93,13 @@ __device__ __forceinline__ void co_line_operands(const Coop& co, int s, const Fp
   y1 = co.coef(c >= 1 ? s : CO_X, (c + 5) % 6);
   y3 = co.coef(c >= 3 ? s : CO_X, (c + 3) % 6);
 }
-__device__ __noinline__ void co_mul_line_fp(const Coop& co, int s, const Fp& d0, const Fp2& d3, const Fp2& d4, bool keep) {
+__device__ __forceinline__ void co_mul_line_fp(const Coop& co, int s, const Fp& d0, const Fp2& d3, const Fp2& d4, bool keep) {
   const Fp2 k = co.own(s);
   Fp2 y1, y3;
   co_line_operands(co, s, k, y1, y3);
   co.put(s, fp2_select(keep, k, fp2_dotk(kfp(k, d0), kp(d3, y1), kp(d4, y3))));
 }
-__device__ __noinline__ void co_mul_line_fp2(const Coop& co, int s, const Fp2& d0, const Fp2& d3, const Fp2& d4) {
+__device__ __forceinline__ void co_mul_line_fp2(const Coop& co, int s, const Fp2& d0, const Fp2& d3, const Fp2& d4) {
   const Fp2 k = co.own(s);
   Fp2 y1, y3;
   co_line_operands(co, s, k, y1, y3);
@@ -282,7 +282,7 @@ __device__ __forceinline__ Fp2 co_sel6(uint32_t c, const Fp2& v0, const Fp2& v1,
 __device__ __forceinline__ Fp2 co_fp_as_fp2(const Fp& a) { Fp2 r; r.c0 = a; r.c1 = fp_zero(); return r; }
 struct CoLine { Fp2 d0, d3, d4, s1, s2, cz; };   // the variable pair's line at A; m1 * X_L, m2 * x_C and c1 * Z_L of the two table-driven pairs (L projective)
 // doubling step: T <- 2 T (bn254_curve.h::g2_double_step), line evaluated at A = (xa, ya); m1 xl, m2 xc in the idle lanes
-__device__ __noinline__ void co_g2_double(const Coop& co, G2Proj& t, const Fp& xa, const Fp& ya, const Fp2& m1, const Fp& xl, const Fp2& m2, const Fp& xc, const Fp2& c1,
+__device__ __forceinline__ void co_g2_double(const Coop& co, G2Proj& t, const Fp& xa, const Fp& ya, const Fp2& m1, const Fp& xl, const Fp2& m2, const Fp& xc, const Fp2& c1,
                                           const Fp& zl, CoLine& out) {
   const uint32_t c = co.c;
   const Fp2 yz = fp2_add(t.y, t.z);
@@ -316,7 +316,7 @@ __device__ __noinline__ void co_g2_double(const Coop& co, G2Proj& t, const Fp& x
   out.d4 = fp2_sub(E, B);
 }
 // addition step: T <- T + Q (bn254_curve.h::g2_add_step), Q = (qx, qy) affine
-__device__ __noinline__ void co_g2_add(const Coop& co, G2Proj& t, const Fp2& qx, const Fp2& qy, const Fp& xa, const Fp& ya, const Fp2& m1, const Fp& xl, const Fp2& m2,
+__device__ __forceinline__ void co_g2_add(const Coop& co, G2Proj& t, const Fp2& qx, const Fp2& qy, const Fp& xa, const Fp& ya, const Fp2& m1, const Fp& xl, const Fp2& m2,
                                        const Fp& xc, const Fp2& c1, const Fp& zl, CoLine& out) {
   const uint32_t c = co.c;
   {  // round 1: yQ Z, xQ Z, -, -, -, m1 xl
