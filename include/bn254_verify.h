@@ -191,6 +191,9 @@ int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, siz
 int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device);                       /* 1 = in G2 (gnark's psi relation, one kernel) */
 int bn254_dbg_g2_subgroup_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* out_flags, size_t n, int device); /* 1 = in G2: the product's test, from the Miller loop's final point (g1: any G1 points) */
 
+/* host-only probe of the GLV scalar decomposition the PlonK MSMs use: k = (-1)^neg1 k1 + (-1)^neg2 k2 lambda (mod r), k1, k2 < 2^127 */
+int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2);
+
 const char* bn254_status_string(int status_byte);
 const char* bn254_last_error(void);
 const char* bn254_version(void);

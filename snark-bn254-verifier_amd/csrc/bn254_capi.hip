@@ -647,6 +647,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   auto t0 = now();
   std::vector<PlonkWork> work(m);
   memset(c.h_terms, 0, m * (size_t)T1 * sizeof(MsmTerm));
+  memset(c.h_flags, 0, m * (size_t)T1);
   // The KZG batching scalar of every proof: fresh, uniform and unpredictable to the prover, as the reference draws it
   // (Fr::random(&mut OsRng), plonk/kzg.rs:149-154).  It MUST be secret until the proof is fixed: the two opening quotients are bound by
   // no transcript, so a prover who knows lambda can shift them by (lambda D, -D) and cancel a wrong evaluation
@@ -660,12 +661,12 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   // ---- stage 1 on the host threads
   plonk_parallel(m, host_threads, [&](size_t i) {
     work[i].lambda = fr_ctx().from_be_reduce(rnd.data() + 48 * i, 48);
-    work[i].status = plonk_stage1(key, proofs + i * proof_stride, proof_stride, public_inputs + i * n_public * 32, n_public, work[i], &c.h_terms[i * T1]);
+    work[i].status = plonk_stage1(key, proofs + i * proof_stride, proof_stride, public_inputs + i * n_public * 32, n_public, work[i], &c.h_terms[i * T1], &c.h_flags[i * T1]);
   });
   auto t1_ = now();
   // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
-  HIPCK(hipMemsetAsync(c.flags, 0, m * (size_t)T1, c.stream));
+  HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)T1, hipMemcpyHostToDevice, c.stream));   // GLV signs (bn254_plonk.hpp::put_term)
   hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipMemcpyAsync(c.h_words, c.words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
@@ -895,6 +896,16 @@ int bn254_dbg_g2_subgroup_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* out
 }
 int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device) {
   return run_probe(128, 0, 1, g2, nullptr, out_flags, n, device, [](const uint8_t* x, const uint8_t*, uint8_t* o, size_t m) { return bn254_launch_dbg_g2_subgroup(x, o, m, nullptr); });
+}
+
+// GLV decomposition probe (host only): k (32 bytes big-endian, any value: reduced mod r) -> |k1|, |k2| (16 bytes big-endian each) and signs
+int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2) {
+  if (!k32 || !k1_16 || !k2_16 || !neg1 || !neg2) return set_err(BN254_E_BAD_ARG, "bad argument");
+  const FrCtx& F = fr_ctx();
+  Glv g = glv_decompose(F.to_canon(F.from_be32(k32)));
+  for (int i = 0; i < 8; i++) { k1_16[i] = (uint8_t)(g.k1[1] >> (56 - 8 * i)); k1_16[8 + i] = (uint8_t)(g.k1[0] >> (56 - 8 * i)); k2_16[i] = (uint8_t)(g.k2[1] >> (56 - 8 * i)); k2_16[8 + i] = (uint8_t)(g.k2[0] >> (56 - 8 * i)); }
+  *neg1 = g.neg1 ? 1 : 0; *neg2 = g.neg2 ? 1 : 0;
+  return BN254_OK;
 }
 
 // ---------------------------------------------------------------- synthetic workload generator

@@ -411,9 +411,9 @@ k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32
 // =====================================================================================================================
 // variable-base G1 multi-scalar multiplication (PlonK: linearised-polynomial digest, folded digests and quotients)
 // =====================================================================================================================
-// lane g = t * n + i: term t of item i.  terms[g * 26]: 18 digits of the affine point, 8 little-endian words of the scalar
-// (canonical, < r).  Fixed 2-bit windows with the complete formulas: data-independent control, no special cases.
-// flags[g] != 0: the point is the identity (the term contributes nothing).  Partial results: part[(t * 27 + k) * n + i].
+// lane g = t * n + i: term t of item i.  terms[g * 26]: 18 digits of the affine point, 8 little-endian words of the GLV-decomposed scalar.
+// Joint double-and-add with the complete formulas (bn254_rlc.h::g1_mul_glv_w): data-independent control, no special cases.
+// flags[g] bit 0: the point is the identity (the term contributes nothing), bits 1 / 2: signs.  Partial results: part[(t * 27 + k) * n + i].
 __global__ void __launch_bounds__(256, 2)
 k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -424,31 +424,17 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { P.x.v[l] = e[l]; P.y.v[l] = e[BN_NL + l]; }
   BN_SETB(P.x, 1.0, 0.5); BN_SETB(P.y, 1.0, 0.5);
-  uint32_t sw[8];
+  // the scalar arrives GLV-decomposed (bn254_plonk.hpp::glv_decompose): k = +-k1 +- k2 lambda with 128-bit magnitudes k1 (words 0..3) and k2
+  // (words 4..7), signs in the flag byte (bit 1, bit 2; bit 0: the point is the identity): 128 joint double-and-add steps instead of 256
+  uint32_t k1[4], k2[4];
 #pragma unroll
-  for (int k = 0; k < 8; k++) sw[k] = (uint32_t)e[18 + k];
-  if (flags[(size_t)i * n_terms + t]) {
+  for (int k = 0; k < 4; k++) { k1[k] = (uint32_t)e[18 + k]; k2[k] = (uint32_t)e[22 + k]; }
+  const uint8_t fl = flags[(size_t)i * n_terms + t];
+  if (fl & 1) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) sw[k] = 0;
+    for (int k = 0; k < 4; k++) { k1[k] = 0; k2[k] = 0; }
   }
-  // 2-bit fixed windows, most significant first: table {P, 2P, 3P} in registers, per window two doublings and one complete
-  // addition of the selected entry (the result is kept only for a non-zero digit): 28 field products per 2 bits instead of 38
-  G1Proj P1 = g1_from_affine(P), P2 = g1_dbl(P1), P3 = g1_add_mixed(P2, P);
-  G1Proj acc = g1_identity();
-  for (int b = 0; b < 128; b++) {
-    const uint32_t dig = sw[7] >> 30;
-#pragma unroll
-    for (int k = 7; k > 0; k--) sw[k] = (sw[k] << 2) | (sw[k - 1] >> 30);
-    sw[0] <<= 2;
-    acc = g1_dbl(g1_dbl(acc));
-    G1Proj q;
-    q.x = fp_select(dig == 3, P3.x, fp_select(dig == 2, P2.x, P1.x));
-    q.y = fp_select(dig == 3, P3.y, fp_select(dig == 2, P2.y, P1.y));
-    q.z = fp_select(dig == 3, P3.z, fp_select(dig == 2, P2.z, P1.z));
-    G1Proj c = g1_add(acc, q);
-    const bool take = dig != 0;
-    acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
-  }
+  G1Proj acc = g1_mul_glv_w<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0);
   int32_t* o = part + (size_t)t * 27 * n + i;
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }

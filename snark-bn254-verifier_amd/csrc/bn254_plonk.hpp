@@ -254,10 +254,63 @@ inline FrM bsb22_hash_to_field(const uint8_t g1_uncompressed[64]) {
 }
 
 // ---------------------------------------------------------------- per-proof state carried between the two host stages
-struct MsmTerm { int32_t pt[18]; uint32_t k[8]; };   // affine point (Montgomery digits) and canonical scalar: what k_g1_scalar_mul reads
+struct MsmTerm { int32_t pt[18]; uint32_t k[8]; };   // affine point (Montgomery digits) and the GLV halves |k1|, |k2| of the scalar: what k_g1_scalar_mul reads
 static_assert(sizeof(MsmTerm) == 104, "term layout");
-inline void put_term(MsmTerm& t, const G1Aff& p, const FrM& k) {
-  fp_to_limbs(t.pt, p.x); fp_to_limbs(t.pt + BN_NL, p.y); fr_ctx().to_words(t.k, k);
+// GLV decomposition of a scalar for G1: k = s1 k1 + s2 k2 lambda (mod r), k1, k2 < 2^127, lambda the eigenvalue of phi(x, y) = (beta x, y)
+// (bn254_rlc.h).  Lattice basis (a1, b1), (a2, b2) of {(x, y): x + y lambda = 0 mod r} from the extended Euclidean algorithm on (r, lambda):
+//   a1 = b2 = 0x89d3256894d213e3,  b1 = -0x6f4d8248eeb859fc8211bbeb7d4f1128,  a2 = 0x6f4d8248eeb859fd0be4e1541221250b,  a1 b2 - a2 b1 = r
+// c1 = floor(k g1 / 2^256), c2 = floor(k g2 / 2^256) with g1 = floor(2^256 b2 / r), g2 = floor(-2^256 b1 / r);  k1 = k - c1 a1 - c2 a2,
+// k2 = -c1 b1 - c2 b2.  (tests/test_capi_cpu.py::test_glv_decomposition checks the identity and the bounds through bn254_dbg_glv_decompose.)
+struct Glv { uint64_t k1[2], k2[2]; bool neg1, neg2; };
+inline Glv glv_decompose(const FrM& kc /* canonical, < r */) {
+  typedef unsigned __int128 u128;
+  const uint64_t A1 = 0x89d3256894d213e3ull;
+  const uint64_t B1[2] = {0x8211bbeb7d4f1128ull, 0x6f4d8248eeb859fcull};        // |b1|
+  const uint64_t A2[2] = {0x0be4e1541221250bull, 0x6f4d8248eeb859fdull};
+  const uint64_t G1[2] = {0xd91d232ec7e0b3d7ull, 0x2ull};
+  const uint64_t G2[3] = {0x7a7bd9d4391eb18dull, 0x4ccef014a773d2cfull, 0x2ull};
+  auto mul_hi256 = [&](const uint64_t* g, int gn, uint64_t out[3]) {   // floor(k * g / 2^256), at most 3 limbs
+    uint64_t prod[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      u128 c = 0;
+      for (int j = 0; j < gn; j++) { c += (u128)kc.l[i] * g[j] + prod[i + j]; prod[i + j] = (uint64_t)c; c >>= 64; }
+      prod[i + gn] += (uint64_t)c;
+    }
+    out[0] = prod[4]; out[1] = prod[5]; out[2] = prod[6];
+  };
+  uint64_t c1[3], c2[3];
+  mul_hi256(G1, 2, c1); mul_hi256(G2, 3, c2);     // c1 < 2^65, c2 < 2^129: the third limbs are 0 or tiny; products below keep 5 limbs
+  // 5-limb two's-complement accumulators
+  auto mac = [](uint64_t acc[5], const uint64_t* x, int xn, const uint64_t* y, int yn, bool subtract) {
+    uint64_t p[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < xn; i++) {
+      u128 c = 0;
+      for (int j = 0; j < yn && i + j < 5; j++) { c += (u128)x[i] * y[j] + p[i + j]; p[i + j] = (uint64_t)c; c >>= 64; }
+      if (i + yn < 5) p[i + yn] += (uint64_t)c;
+    }
+    if (subtract) { uint64_t br = 0; for (int i = 0; i < 5; i++) { u128 d = (u128)acc[i] - p[i] - br; acc[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
+    else { u128 c = 0; for (int i = 0; i < 5; i++) { c += (u128)acc[i] + p[i]; acc[i] = (uint64_t)c; c >>= 64; } }
+  };
+  uint64_t k1[5] = {kc.l[0], kc.l[1], kc.l[2], kc.l[3], 0}, k2[5] = {0, 0, 0, 0, 0};
+  const uint64_t a1[1] = {A1};
+  mac(k1, c1, 3, a1, 1, true); mac(k1, c2, 3, A2, 2, true);
+  mac(k2, c1, 3, B1, 2, false); mac(k2, c2, 3, a1, 1, true);        // -c1 b1 = +c1 |b1|;  -c2 b2 with b2 = a1
+  auto finish = [](uint64_t v[5], uint64_t out[2], bool& neg) {
+    neg = (v[4] >> 63) != 0;
+    if (neg) { u128 c = 1; for (int i = 0; i < 5; i++) { c += (u128)(~v[i]); v[i] = (uint64_t)c; c >>= 64; } }
+    out[0] = v[0]; out[1] = v[1];
+  };
+  Glv g;
+  finish(k1, g.k1, g.neg1); finish(k2, g.k2, g.neg2);
+  return g;
+}
+// flag: bit 1 / bit 2 = sign of k1 / k2 (bit 0, set by the caller, marks an identity point)
+inline void put_term(MsmTerm& t, const G1Aff& p, const FrM& k, uint8_t* flag) {
+  fp_to_limbs(t.pt, p.x); fp_to_limbs(t.pt + BN_NL, p.y);
+  const Glv g = glv_decompose(fr_ctx().to_canon(k));
+  t.k[0] = (uint32_t)g.k1[0]; t.k[1] = (uint32_t)(g.k1[0] >> 32); t.k[2] = (uint32_t)g.k1[1]; t.k[3] = (uint32_t)(g.k1[1] >> 32);
+  t.k[4] = (uint32_t)g.k2[0]; t.k[5] = (uint32_t)(g.k2[0] >> 32); t.k[6] = (uint32_t)g.k2[1]; t.k[7] = (uint32_t)(g.k2[1] >> 32);
+  *flag = (uint8_t)((*flag & 1) | (g.neg1 ? 2 : 0) | (g.neg2 ? 4 : 0));
 }
 struct PlonkWork {
   int status;                 // PL_OK while the proof is still alive, else the final status
@@ -272,7 +325,7 @@ inline int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }
 // Stage 1 (plonk/verify.rs:46-284): everything up to the scalars of the linearised polynomial digest.  On a failed check the
 // proof's final status is returned and its terms are left zeroed.
 inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
-                        PlonkWork& wk, MsmTerm* terms /* plonk_stage1_terms(vk) */) {
+                        PlonkWork& wk, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */) {
   const FrCtx& F = fr_ctx();
   PlonkProof& pr = wk.pr;
   int st = parse_plonk_proof(pr, proof, proof_len);                       // lib.rs:70
@@ -375,10 +428,11 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
   FrM zh = F.neg(zh_zeta);
   // verify.rs:252-284: the MSM of the linearised polynomial digest
   int np = 0;
-  for (uint32_t i = 0; i < pr.n_bsb; i++) put_term(terms[np++], pr.bsb[i], pr.claimed[6 + i]);
-  put_term(terms[np++], vk.ql, l); put_term(terms[np++], vk.qr, r); put_term(terms[np++], vk.qm, rl); put_term(terms[np++], vk.qo, o);
-  put_term(terms[np++], vk.qk, one); put_term(terms[np++], vk.s[2], _s1); put_term(terms[np++], pr.z, coeff_z);
-  put_term(terms[np++], pr.h[0], zh); put_term(terms[np++], pr.h[1], zn2); put_term(terms[np++], pr.h[2], zn2sq);
+  auto put = [&](const G1Aff& p, const FrM& k) { tflags[np] = 0; put_term(terms[np], p, k, &tflags[np]); np++; };
+  for (uint32_t i = 0; i < pr.n_bsb; i++) put(pr.bsb[i], pr.claimed[6 + i]);
+  put(vk.ql, l); put(vk.qr, r); put(vk.qm, rl); put(vk.qo, o);
+  put(vk.qk, one); put(vk.s[2], _s1); put(pr.z, coeff_z);
+  put(pr.h[0], zh); put(pr.h[1], zn2); put(pr.h[2], zn2sq);
   return PL_OK;
 }
 
@@ -386,7 +440,7 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
 // MSM result as 16 little-endian words (x | y) and its identity flag.  Writes the terms of
 //   P0 = sum_i gamma^i D_i + lambda Z - fe G_kzg + zeta H_batch + lambda zeta omega H_zs      (plonk_stage2_terms(vk) terms)
 //   P1 = -(H_batch + lambda H_zs)                                                              (2 terms)
-// for the check e(P0, g2[0]) e(P1, g2[1]) == 1 (kzg.rs:175-187).
+// for the check e(P0, g2[0]) e(P1, g2[1]) == 1 (kzg.rs:175-187).  t1 must be t0 + plonk_stage2_terms(vk): one flag array (t0_inf) covers both.
 inline void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWork& wk, const uint32_t lin_words[16], bool lin_inf,
                          MsmTerm* t0, uint8_t* t0_inf, MsmTerm* t1) {
   const FrCtx& F = fr_ctx();
@@ -418,17 +472,19 @@ inline void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWo
   FrM fe = F.add(folded_eval, F.mul(pr.zs_value, lam));
   FrM shifted = F.mul(wk.zeta, vk.generator);
   int np = 0;
-  memset(t0_inf, 0, (size_t)plonk_stage2_terms(vk));
-  t0_inf[np] = lin_inf ? 1 : 0; put_term(t0[np++], lin, gi[0]);
-  put_term(t0[np++], pr.lro[0], gi[1]); put_term(t0[np++], pr.lro[1], gi[2]); put_term(t0[np++], pr.lro[2], gi[3]);
-  put_term(t0[np++], vk.s[0], gi[4]); put_term(t0[np++], vk.s[1], gi[5]);
-  for (uint32_t i = 0; i < vk.n_qcp; i++) put_term(t0[np++], vk.qcp[i], gi[6 + i]);
-  put_term(t0[np++], pr.z, lam);
-  put_term(t0[np++], vk.kzg_g1, F.neg(fe));
-  put_term(t0[np++], pr.batch_h, wk.zeta);
-  put_term(t0[np++], pr.zs_h, F.mul(lam, shifted));
-  put_term(t1[0], pr.batch_h, F.neg(F.one));
-  put_term(t1[1], pr.zs_h, F.neg(lam));
+  memset(t0_inf, 0, (size_t)plonk_stage2_terms(vk) + 2);
+  auto put = [&](const G1Aff& p, const FrM& k) { put_term(t0[np], p, k, &t0_inf[np]); np++; };
+  t0_inf[np] = lin_inf ? 1 : 0; put(lin, gi[0]);
+  put(pr.lro[0], gi[1]); put(pr.lro[1], gi[2]); put(pr.lro[2], gi[3]);
+  put(vk.s[0], gi[4]); put(vk.s[1], gi[5]);
+  for (uint32_t i = 0; i < vk.n_qcp; i++) put(vk.qcp[i], gi[6 + i]);
+  put(pr.z, lam);
+  put(vk.kzg_g1, F.neg(fe));
+  put(pr.batch_h, wk.zeta);
+  put(pr.zs_h, F.mul(lam, shifted));
+  // P1 = -(H_batch + lambda H_zs): the two terms follow P0's (t1 = t0 + plonk_stage2_terms(vk), their flags likewise)
+  put_term(t1[0], pr.batch_h, F.neg(F.one), &t0_inf[np]);
+  put_term(t1[1], pr.zs_h, F.neg(lam), &t0_inf[np + 1]);
 }
 
 }  // namespace bn254host

@@ -140,16 +140,24 @@ BN_HD Fr8 rlc_weight(const uint32_t k[4]) {
   for (int i = 0; i < 8; i++) lam.w[i] = bn_glv_lambda_word(i);
   return fr8_add(fr8_mul_plain(k2, lam), k1);
 }
-// (k1 + k2 lambda) P: joint double-and-add over the 64 bit positions with the table {P, phi(P), P + phi(P)}, complete formulas, data-independent
-// control flow
-BN_HD G1Proj g1_mul_glv(const G1Aff& P, const uint32_t k[4]) {
-  G1Aff Pe; Pe.x = fp_mul(P.x, fp_from_limbs(BN_GLV_BETA)); Pe.y = P.y;
-  const G1Proj T1 = g1_from_affine(P), T2 = g1_from_affine(Pe), T3 = g1_add_mixed(T1, Pe);
+// (+-k1) P + (+-k2) phi(P) for W-word magnitudes k1, k2: joint double-and-add over the 32 W bit positions with the table {P1, P2, P1 + P2},
+// P1 = +-P, P2 = +-phi(P); complete formulas, data-independent control flow.  W = 2: the RLC weights; W = 4: the GLV halves of a full scalar
+// (PlonK's MSMs, decomposed on the host by bn254_plonk.hpp::glv_decompose).
+template <int W>
+BN_HD G1Proj g1_mul_glv_w(const G1Aff& P, const uint32_t* k1, bool neg1, const uint32_t* k2, bool neg2) {
+  G1Aff P1 = P, P2;
+  P1.y = fp_select(neg1, fp_neg(P.y), P.y);
+  P2.x = fp_mul(P.x, fp_from_limbs(BN_GLV_BETA)); P2.y = fp_select(neg2, fp_neg(P.y), P.y);
+  const G1Proj T1 = g1_from_affine(P1), T2 = g1_from_affine(P2), T3 = g1_add_mixed(T1, P2);
   G1Proj acc = g1_identity();
-  uint32_t a0 = k[0], a1 = k[1], b0 = k[2], b1 = k[3];
-  for (int b = 0; b < 64; b++) {
-    const uint32_t d1 = a1 >> 31, d2 = b1 >> 31;
-    a1 = (a1 << 1) | (a0 >> 31); a0 <<= 1; b1 = (b1 << 1) | (b0 >> 31); b0 <<= 1;
+  uint32_t a[W], b[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) { a[i] = k1[i]; b[i] = k2[i]; }
+  for (int bit = 0; bit < 32 * W; bit++) {
+    const uint32_t d1 = a[W - 1] >> 31, d2 = b[W - 1] >> 31;
+#pragma unroll
+    for (int i = W - 1; i > 0; i--) { a[i] = (a[i] << 1) | (a[i - 1] >> 31); b[i] = (b[i] << 1) | (b[i - 1] >> 31); }
+    a[0] <<= 1; b[0] <<= 1;
     acc = g1_dbl(acc);
     G1Proj q;
     q.x = fp_select(d2 != 0, fp_select(d1 != 0, T3.x, T2.x), T1.x);
@@ -161,6 +169,7 @@ BN_HD G1Proj g1_mul_glv(const G1Aff& P, const uint32_t k[4]) {
   }
   return acc;
 }
+BN_HD G1Proj g1_mul_glv(const G1Aff& P, const uint32_t k[4]) { return g1_mul_glv_w<2>(P, k, false, k + 2, false); }
 
 // ---- per proof: A <- r A (affine), C' <- r C (projective), t_0 = r, t_j = r x_j ---------------------------------------------------------------------
 // LX(j, out_words[8]): the j-th public input of this proof as little-endian words (raw 256-bit value, used modulo r like bn::Fr)

@@ -182,3 +182,19 @@ def test_no_constant_kzg_batching_scalar_in_the_product():
     body = src[src.index("static int plonk_run("):src.index("int bn254_plonk_verify(const uint8_t* proof")]
     assert "getrandom(" in body and "from_be_reduce(rnd.data()" in body
     assert not re.search(r"lambda\s*=\s*fr_ctx\(\)\.from_u64", src)
+
+
+def test_glv_decomposition(pkg):
+    """The scalar decomposition behind the PlonK MSMs (bn254_plonk.hpp::glv_decompose): s1 k1 + s2 k2 lambda == k (mod r), k1, k2 < 2^127."""
+    import random
+    L = pkg.lib()
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    LAM = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    rng = random.Random(11)
+    cases = [0, 1, 2, R - 1, R - 2, LAM, LAM + 1, R // 2, (1 << 128) - 1, 1 << 127, (1 << 256) - 1] + [rng.randrange(R) for _ in range(3000)]
+    k1 = (C.c_uint8 * 16)(); k2 = (C.c_uint8 * 16)(); n1 = C.c_int(); n2 = C.c_int()
+    for k in cases:
+        assert L.bn254_dbg_glv_decompose(int(k).to_bytes(32, "big"), k1, k2, C.byref(n1), C.byref(n2)) == 0
+        a, b = int.from_bytes(bytes(k1), "big"), int.from_bytes(bytes(k2), "big")
+        assert a < (1 << 127) and b < (1 << 127), hex(k)
+        assert ((-a if n1.value else a) + (-b if n2.value else b) * LAM - k) % R == 0, hex(k)

@@ -96,7 +96,7 @@ TRIPS_BY_KERNEL = {                   # loops whose trip count is a launch param
     ("k_rlc_group_points", "window_outer"): (N_PUBLIC, "one pass per public input"),
     ("k_g16_msm_partial", "window_outer"): (16, "G16_WIDE_MSM_INPUTS_PER_LANE inputs per lane"),
     ("k_rlc_scale", "scalar_mul"): (64, "64 joint bit positions of the GLV weight k1 + k2 lambda"),
-    ("k_g1_scalar_mul", "scalar_mul"): (128, "128 two-bit windows of a 256-bit scalar"),
+    ("k_g1_scalar_mul", "scalar_mul"): (128, "128 joint bit positions of the GLV halves of a 254-bit scalar"),
     ("k_rlc_scale", "fr_products"): (N_PUBLIC, "one Fr product pair per public input"),
     ("k_f12_cyclo_sqr_n", "cyclo_sqr"): (186 / 39.0, "3 x 62 squarings of exp-by-u in 39 launches (BN_U_W4)"),
 }
@@ -137,7 +137,7 @@ def model_kernel(name, ins):
         elif 1700 <= c <= 1900 and inner:
             t, why = TRIPS_BY_KERNEL.get((name, "window_outer"), (1, "UNMODELLED outer window loop"))
             weight_ranges.append((h, latches[-1], float(t))); notes.append("outer window loop x%g: %s" % (t, why))
-        elif 4300 <= c <= 4600 or (name == "k_rlc_scale" and 3000 <= c <= 3400):
+        elif 4300 <= c <= 4600 or (name in ("k_rlc_scale", "k_g1_scalar_mul") and 3000 <= c <= 3400):
             t, why = TRIPS_BY_KERNEL.get((name, "scalar_mul"), (1, "UNMODELLED scalar multiplication loop"))
             weight_ranges.append((h, latches[-1], float(t))); notes.append("2-bit window loop x%g (%d mads per window): %s" % (t, c, why))
         elif c == 224:
