@@ -324,9 +324,20 @@ inline int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }
 
 // Stage 1 (plonk/verify.rs:46-284): everything up to the scalars of the linearised polynomial digest.  On a failed check the
 // proof's final status is returned and its terms are left zeroed.
-inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
-                        PlonkWork& wk, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */) {
+// The stage has ONE field inversion (of the product of its denominators, Montgomery's trick), which is a third of its host time; it is
+// therefore written in two halves around it -- a() up to the product `acc`, b(1 / acc) from there -- so that a batch can invert the
+// products of many proofs with a single inversion (bn254_capi.hip::plonk_run); plonk_stage1() below runs both halves for one proof.
+struct PlonkStage1 {
+  enum { MAXDEN = 2 + 64 + PLONK_MAX_QCP };
+  const PlonkKey* vkp; const uint8_t* proof; const uint8_t* inputs; size_t n_inputs; PlonkWork* wkp;
+  FrM alpha, beta, gamma, zeta, zeta_n, zh_zeta, acc;
+  FrM den[MAXDEN], pre[MAXDEN]; bool zero[MAXDEN]; int nden; size_t n_in;
+  int a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk);
+  int b(const FrM& acc_inv, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */);
+};
+inline int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk) {
   const FrCtx& F = fr_ctx();
+  vkp = &vk; proof = proof_; inputs = inputs_; n_inputs = n_inputs_; wkp = &wk;
   PlonkProof& pr = wk.pr;
   int st = parse_plonk_proof(pr, proof, proof_len);                       // lib.rs:70
   if (st != PL_OK) return st;
@@ -340,38 +351,43 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
   for (uint32_t i = 0; i < 8 + vk.n_qcp; i++) cg.bind(vk.enc[i], 64);
   cg.bind(inputs, 32 * n_inputs);                                         // the public inputs as stored (raw big-endian)
   cg.bind(proof, 192);                                                    // l, r, o
-  FrM gamma = cg.finish(dg);
-  Challenge cb("beta", dg); FrM beta = cb.finish(db);
+  gamma = cg.finish(dg);
+  Challenge cb("beta", dg); beta = cb.finish(db);
   Challenge ca("alpha", db);
   ca.bind(proof + pr.off_bsb, 64 * (size_t)pr.n_bsb);
   ca.bind(proof + 192, 64);                                               // z
-  FrM alpha = ca.finish(da);
+  alpha = ca.finish(da);
   Challenge cz("zeta", da);
   cz.bind(proof + 256, 192);                                              // h0, h1, h2
-  FrM zeta = cz.finish(dz);
+  zeta = cz.finish(dz);
   wk.zeta = zeta;
   // verify.rs:97-107
-  FrM zeta_n = F.pow_u64(zeta, vk.size);
-  FrM zh_zeta = F.sub(zeta_n, one);
+  zeta_n = F.pow_u64(zeta, vk.size);
+  zh_zeta = F.sub(zeta_n, one);
   FrM zm1 = F.sub(zeta, one);
   if (F.is_zero(zm1)) return PL_INVERSE;
   // every inversion of the proof in one (Montgomery's trick): zeta - 1, zeta - omega^i (public inputs), zeta - omega^(n_pub + cci)
   // (BSB22).  A zero denominator keeps the reference's behaviour: batch_invert leaves zeros alone (verify.rs:377,389) and the
   // BSB22 division by zero gives zero.
-  FrM den[2 + 64 + PLONK_MAX_QCP], pre[2 + 64 + PLONK_MAX_QCP], inv[2 + 64 + PLONK_MAX_QCP];
-  bool zero[2 + 64 + PLONK_MAX_QCP];
-  int nden = 0;
+  nden = 0;
   den[nden++] = zm1;
-  const size_t n_in = n_inputs <= 64 ? n_inputs : 64;   // larger public-input counts fall back to per-term inversions below
+  n_in = n_inputs <= 64 ? n_inputs : 64;   // larger public-input counts fall back to per-term inversions below
   {
     FrM accw = one;
     for (size_t i = 0; i < n_in; i++) { den[nden++] = F.sub(zeta, accw); accw = F.mul(accw, vk.generator); }
   }
   for (uint64_t i = 0; i < vk.n_cci; i++) den[nden++] = F.sub(zeta, vk.wpow[i]);
+  acc = one;
+  for (int i = 0; i < nden; i++) { zero[i] = F.is_zero(den[i]); pre[i] = acc; if (!zero[i]) acc = F.mul(acc, den[i]); }
+  return PL_OK;
+}
+inline int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
+  const FrCtx& F = fr_ctx();
+  const PlonkKey& vk = *vkp; PlonkWork& wk = *wkp; PlonkProof& pr = wk.pr;
+  const FrM one = F.one;
+  FrM inv[MAXDEN];
   {
-    FrM acc = one;
-    for (int i = 0; i < nden; i++) { zero[i] = F.is_zero(den[i]); pre[i] = acc; if (!zero[i]) acc = F.mul(acc, den[i]); }
-    FrM ai = F.inverse(acc);
+    FrM ai = acc_inv;
     for (int i = nden - 1; i >= 0; i--) {
       if (zero[i]) { inv[i] = den[i]; continue; }
       inv[i] = F.mul(ai, pre[i]); ai = F.mul(ai, den[i]);
@@ -434,6 +450,13 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
   put(vk.qk, one); put(vk.s[2], _s1); put(pr.z, coeff_z);
   put(pr.h[0], zh); put(pr.h[1], zn2); put(pr.h[2], zn2sq);
   return PL_OK;
+}
+inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
+                        PlonkWork& wk, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */) {
+  PlonkStage1 s;
+  int st = s.a(vk, proof, proof_len, inputs, n_inputs, wk);
+  if (st != PL_OK) return st;
+  return s.b(fr_ctx().inverse(s.acc), terms, tflags);
 }
 
 // Stage 2 (plonk/verify.rs:286-303, kzg.rs:46-190): fold the opening proofs at zeta and at zeta * omega.  lin_digest: the stage-1
