@@ -338,6 +338,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
       a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
       a.strict_scalars = (flags & BN254_FLAG_STRICT_SCALARS) ? 1 : 0;
+      a.part_of_larger = parts > 1 ? 1 : 0;
       a.msm_part = wide ? d->msm_part : nullptr;
       if (split_small && parts == 1) {
         a.split_streams[0] = d->aux[1]; a.split_streams[1] = d->aux[2];

@@ -34,20 +34,23 @@ static_assert(COOP_T_ELEM == VE_S2, "COOP_T_ELEM must name a workspace slot that
 #define CO_SLOTS 13
 #define CO_WAVE_DWORDS (CO_SLOTS * 64 * CO_STRIDE)
 
+typedef __attribute__((address_space(3))) int32_t co_lds_i32;   // LDS pointers keep their address space through the out-of-line operations (ds_* instead of flat_*)
+typedef int co_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) co_v4i co_lds_i4;
 struct Coop {
-  int32_t* img;          // this wavefront's LDS image
+  co_lds_i32* img;       // this wavefront's LDS image
   uint32_t lane, g0, c;  // lane in the wavefront, first lane of the proof's group, coefficient index (lanes 60..63: a copy of group 9, never stored)
   __device__ __forceinline__ void put(int slot, const Fp2& a) const {
-    int4* q = (int4*)(img + ((size_t)slot * 64 + lane) * CO_STRIDE);
-    q[0] = make_int4(a.c0.v[0], a.c0.v[1], a.c0.v[2], a.c0.v[3]);
-    q[1] = make_int4(a.c0.v[4], a.c0.v[5], a.c0.v[6], a.c0.v[7]);
-    q[2] = make_int4(a.c0.v[8], a.c1.v[0], a.c1.v[1], a.c1.v[2]);
-    q[3] = make_int4(a.c1.v[3], a.c1.v[4], a.c1.v[5], a.c1.v[6]);
-    q[4] = make_int4(a.c1.v[7], a.c1.v[8], 0, 0);
+    co_lds_i4* q = (co_lds_i4*)(img + ((size_t)slot * 64 + lane) * CO_STRIDE);
+    q[0] = (co_v4i){a.c0.v[0], a.c0.v[1], a.c0.v[2], a.c0.v[3]};
+    q[1] = (co_v4i){a.c0.v[4], a.c0.v[5], a.c0.v[6], a.c0.v[7]};
+    q[2] = (co_v4i){a.c0.v[8], a.c1.v[0], a.c1.v[1], a.c1.v[2]};
+    q[3] = (co_v4i){a.c1.v[3], a.c1.v[4], a.c1.v[5], a.c1.v[6]};
+    q[4] = (co_v4i){a.c1.v[7], a.c1.v[8], 0, 0};
   }
   __device__ __forceinline__ Fp2 at(int slot, uint32_t ln) const {
-    const int4* q = (const int4*)(img + ((size_t)slot * 64 + ln) * CO_STRIDE);
-    int4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4];
+    const co_lds_i4* q = (const co_lds_i4*)(img + ((size_t)slot * 64 + ln) * CO_STRIDE);
+    const co_v4i v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4];
     Fp2 a;
     a.c0.v[0] = v0.x; a.c0.v[1] = v0.y; a.c0.v[2] = v0.z; a.c0.v[3] = v0.w; a.c0.v[4] = v1.x; a.c0.v[5] = v1.y; a.c0.v[6] = v1.z; a.c0.v[7] = v1.w;
     a.c0.v[8] = v2.x; a.c1.v[0] = v2.y; a.c1.v[1] = v2.z; a.c1.v[2] = v2.w; a.c1.v[3] = v3.x; a.c1.v[4] = v3.y; a.c1.v[5] = v3.z; a.c1.v[6] = v3.w;
@@ -230,7 +233,7 @@ __device__ __forceinline__ FixedLine co_line_entry(const int32_t* entry) {   // 
   const uint8_t st = status[pc];                                                                              \
   const bool pending = live && (st & BN254_ST_PENDING) != 0;                                                  \
   if (__builtin_amdgcn_ballot_w64(pending) == 0) return;                                                      \
-  Coop co{co_lds + (size_t)wave * CO_WAVE_DWORDS, lane, pl * 6, c}
+  Coop co{(co_lds_i32*)co_lds + (size_t)wave * CO_WAVE_DWORDS, lane, pl * 6, c}
 
 // ---- final exponentiation of VE_F (workspace) -> VE_S0 (workspace), the whole program in one launch ---------------------------------------------------------
 __global__ void __launch_bounds__(64) k_coop_final_exp(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status) {

@@ -44,6 +44,7 @@ struct G16LaunchArgs {
   const int32_t* target;    // 108 dwords: the GT element the product must equal, w-power (k) order
   int inputs_match_key;     // n_public + 1 == len(vk.K)
   int strict_scalars = 0;   // BN254_FLAG_STRICT_SCALARS: inputs >= r -> NOT_MEMBER
+  int part_of_larger = 0;   // this launch is one of several sub-batches of a larger batch: never the cooperative (small-batch) kernels
   int32_t* msm_part;        // wide keys: ceil(n_public / G16_WIDE_MSM_INPUTS_PER_LANE) * 27 * n dwords of partial sums, else nullptr
   // small batches (n <= G16_SPLIT_MAX_PROOFS): two extra streams and three events (fork, join, join) let the three pairs run their
   // Miller loops as three concurrent chains (the GPU is mostly idle at such sizes: latency, not throughput, is what counts)
@@ -90,12 +91,22 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
                                        int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
 // cooperative layout for small batches (bn254_coop.hip): six lanes per proof, the whole Miller loop / final exponentiation in one launch
 #define COOP_T_ELEM 46          // = VE_S2: where the cooperative Miller loop leaves the running G2 point for k_g16_subgroup
-#define COOP_MAX_PROOFS 10240   // above this the one-proof-per-lane kernels fill the GPU better
+#define COOP_MAX_PROOFS 10240   // six-lane generation: above this the one-proof-per-lane kernels fill the GPU better
+#define COOP12_MAX_PROOFS 20480 // twelve-lane generation (four passes of 1024 wavefronts x 5 proofs: 9.3 ms against 12 ms of the lane kernels at 16384)
 hipError_t bn254_coop_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
                                  int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
 hipError_t bn254_coop_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
 hipError_t bn254_coop_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
                                    int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
+// second generation (bn254_coop12.hip): twelve lanes per proof (one Fp number of every Fp12 value per lane), 39 KB of LDS per wavefront
+hipError_t bn254_coop12_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
+                                   int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
+hipError_t bn254_coop12_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
+hipError_t bn254_coop12_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
+                                     int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
+// BN254_COOP_LANES = 6 | 12 selects the generation (default 12)
+int bn254_coop_lanes();
+static inline size_t bn254_coop_max_proofs() { return bn254_coop_lanes() == 12 ? COOP12_MAX_PROOFS : COOP_MAX_PROOFS; }
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

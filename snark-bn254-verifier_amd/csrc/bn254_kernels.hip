@@ -785,6 +785,10 @@ static const uint8_t* step_kinds_host() {
   return g_step_kinds;
 }
 
+int bn254_coop_lanes() {
+  static const int lanes = [] { const char* e = getenv("BN254_COOP_LANES"); return (e && atoi(e) == 6) ? 6 : 12; }();
+  return lanes;
+}
 hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev /* 5 events or nullptr */, G16Prof* prof) {
   unsigned grid = grid_for(a.n);
   uint32_t n = (uint32_t)a.n;
@@ -794,7 +798,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   // cooperative path (small batches): the public-input MSM moves into the cooperative kernel (six lanes per proof, L kept projective), so
   // k_g16_prepare stops after C; keys with many inputs keep their wide MSM kernels and hand L over through the workspace.  A key with more
   // than G16_WIDE_MSM_MIN_INPUTS inputs but no partial-sum buffer (wrong input count) takes the one-proof-per-lane path.
-  const bool coop = coop_on && a.n <= COOP_MAX_PROOFS && (wide || a.n_public <= G16_WIDE_MSM_MIN_INPUTS);
+  const bool coop = coop_on && !a.part_of_larger && a.n <= bn254_coop_max_proofs() && (wide || a.n_public <= G16_WIDE_MSM_MIN_INPUTS);
   BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, (wide || coop) ? 1 : 0);
   if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
   if (wide) {
@@ -808,7 +812,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (coop) {
     // small batch: cooperative layout (bn254_coop.hip): public-input MSM, Miller loop of the three pairs and final exponentiation in ONE launch
     hipError_t e;
-    { ProfScope ps_(prof, KID_COOP_G16, s); e = bn254_coop_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s); }
+    { ProfScope ps_(prof, KID_COOP_G16, s); e = (bn254_coop_lanes() == 12 ? bn254_coop12_miller_g16 : bn254_coop_miller_g16)(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s); }
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[2], s); }
     BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)COOP_T_ELEM);
@@ -993,9 +997,9 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1, nullptr}, nullptr};
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
-  if (coop_on && n <= COOP_MAX_PROOFS) {
+  if (coop_on && n <= bn254_coop_max_proofs()) {
     // small batch: the cooperative layout (bn254_coop.hip), Miller loop of the two pairs and final exponentiation in ONE launch
-    hipError_t e = bn254_coop_miller_fixed(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
+    hipError_t e = (bn254_coop_lanes() == 12 ? bn254_coop12_miller_fixed : bn254_coop_miller_fixed)(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
     if (e != hipSuccess) return e;
     BN_LAUNCH(KID_COMPARE, k_g16_compare, ws, nn, status, target_one, reject_code);
     return hipGetLastError();
