@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--n-public", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="proofs timed on the host per cpu_baseline row")
+    ap.add_argument("--no-rlc", action="store_true", help="skip the rlc_mode side measurement (all-valid batch, exact against RLC)")
     ap.add_argument("--rlc", action="store_true", help="time the random-linear-combination batch mode instead of the exact path")
     ap.add_argument("--host-buffers", action="store_true", help="also time the host-buffer entry (PCIe-inclusive), reported beside `value`")
     return ap.parse_args(argv)
@@ -354,6 +355,38 @@ def _host_buffer_line(args, pkg, vk, proofs, inputs, expected, local_rank):
     return {"value": n / dt, "unit": "proofs/s", "ms": dt * 1e3, "note": "bn254_groth16_verify_batch on pageable host buffers: H2D of proofs and inputs, compute, D2H of status"}
 
 
+def _rlc_line(args, pkg, local_rank):
+    """The random-linear-combination batch mode next to the exact path on an ALL-VALID batch of the same shape (the
+    headline workload carries 1/16 invalid proofs, which sends most groups of 32 to the exact fallback; tools/bench_rlc.py has the sweep).
+    Never `value`: the status bytes are identical by construction, the mode is opt-in (BN254_FLAG_RLC)."""
+    import torch
+    n = 1 << args.batch_log2
+    dev = torch.device("cuda", local_rank)
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540020, args.n_public, n, invalid_every=0, agree=True, threads=min(16, os.cpu_count() or 1))
+    pvk = pkg.PreparedVk(vk)
+    pvk.reserve(n, local_rank)
+    dp = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev)
+    di = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(dev)
+    ds = torch.zeros(n, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    row = {"workload": "2^%d valid proofs, %d public inputs" % (args.batch_log2, args.n_public), "unit": "proofs/s"}
+    steps = 2
+    for name, flags in (("exact", 0), ("rlc", pkg.FLAG_RLC)):
+        for it in range(steps + 1):
+            if it == 1:
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+            ds.zero_()
+            pvk.verify_batch_device(dp.data_ptr(), di.data_ptr(), ds.data_ptr(), n, 256, args.n_public, local_rank, st.cuda_stream, flags=flags)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t) / steps
+        assert bytes(ds.cpu().numpy().tobytes()) == exp, name
+        row[name] = n / dt
+    row["speedup"] = row["rlc"] / row["exact"]
+    pvk.close()
+    return row
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -392,6 +425,8 @@ def main(argv=None):
         if world == 1:
             if args.host_buffers:
                 out["host_buffers"] = _host_buffer_line(args, pkg, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"], local_rank)
+            if not args.no_rlc and not args.rlc and args.n_public <= 8:
+                out["rlc_mode"] = _rlc_line(args, pkg, local_rank)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = _cpu_baseline(args, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"])
         print(json.dumps(out), flush=True)

@@ -12,11 +12,11 @@ tail -1 $O/smoke.log
 python bench.py --host-buffers > $O/bench.json 2> $O/bench.err || fail bench $O/bench.err
 cut -c1-400 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err || fail rocprof $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rlc > $O/prof_bench.json 2> $O/prof.err || fail rocprof $O/prof.err
 echo "kernel trace done"
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $c | cut -d' ' -f1)
-  BN254_STREAMS=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch-log2 18 > $O/pmc_$tag.json 2> $O/pmc_$tag.err || fail "pmc $tag" $O/pmc_$tag.err
+  BN254_STREAMS=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-rlc --batch-log2 18 > $O/pmc_$tag.json 2> $O/pmc_$tag.err || fail "pmc $tag" $O/pmc_$tag.err
   echo "pmc $tag done"
 done
 cd $R
@@ -24,9 +24,18 @@ cd $R
 find $O -name "*kernel_trace.csv" -size +30M -delete
 python tools/bench_rlc.py --batch-log2 20 --steps 3 --invalid-every 0,256,16 > $O/rlc.txt 2> $O/rlc.err || fail rlc $O/rlc.err
 cat $O/rlc.txt
-python tools/bench_small.py > $O/small_coop.txt 2> $O/small_coop.err || fail small $O/small_coop.err
+python tools/bench_small.py > $O/small_coop12.txt 2> $O/small_coop12.err || fail small $O/small_coop12.err
+BN254_COOP_LANES=6 python tools/bench_small.py > $O/small_coop.txt 2> $O/small_coop.err || fail small6 $O/small_coop.err
 BN254_COOP=0 python tools/bench_small.py > $O/small_lane.txt 2> $O/small_lane.err || fail small_lane $O/small_lane.err
-grep 4096 $O/small_coop.txt $O/small_lane.txt
+grep 4096 $O/small_coop12.txt $O/small_coop.txt $O/small_lane.txt
+# batch 4096 (BASELINE configs[1]) under the profiler: kernel trace, then SQ counters in their own passes
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_small -o run -- python3 $R/bench.py --batch-log2 12 --steps 20 --warmup 2 --no-cpu-baseline --no-rlc > $O/small.json 2> $O/small.err || fail "rocprof small" $O/small.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_small -o run -- python3 $R/bench.py --batch-log2 12 --steps 3 --warmup 1 --no-cpu-baseline --no-rlc > $O/pmc_small.json 2> $O/pmc_small.err || fail "pmc small" $O/pmc_small.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_small2 -o run -- python3 $R/bench.py --batch-log2 12 --steps 3 --warmup 1 --no-cpu-baseline --no-rlc > $O/pmc_small2.json 2> $O/pmc_small2.err || fail "pmc small2" $O/pmc_small2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rlc -o run -- python3 $R/tools/bench_rlc.py --batch-log2 20 --steps 2 --invalid-every 0 > $O/rlc_prof.txt 2> $O/rlc_prof.err || fail "rocprof rlc" $O/rlc_prof.err
+find $O -name "*kernel_trace.csv" -size +30M -delete
+cd $R
 BN254_PLONK_TIMING=1 python tools/bench_plonk.py > $O/plonk.json 2> $O/plonk.err || fail plonk $O/plonk.err
 cut -c1-200 $O/plonk.json
 cd /tmp

@@ -70,3 +70,62 @@ for k in sorted(sq, key=lambda k: -sq[k]["SQ_WAVE_CYCLES"]):
 open(os.path.join(out, tag + "_pmc_summary.csv"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
+
+
+# ---- the secondary measurements of tools/gpu_round2.sh (each only if its output exists) ---------------------------------------------------------
+def kernel_stats(pattern, name, header):
+    tr = glob.glob(os.path.join(root, src, pattern), recursive=True)
+    if not tr:
+        return
+    a = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        a[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    t = sum(sum(v) for v in a.values())
+    with open(os.path.join(out, name), "w") as f:
+        f.write("# " + header + "\nkernel,calls,total_ms,avg_us,percent\n")
+        for k, v in sorted(a.items(), key=lambda kv: -sum(kv[1])):
+            f.write("%s,%d,%.3f,%.1f,%.2f\n" % (k, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, 100.0 * sum(v) / t))
+
+
+rnd = tag.split("_")[0]
+kernel_stats("prof_small/**/*kernel_trace.csv", rnd + "_coop12_batch4096_kernel_stats.csv",
+             "rocprofv3 --kernel-trace --stats -- python3 bench.py --batch-log2 12 --steps 20 --warmup 2 (22 batches of 4096 Groth16 proofs, cooperative layout, twelve lanes per proof)")
+kernel_stats("prof_rlc/**/*kernel_trace.csv", rnd + "_rlc_kernel_stats.csv",
+             "rocprofv3 --kernel-trace --stats -- python3 tools/bench_rlc.py --batch-log2 20 --steps 2 --invalid-every 0 (3 exact + 3 RLC passes over 2^20 valid proofs)")
+kernel_stats("prof_plonk/**/*kernel_trace.csv", rnd + "_plonk_kernel_stats.csv",
+             "rocprofv3 --kernel-trace --stats -- python3 tools/bench_plonk.py --steps 3 (4 batches of 4096 PlonK proofs, cooperative pairing check)")
+pm = glob.glob(os.path.join(root, src, "pmc_small/**/*counter_collection.csv"), recursive=True)
+if pm:
+    a = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.Counter(); waves = {}
+    files = pm + glob.glob(os.path.join(root, src, "pmc_small2/**/*counter_collection.csv"), recursive=True)
+    for p in files:
+        rows = list(csv.DictReader(open(p)))
+        first = rows[0]["Counter_Name"]
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if not k.startswith("k_"):
+                continue
+            a[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if p == pm[0] and r["Counter_Name"] == first:
+                launches[k] += 1
+                waves[k] = int(r["Grid_Size"]) // 64
+    with open(os.path.join(out, rnd + "_coop12_pmc_summary.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_* -- python3 bench.py --batch-log2 12 --steps 3 --warmup 1 (batch 4096, cooperative layout, twelve lanes per proof): "
+                "per-kernel SQ activity as fractions of wave cycles; two counter passes\n")
+        f.write("kernel,launches,waves,valu_active_frac,lds_active_frac,any_active_frac,wait_any_frac,wait_inst_frac,valu_insts_per_wave,lds_insts_per_wave,lds_bank_conflict_frac\n")
+        for k in sorted(a, key=lambda k: -a[k]["SQ_WAVE_CYCLES"]):
+            c = a[k]; wc = c["SQ_WAVE_CYCLES"] or 1; n_l = max(launches[k], 1); w = max(waves.get(k, 1), 1)
+            f.write("%s,%d,%d,%.3f,%.3f,%.3f,%.3f,%.3f,%.0f,%.0f,%.3f\n" % (
+                k, n_l, w, c["SQ_ACTIVE_INST_VALU"] / wc, c["SQ_ACTIVE_INST_LDS"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_WAIT_ANY"] / wc,
+                c["SQ_WAIT_INST_ANY"] / wc, c["SQ_INSTS_VALU"] / n_l / w, c["SQ_INSTS_LDS"] / n_l / w,
+                c["SQ_LDS_BANK_CONFLICT"] / (c["SQ_LDS_IDX_ACTIVE"] or 1)))
+for a_, b_ in (("small_coop12.txt", "_small_batches_coop12.txt"), ("small_coop.txt", "_small_batches_coop.txt"), ("small_lane.txt", "_small_batches_lane.txt"),
+               ("rlc.txt", "_rlc_vs_exact.txt"), ("plonk.json", "_plonk_bench.json"), ("cfg5.json", "_cfg5_bench.json")):
+    p = os.path.join(root, src, a_)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(out, rnd + b_))
+p = os.path.join(root, src, "plonk.err")
+if os.path.exists(p):
+    lines_ = [l for l in open(p) if l.startswith("plonk sub-batch")]
+    if lines_:
+        open(os.path.join(out, rnd + "_plonk_stage_times.txt"), "w").write("".join(lines_))
