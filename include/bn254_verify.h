@@ -75,7 +75,11 @@ enum { BN254_VK_REFERENCE = 0, BN254_VK_GNARK = 1 };
  *     one variable-argument Miller loop per proof and one final exponentiation per group; proofs of a group that fails are
  *     re-verified by the exact path, so the status bytes are those of the exact path except with probability <= 2^-120 per batch
  *     (a false ACCEPT).  Loader errors (member / curve / subgroup) are always exact.  The weights come from ChaCha20 keyed by
- *     getrandom(2) per call.  The call synchronises the stream once (to learn which groups failed). */
+ *     getrandom(2) per call.  The call synchronises the stream once (to learn which groups failed).
+ *     Adaptive: an RLC pass costs about half an exact pass and every proof of a failed group pays the exact pass on top, so per
+ *     (key, device) the share of proofs that fell back is tracked, and while it is above 0.45 the flag is ignored (the exact path
+ *     runs: same status bytes) except for one measuring RLC pass every 8 calls.  BN254_RLC_ADAPTIVE=0 in the environment
+ *     switches this off; bn254_groth16_rlc_state reports the tracked share (-1: no RLC pass yet) and the number of bypassed calls. */
 enum { BN254_FLAG_STRICT_SCALARS = 1u, BN254_FLAG_RLC = 2u };
 
 typedef struct bn254_g16_pvk bn254_g16_pvk;
@@ -167,6 +171,7 @@ int bn254_sp1_fixture_parse(const uint8_t* buf, size_t len, int* variant, uint8_
 void bn254_set_profiling(int enabled);
 void bn254_set_profile_kernels(unsigned mask);
 int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]);
+int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallback_share, unsigned* bypassed_calls);   /* BN254_FLAG_RLC, adaptive use */
 const char* bn254_groth16_kernel_name(int i);                 /* phase names */
 int bn254_groth16_num_kernel_kinds(void);
 const char* bn254_groth16_kernel_kind_name(int i);

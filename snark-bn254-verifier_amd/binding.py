@@ -52,6 +52,7 @@ def lib():
         L.bn254_groth16_proof_write_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p]
         L.bn254_groth16_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
         L.bn254_groth16_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.bn254_groth16_rlc_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
         L.bn254_groth16_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p]
         L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.bn254_synth_groth16.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -169,6 +170,12 @@ class PreparedVk:
 
     def reserve(self, n, device=0):
         _check(lib().bn254_groth16_reserve(self._h, n, device))
+
+    def rlc_state(self, device=0):
+        """(share of the checked proofs the recent FLAG_RLC passes sent to the exact fallback, -1.0 before the first pass; calls that bypassed the mode)."""
+        share, by = C.c_float(), C.c_uint()
+        _check(lib().bn254_groth16_rlc_state(self._h, device, C.byref(share), C.byref(by)))
+        return share.value, by.value
 
     def last_kernel_ms(self, device=0):
         ms = (C.c_float * NUM_KERNELS)()

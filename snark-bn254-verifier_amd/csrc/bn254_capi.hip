@@ -38,13 +38,18 @@ struct RlcDev {
   uint32_t* idx = nullptr; size_t idx_cap = 0;
   uint8_t *fb_proofs = nullptr, *fb_inputs = nullptr, *fb_status = nullptr; size_t fb_cap = 0, fb_in_cap = 0;
   uint8_t* h_status = nullptr; uint32_t* h_idx = nullptr; size_t h_cap = 0;   // pinned
+  // adaptive use of the mode: share of the checked proofs the last RLC passes sent to the exact fallback (exponential average) and how many
+  // calls have bypassed the mode since the last pass that measured it
+  bool have_obs = false; float fb_share = 0.f; unsigned bypassed = 0, bypassed_total = 0;
 };
 static void rlc_dev_free(RlcDev& r) {
   void* ptrs[] = {r.btab, r.tab, r.one, r.grp_status, r.idx, r.fb_proofs, r.fb_inputs, r.fb_status};
   for (auto q : ptrs) if (q) (void)hipFree(q);
   if (r.h_status) (void)hipHostFree(r.h_status);
   if (r.h_idx) (void)hipHostFree(r.h_idx);
+  const RlcDev keep = r;
   r = RlcDev();
+  r.have_obs = keep.have_obs; r.fb_share = keep.fb_share; r.bypassed = keep.bypassed; r.bypassed_total = keep.bypassed_total;
 }
 
 // Per (key, device) state.  `mu` serialises everything that touches it: uploads, (re)allocation and the enqueue of a batch.  The
@@ -394,6 +399,7 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
   static const int log2_share_env = [] { const char* e = getenv("BN254_RLC_SHARE_LOG2"); int v = e ? atoi(e) : 3; return v < 0 ? 0 : (v > 3 ? 3 : v); }();
   uint32_t key[11];
   if (getrandom(key, sizeof key, 0) != (ssize_t)sizeof key) return set_err(BN254_E_HIP, "getrandom failed: no weights for the RLC mode");
+  size_t seen_checked = 0, seen_fallback = 0;
   const size_t chunk = G16_MAX_BATCH;
   for (size_t off = 0; off < n; off += chunk) {
     const size_t m = n - off < chunk ? n - off : chunk;
@@ -439,7 +445,11 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
     HIPCK(hipMemcpyAsync(r.h_status, (const uint8_t*)d_status + off, m, hipMemcpyDeviceToHost, user));
     HIPCK(hipStreamSynchronize(user));
     uint32_t cnt = 0;
-    for (size_t i = 0; i < m; i++) if (r.h_status[i] == BN254_ST_PENDING) r.h_idx[cnt++] = (uint32_t)i;
+    for (size_t i = 0; i < m; i++) {
+      if (r.h_status[i] == BN254_ST_PENDING) r.h_idx[cnt++] = (uint32_t)i;
+      else if (r.h_status[i] == BN254_ST_ACCEPT) seen_checked++;
+    }
+    seen_checked += cnt; seen_fallback += cnt;
     if (cnt == 0) continue;
     if (cnt > r.fb_cap || (size_t)cnt * n_public * 32 > r.fb_in_cap) {
       void* ptrs[] = {r.fb_proofs, r.fb_inputs, r.fb_status};
@@ -460,7 +470,27 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
     e = bn254_launch_scatter_status((uint8_t*)d_status + off, r.fb_status, r.idx, cnt, user);
     if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("scatter launch: ") + hipGetErrorString(e));
   }
+  if (seen_checked) {
+    RlcDev& r = d->rlc;
+    const float share = (float)seen_fallback / (float)seen_checked;
+    r.fb_share = r.have_obs ? 0.5f * r.fb_share + 0.5f * share : share;
+    r.have_obs = true;
+  }
   return BN254_OK;
+}
+// The RLC pass costs about half an exact pass and every proof of a failed group pays the exact pass on top, so the mode loses once about half
+// of the proofs fall back (measured: 0.84 x at 1/16 invalid proofs and groups of 32).  While the recent share is above RLC_BYPASS_SHARE the
+// batch entry points run the exact path directly (same status bytes by construction) and re-measure with an RLC pass every RLC_PROBE_EVERY calls.
+// BN254_RLC_ADAPTIVE=0 switches this off.
+#define RLC_BYPASS_SHARE 0.45f
+#define RLC_PROBE_EVERY 8
+static bool rlc_bypass(RlcDev& r) {
+  const char* e = getenv("BN254_RLC_ADAPTIVE");      // read per call (as BN254_RLC_SHARE_MIN_LANES): tests switch it
+  const bool adaptive = !e || atoi(e) != 0;
+  if (!adaptive || !r.have_obs || r.fb_share <= RLC_BYPASS_SHARE) { r.bypassed = 0; return false; }
+  if (r.bypassed + 1 >= RLC_PROBE_EVERY) { r.bypassed = 0; return false; }
+  r.bypassed++; r.bypassed_total++;
+  return true;
 }
 // one batch on `user`: waits for the previous batch of this (key, device), runs the exact or the RLC pipeline, records busy_ev
 static int g16_enqueue(const bn254_g16_pvk* pvk, DevState* d, int device, const void* d_proofs, size_t proof_stride, const void* d_inputs,
@@ -468,7 +498,7 @@ static int g16_enqueue(const bn254_g16_pvk* pvk, DevState* d, int device, const 
   if (d->busy_valid) HIPCK(hipStreamWaitEvent(user, d->busy_ev, 0));
   int rc;
   const bool rlc = (flags & BN254_FLAG_RLC) && n_public + 1 == pvk->host.n_k && n_public <= (size_t)RLC_MAX_PUBLIC && n >= (size_t)RLC_MIN_BATCH;
-  if (rlc) rc = g16_enqueue_rlc(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
+  if (rlc && !rlc_bypass(d->rlc)) rc = g16_enqueue_rlc(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
   else rc = g16_enqueue_exact(pvk, d, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
   if (rc) return rc;
   HIPCK(hipEventRecord(d->busy_ev, user));
@@ -487,6 +517,15 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
   int rc = ensure_dev(pvk, *d, device, n);
   if (rc) return rc;
   return g16_enqueue(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, (hipStream_t)hip_stream, flags);
+}
+
+int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallback_share, unsigned* bypassed_calls) {
+  if (!pvk) return set_err(BN254_E_BAD_ARG, "bad argument");
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (fallback_share) *fallback_share = d->rlc.have_obs ? d->rlc.fb_share : -1.f;
+  if (bypassed_calls) *bypassed_calls = d->rlc.bypassed_total;
+  return BN254_OK;
 }
 
 int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]) {

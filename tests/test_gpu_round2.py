@@ -21,6 +21,12 @@ def L(pkg):
     return pkg.lib()
 
 
+@pytest.fixture(autouse=True)
+def _rlc_always(monkeypatch):
+    """The RLC tests want the RLC kernels to run on every call: switch the adaptive bypass off (test_rlc_adaptive_bypass switches it on)."""
+    monkeypatch.setenv("BN254_RLC_ADAPTIVE", "0")
+
+
 @pytest.fixture(scope="module")
 def wl(pkg):
     """4133 synthetic proofs (not a multiple of anything), every 8th invalid, cycling through the 5 failure classes."""
@@ -43,6 +49,31 @@ def test_rlc_statuses_identical_to_exact(pkg, O, wl, L):
         # a second call draws fresh weights: same answer
         assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exact
         pvk.close()
+
+
+def test_rlc_adaptive_bypass(pkg, wl, L, monkeypatch):
+    """With most groups failing (every 8th proof invalid, groups of 32) the flag stops paying: after the first RLC pass has measured the
+    fallback share the next calls run the exact path (same status bytes), with a measuring RLC pass every 8 calls; a mostly valid
+    workload on the same key brings the mode back."""
+    monkeypatch.setenv("BN254_RLC_ADAPTIVE", "1")
+    vk, proofs, inputs, exp = wl
+    pvk = pkg.PreparedVk(vk)
+    assert pvk.rlc_state() == (-1.0, 0)
+    for i in range(10):
+        assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exp
+        share, bypassed = pvk.rlc_state()
+        assert share > 0.9
+        assert bypassed == (0, 1, 2, 3, 4, 5, 6, 7, 7, 8)[i], (i, bypassed)     # call 0 and call 8 are RLC passes
+    # valid proofs only: the measuring passes pull the share down and the mode stays on
+    n = len(exp)
+    keep = [i for i in range(n) if exp[i] == 1][:2048]
+    vp = b"".join(proofs[256 * i:256 * i + 256] for i in keep); vi = b"".join(inputs[64 * i:64 * i + 64] for i in keep)
+    seen = pvk.rlc_state()[1]
+    for i in range(24):
+        assert pvk.verify_batch(vp, vi, len(keep), flags=pkg.FLAG_RLC) == b"\x01" * len(keep)
+    share, bypassed = pvk.rlc_state()
+    assert share < 0.45 and bypassed - seen <= 14, (share, bypassed - seen)
+    pvk.close()
 
 
 def test_rlc_shared_accumulator_layout(pkg, O, wl, L):
