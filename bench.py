@@ -238,7 +238,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         }
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
-            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch)
+            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, concurrent=per_launch < n)
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
             out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown)
         emit(json.dumps(out))
@@ -252,7 +252,7 @@ def _load_json(name):
         return None
 
 
-def _valu_roofline(dom, launches_ms, per_launch):
+def _valu_roofline(dom, launches_ms, per_launch, concurrent=True):
     """The binding roofline, for the dominant kernel kind: multiply-adds per launch / average launch duration vs the v_mad peak."""
     launches, total_ms = launches_ms
     avg_ms = total_ms / max(1, launches)
@@ -263,9 +263,10 @@ def _valu_roofline(dom, launches_ms, per_launch):
          "traffic": (traffic["read_bytes_per_proof"] + traffic["write_bytes_per_proof"]) * per_launch if traffic else None,
          "note": "v_mad_[iu]64_[iu]32 per proof and launch counted in the gfx950 code object (tools/count_mads.py -> profiles/kernel_mads.json) x proofs "
                  "per launch / HIP-event launch duration inside the timed region; peak = measured issue rate (profiles/r01_ubench_valu.txt); "
-                 "launches of the concurrent sub-batch streams share the GPU, so one stream's launch sees about half the chip"}
+                 "launches of the concurrent sub-batch streams share the GPU, so one stream's launch sees about half the chip (batches below 32768 proofs: "
+                 "one launch, no concurrent stream; cooperative kernels: 12 lanes per proof, count from the call-graph model checked against SQ_INSTS_VALU_INT64)"}
     if mads:
-        streams = int(os.environ.get("BN254_STREAMS", "2"))
+        streams = int(os.environ.get("BN254_STREAMS", "2")) if concurrent else 1
         # sub-batch streams run the same kernel kind side by side: a launch of one stream competes with the other stream's
         ach = mads * per_launch / (avg_ms * 1e-3) / 1e12
         r.update({"mads_per_proof_launch": mads, "achieved_one_stream": ach, "achieved": ach * streams, "concurrent_streams": streams,

@@ -141,6 +141,11 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
                              size_t n_public, size_t n, uint8_t* status, int device);
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                        size_t n_public, uint8_t* status);
+/* Durations (ms) of the first sub-batch of the last bn254_plonk_verify_batch on `device`: host stage 1, digest MSM (wall, copies included),
+ * host stage 2, folding MSMs + pairing check (wall); then from HIP events on the sub-batch's stream: digest MSM kernels, the merged
+ * k_g1_scalar_mul launch of stage 2, the pairing check.  lanes: scalar multiplications (= lanes) of the two k_g1_scalar_mul launches. */
+#define BN254_PLONK_NUM_TIMINGS 7
+int bn254_plonk_last_timing(const bn254_plonk_pvk* pvk, int device, float ms[BN254_PLONK_NUM_TIMINGS], size_t lanes[2]);
 
 /* ---- gnark / SP1 formats, both directions (host only) ------------------------------------------------------------------
  * Point codecs of verifier/src/converter.rs:23-153.  compress: uncompressed big-endian coordinates (G1: x | y; G2: x.c1 | x.c0 |

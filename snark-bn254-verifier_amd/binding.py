@@ -52,6 +52,7 @@ def lib():
         L.bn254_groth16_proof_write_raw.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p]
         L.bn254_groth16_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
         L.bn254_groth16_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.bn254_plonk_last_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_size_t)]
         L.bn254_groth16_rlc_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
         L.bn254_groth16_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p]
         L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
@@ -107,6 +108,14 @@ class PreparedPlonkVk:
         st = (C.c_uint8 * max(n, 1))()
         _check(lib().bn254_plonk_verify_batch(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device))
         return bytes(st)[:n]
+
+    def last_timing(self, device=0):
+        """Stage and kernel durations (ms) of the first sub-batch of the last verify_batch (bn254_plonk_last_timing)."""
+        ms = (C.c_float * 7)()
+        lanes = (C.c_size_t * 2)()
+        _check(lib().bn254_plonk_last_timing(self._h, device, ms, lanes))
+        names = ("host_stage1", "digest_msm_wall", "host_stage2", "fold_msm_pairing_wall", "digest_msm_kernels", "k_g1_scalar_mul_stage2", "pairing_check")
+        return dict(zip(names, ms)), (lanes[0], lanes[1])
 
     def close(self):
         if self._h:

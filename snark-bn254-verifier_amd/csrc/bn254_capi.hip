@@ -163,6 +163,8 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 struct PlonkCtx {
   size_t cap = 0;                      // proofs the buffers below hold
   hipStream_t stream = nullptr, aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t tk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // timing: digest MSM, scalar multiplications of stage 2, pairing check
+  float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
   int32_t *ws = nullptr, *part = nullptr;
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
@@ -188,6 +190,7 @@ static void plonk_ctx_free(PlonkCtx& c) {
   if (c.aux) (void)hipStreamDestroy(c.aux);
   if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
   if (c.ev_join) (void)hipEventDestroy(c.ev_join);
+  for (auto e : c.tk) if (e) (void)hipEventDestroy(e);
   c = PlonkCtx();
 }
 static void plonk_dev_free(PlonkDev& d) {
@@ -211,6 +214,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   if (!c.stream) {
     HIPCK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+    for (auto& e : c.tk) HIPCK(hipEventCreate(&e));
   }
   size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
   if (need <= c.cap) return BN254_OK;
@@ -262,7 +266,10 @@ const char* bn254_status_string(int s) {
 void bn254_set_profiling(int enabled) { g_profiling.store(enabled); }
 void bn254_set_profile_kernels(unsigned mask) { g_prof_mask.store(mask); }
 int bn254_groth16_num_kernel_kinds(void) { return KID_COUNT; }
-const char* bn254_groth16_kernel_kind_name(int i) { return (i >= 0 && i < KID_COUNT) ? bn254_kernel_kind_names[i] : ""; }
+const char* bn254_groth16_kernel_kind_name(int i) {
+  if (i == KID_COOP_G16 && bn254_coop_lanes() == 12) return "k_coop12_miller_g16";   // the generation in use (BN254_COOP_LANES)
+  return (i >= 0 && i < KID_COUNT) ? bn254_kernel_kind_names[i] : "";
+}
 const char* bn254_groth16_kernel_name(int i) {
   static const char* names[BN254_G16_NUM_KERNELS] = {"phase_prepare", "phase_miller", "phase_subgroup", "phase_finalexp"};
   return (i >= 0 && i < BN254_G16_NUM_KERNELS) ? names[i] : "";
@@ -730,8 +737,10 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)T1, hipMemcpyHostToDevice, c.stream));   // GLV signs (bn254_plonk.hpp::put_term)
+  HIPCK(hipEventRecord(c.tk[0], c.stream));
   hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+  HIPCK(hipEventRecord(c.tk[1], c.stream));
   HIPCK(hipMemcpyAsync(c.h_words, c.words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipMemcpyAsync(c.h_inf, c.inf, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
@@ -754,16 +763,38 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.status, c.h_status, m, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * TT * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)TT, hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipEventRecord(c.tk[2], c.stream));
   e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.stream);
+  HIPCK(hipEventRecord(c.tk[3], c.stream));
   if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
   if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+  HIPCK(hipEventRecord(c.tk[4], c.stream));
   e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
+  HIPCK(hipEventRecord(c.tk[5], c.stream));
   HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
   memcpy(status, c.h_status, m);
+  {
+    auto t4_ = now();
+    c.last_ms[0] = (float)ms(t0, t1_); c.last_ms[1] = (float)ms(t1_, t2_); c.last_ms[2] = (float)ms(t2_, t3_); c.last_ms[3] = (float)ms(t3_, t4_);
+    HIPCK(hipEventElapsedTime(&c.last_ms[4], c.tk[0], c.tk[1])); HIPCK(hipEventElapsedTime(&c.last_ms[5], c.tk[2], c.tk[3]));
+    HIPCK(hipEventElapsedTime(&c.last_ms[6], c.tk[4], c.tk[5])); c.last_ms[7] = 0.f;
+    c.last_lanes[0] = m * (size_t)T1; c.last_lanes[1] = m * (size_t)TT; c.last_valid = true;
+  }
   if (timing) fprintf(stderr, "plonk sub-batch %zu: stage1 %.2f ms, msm1 %.2f ms, stage2 %.2f ms, msm2+pairing %.2f ms\n", m, ms(t0, t1_), ms(t1_, t2_), ms(t2_, t3_), ms(t3_, now()));
+  return BN254_OK;
+}
+
+int bn254_plonk_last_timing(const bn254_plonk_pvk* pvk, int device, float ms[BN254_PLONK_NUM_TIMINGS], size_t lanes[2]) {
+  if (!pvk || !ms) return set_err(BN254_E_BAD_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  auto it = pvk->dev.find(device);
+  if (it == pvk->dev.end() || !it->second.ctx[0].last_valid) return set_err(BN254_E_BAD_ARG, "no PlonK batch on this device yet");
+  const PlonkCtx& c = it->second.ctx[0];
+  for (int i = 0; i < BN254_PLONK_NUM_TIMINGS; i++) ms[i] = c.last_ms[i];
+  if (lanes) { lanes[0] = c.last_lanes[0]; lanes[1] = c.last_lanes[1]; }
   return BN254_OK;
 }
 

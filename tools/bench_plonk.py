@@ -35,6 +35,22 @@ def main():
     for _ in range(args.steps):
         st = pvk.verify_batch(pb, ib)
     dt = time.perf_counter() - t
+    # the dominant GPU kernel against the VALU peak: the merged k_g1_scalar_mul launch of stage 2 (one lane per scalar multiplication,
+    # multiply-adds per lane from the code object: tools/count_mads.py), and the pairing check on the cooperative kernel
+    stage_ms, lanes = pvk.last_timing()
+    km = json.load(open(os.path.join(ROOT, "profiles", "kernel_mads.json")))["kernels"]
+    peak = 35.1e12
+    sm = km["k_g1_scalar_mul"]["mads_per_proof_launch"]
+    ach = sm * lanes[1] / (stage_ms["k_g1_scalar_mul_stage2"] * 1e-3)
+    roofline = {"bound": "valu", "kernel": "k_g1_scalar_mul", "unit": "T mad/s", "peak": peak / 1e12, "achieved": ach / 1e12, "frac": ach / peak,
+                "avg_launch_ms": stage_ms["k_g1_scalar_mul_stage2"], "lanes_per_launch": lanes[1], "mads_per_lane": sm, "traffic": None,
+                "note": "%d lanes = %.2f wavefronts per SIMD: the launch lasts as long as one wavefront's chain of %d multiply-adds (GLV halves, 128 joint bit "
+                        "positions); peak = measured issue rate with full occupancy (profiles/r01_ubench_valu.txt)" % (lanes[1], lanes[1] / 64 / 1024.0, int(sm))}
+    pc = km.get("k_coop12_miller_fixed")
+    pairing = None
+    if pc and args.batch <= 20480:
+        a2 = pc["mads_per_proof_launch"] * min(args.batch, 65536) / (stage_ms["pairing_check"] * 1e-3)
+        pairing = {"kernel": "k_coop12_miller_fixed", "ms": stage_ms["pairing_check"], "mads_per_proof": pc["mads_per_proof_launch"], "achieved": a2 / 1e12, "frac": a2 / peak}
     m = min(args.cpu_sample, args.batch)
     t = time.perf_counter()
     ref = bytes(O.plonk_verify(proofs[i], vk, [int.from_bytes(inputs[i][:32], "big"), int.from_bytes(inputs[i][32:], "big")]) for i in range(m))
@@ -45,6 +61,7 @@ def main():
                       "unit": "proofs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
                       "higher_is_better": True, "dtype": "int64", "data": "reference fixtures + mutations",
                       "config": {"workload": "BASELINE configs[3]: PlonK batch %d, 904-byte proofs, 2 public inputs, 1/8 invalid" % args.batch},
+                      "roofline": roofline, "pairing_check": pairing, "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                       "cpu_baseline": {"value": m / cdt, "unit": "proofs/s", "cores": 1, "kind": "port", "sample": "first %d proofs, %.1f s" % (m, cdt)}}))
 
 

@@ -33,14 +33,15 @@ PM2_BITS = bin(P - 2)[2:]
 INV_SQUARINGS = len(PM2_BITS) - 1
 INV_MUL_FRACTION = (PM2_BITS.count("1") - 1) / (len(PM2_BITS) - 1)
 
-def extract_code_object(workdir):
+def extract_code_objects(workdir):
+    """One code object per translation unit (kernels, C ABI, the two cooperative files)."""
     lib = os.path.join(workdir, "lib.so")
     shutil.copy(LIB, lib)
     subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], stdout=subprocess.DEVNULL, cwd=workdir)
-    for f in os.listdir(workdir):
-        if "amdgcn" in f:
-            return os.path.join(workdir, f)
-    raise SystemExit("no gfx950 code object found in " + LIB)
+    cos = sorted(os.path.join(workdir, f) for f in os.listdir(workdir) if "amdgcn" in f)
+    if not cos:
+        raise SystemExit("no gfx950 code object found in " + LIB)
+    return cos
 
 
 def disassemble(co):
@@ -166,18 +167,190 @@ def model_kernel(name, ins):
         total -= len(psi) * (1.0 - 2.0 / 23.0)
         notes.append("psi / psi^2 maps (%d mads) run in 2 of the 23 launches" % len(psi))
     return {"static_mads": len(mads), "valu_instructions_static": valu, "mads_per_proof_launch": total, "model": "; ".join(notes) if notes else "straight-line: static count",
-            "unmodelled": unmodelled}
+            "unmodelled": unmodelled, "weights": weight_ranges}
+
+
+# ---- cooperative small-batch kernels (bn254_coop12.hip): one launch = public-input MSM + Miller loop + final exponentiation, operations of the
+# final exponentiation are out-of-line device functions.  Dynamic count per WAVEFRONT = sum over address ranges of (static count x executions):
+# the Miller loop's ranges are recognised by their multiply-add signature, the executions come from the step program (bn254_vm.h /
+# bn254_constants.h: 65 doubling steps, 64 of them with the squaring of f, 23 addition steps) and from vm_final_exp_program / vm_exp_u.  The same
+# weights applied to (v_mad_64 + v_lshl_add_u64 + v_ashrrev_i64) and to all VALU instructions predict the counters SQ_INSTS_VALU_INT64 and
+# SQ_INSTS_VALU of a rocprofv3 --pmc run (tools/gpu_round2.sh), which is how the model is checked: `pmc_check` in the output.
+INT64 = re.compile(r"^\s*(v_mad_[iu]64_[iu]32|v_lshl_add_u64|v_ashrrev_i64)\b")     # what SQ_INSTS_VALU_INT64 counts (calibrated on the straight-line kernels)
+CLASSES = {"mads": MAD, "int64": INT64, "valu": VALU}
+
+
+def u_w4_digits():
+    src = open(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", "bn254_constants.h")).read()
+    m = re.search(r"BN_U_W4\[\d+\]\s*=\s*\{([^}]*)\}", src)
+    return [int(x) for x in m.group(1).split(",")]
+
+
+def final_exp_ops():
+    """Operation counts of vm_final_exp_program (bn254_vm.h): three vm_exp_u (one squaring + 3 table products + per non-zero digit after the
+    first a run of squarings and a product) and the fixed part."""
+    d = u_w4_digits()
+    nz = sum(1 for x in d[1:] if x != 0)
+    return {"inv": 1, "conj": 5, "frob": 4, "mul": 12 + 3 * (3 + nz), "cyclo_calls": 3 + 3 * (1 + nz), "cyclo_squarings": 3 + 3 * (1 + (len(d) - 1))}
+
+
+def wcount(ins, ranges, rx):
+    t = 0.0
+    for a, text, _ in ins:
+        if rx.match(text):
+            w = 1.0
+            for lo, hi, f in ranges:
+                if lo <= a <= hi:
+                    w *= f
+            t += w
+    return t
+
+
+def counts(ins, ranges):
+    return {k: wcount(ins, ranges, rx) for k, rx in CLASSES.items()}
+
+
+def add(a, b, f=1.0):
+    return {k: a.get(k, 0.0) + f * b[k] for k in b}
+
+
+def loops_of(ins):
+    mads = [a for a, t, _ in ins if MAD.match(t)]
+    return [(h, l, count_in(mads, h, l[-1])) for h, l in loop_groups(ins, mads)], mads
+
+
+def callee_straight(funcs, frag):
+    sym = [k for k in funcs if frag in k]
+    assert len(sym) == 1, (frag, sym)
+    return funcs[sym[0]]
+
+
+def coop12_callees(funcs, notes):
+    """Dynamic counts per call of the out-of-line operations."""
+    ops = final_exp_ops()
+    out = {}
+    for name in ("c12_mul", "c12_conj", "c12_frob"):
+        ins = callee_straight(funcs, "%d%sENS" % (len(name), name))
+        assert not [1 for a, t, tg in ins if tg is not None and tg <= a and MAD.match("v_mad_u64_u32") and count_in([x for x, tt, _ in ins if MAD.match(tt)], tg, a) > 0], name
+        out[name] = counts(ins, [])
+    # Granger-Scott squarings: prologue + count x loop body
+    ins = callee_straight(funcs, "15c12_cyclo_sqr_nENS")
+    lg, _ = loops_of(ins)
+    lg = [g for g in lg if g[2] > 0]
+    assert len(lg) == 1, "c12_cyclo_sqr_n: one squaring loop expected"
+    h, latches, c = lg[0]
+    per_call = counts(ins, [(h, latches[-1], 0.0)])
+    per_sq = add({}, counts(ins, []), 1.0)
+    per_sq = {k: per_sq[k] - per_call[k] for k in per_sq}
+    out["cyclo_call"], out["cyclo_sq"] = per_call, per_sq
+    notes.append("c12_cyclo_sqr_n: %d multiply-adds per squaring" % per_sq["mads"])
+    # inversion: fp12_inv with its Fermat loop (same recognition as k_f12_inv) + the out-of-line fp6 products it calls
+    ins = callee_straight(funcs, "7c12_invENS")
+    e = model_kernel("c12_inv", ins)
+    assert not e["unmodelled"], e["unmodelled"]
+    calls = sum(1 for _, t, _ in ins if t.startswith("s_swappc"))
+    f6 = counts(callee_straight(funcs, "10fp6_mul_nlE"), [])
+    out["c12_inv"] = add(counts(ins, e["weights"]), f6, calls)
+    notes.append("c12_inv: %s + %d fp6_mul_nl calls" % (e["model"], calls))
+    # public-input MSM: ceil(32 n_public / 12) window additions per lane (the wavefront runs the longest lane), then the tree
+    ins = callee_straight(funcs, "20c12_public_input_msmENS")
+    lg, _ = loops_of(ins)
+    lg = [g for g in lg if g[2] > 1000]
+    assert len(lg) == 1, "c12_public_input_msm: one window loop expected"
+    trips = -(-32 * N_PUBLIC // 12)
+    out["msm"] = counts(ins, [(lg[0][0], lg[0][1][-1], float(trips))])
+    notes.append("c12_public_input_msm: window loop x%d (%d multiply-adds per table addition)" % (trips, lg[0][2]))
+    return out, ops
+
+
+def coop12_kernel(funcs, frag, kind, callees, ops, n_pairs=2):
+    """kind 'g16': k_coop12_miller_g16; 'fixed': k_coop12_miller_fixed with n_pairs table-driven pairs."""
+    ins = callee_straight(funcs, frag)
+    lg, mads = loops_of(ins)
+    h, latches, c = max(lg, key=lambda g: g[2])              # the Miller loop: the loop holding the most multiply-adds
+    lo, hi = h, latches[-1]
+    conds = []
+    for a, text, tgt in ins:
+        if lo <= a <= hi and tgt is not None and a < tgt <= hi and text.startswith("s_cbranch"):
+            m = count_in(mads, a + 1, tgt - 1)
+            if m >= 100:
+                conds.append((a + 1, tgt - 1, m))
+    steps = 88.0
+    ranges = [(lo, hi, steps)]
+    notes = []
+    if kind == "g16":
+        assert len(latches) == 2 and len(conds) == 2, ("k_coop12_miller_g16: layout changed", latches, conds)
+        (s_lo, s_hi, s_m), (a_lo, a_hi, a_m) = conds
+        d_lo, d_hi = latches[0] + 1, latches[1]
+        d_m = count_in(mads, d_lo, d_hi)
+        assert 700 <= s_m <= 800 and 950 <= a_m <= 1000 and 800 <= d_m <= 900, (s_m, a_m, d_m)
+        ranges += [(s_lo, s_hi, 64.0 / steps), (a_lo, a_hi, 23.0 / steps), (d_lo, d_hi, 65.0 / steps)]
+        notes.append("Miller loop x88: squaring of f (%d multiply-adds) x64, G2 addition rounds (%d) x23, G2 doubling rounds (%d) x65, three line products (%d) x88"
+                     % (s_m, a_m, d_m, count_in(mads, lo, hi) - s_m - a_m - d_m))
+    else:
+        # sqr (conditional), pair 0, pair 1 (conditional: n_pairs > 1), first latch (taken when n_pairs <= 2), pair 2, second latch
+        assert len(latches) == 2 and len(conds) == 2, ("k_coop12_miller_fixed: layout changed", latches, conds)
+        (s_lo, s_hi, s_m), (p1_lo, p1_hi, p1_m) = conds
+        p2_lo, p2_hi = latches[0] + 1, latches[1]
+        p2_m = count_in(mads, p2_lo, p2_hi)
+        assert 700 <= s_m <= 800 and 800 <= p1_m <= 900 and p1_m == p2_m, (s_m, p1_m, p2_m)
+        ranges += [(s_lo, s_hi, 64.0 / steps), (p1_lo, p1_hi, 1.0 if n_pairs > 1 else 0.0), (p2_lo, p2_hi, 1.0 if n_pairs > 2 else 0.0)]
+        notes.append("Miller loop x88: squaring of f (%d multiply-adds) x64, line product of a table-driven pair (%d) x88 for each of the %d pairs"
+                     % (s_m, p1_m, n_pairs))
+    tot = counts(ins, ranges)
+    if kind == "g16":
+        tot = add(tot, callees["msm"])
+    tot = add(tot, callees["c12_inv"], ops["inv"])
+    tot = add(tot, callees["c12_conj"], ops["conj"])
+    tot = add(tot, callees["c12_frob"], ops["frob"])
+    tot = add(tot, callees["c12_mul"], ops["mul"])
+    tot = add(tot, callees["cyclo_call"], ops["cyclo_calls"])
+    tot = add(tot, callees["cyclo_sq"], ops["cyclo_squarings"])
+    notes.append("final exponentiation: %(inv)d inversion, %(mul)d products, %(cyclo_squarings)d cyclotomic squarings in %(cyclo_calls)d calls, %(frob)d Frobenius maps, %(conj)d conjugations" % ops)
+    return tot, notes
+
+
+def model_coop12(funcs):
+    notes = []
+    callees, ops = coop12_callees(funcs, notes)
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "coop12_pmc_counts.json")))
+    except Exception:
+        pass
+    out = {}
+    for name, frag, kind in (("k_coop12_miller_g16", "19k_coop12_miller_g16E", "g16"), ("k_coop12_miller_fixed", "21k_coop12_miller_fixedE", "fixed")):
+        tot, n2 = coop12_kernel(funcs, frag, kind, callees, ops)
+        e = {"lanes_per_proof": 12, "proofs_per_wavefront": 5,
+             "wavefront_instructions": {k: round(v, 1) for k, v in tot.items()},
+             "mads_per_proof_launch": tot["mads"] * 12,
+             "static_mads": sum(1 for _, t, _ in callee_straight(funcs, frag) if MAD.match(t)),
+             "model": "; ".join(n2 + notes) + "; per proof = 12 lanes x the wavefront's count (lanes 60..63 idle)", "unmodelled": [], "symbol": frag}
+        if pmc and name in pmc:
+            m = pmc[name]
+            e["pmc_check"] = {"SQ_INSTS_VALU_INT64_per_wavefront": m["SQ_INSTS_VALU_INT64"], "model_int64": round(tot["int64"], 1),
+                              "SQ_INSTS_VALU_per_wavefront": m["SQ_INSTS_VALU"], "model_valu": round(tot["valu"], 1),
+                              "int64_error": tot["int64"] / m["SQ_INSTS_VALU_INT64"] - 1.0, "valu_error": tot["valu"] / m["SQ_INSTS_VALU"] - 1.0}
+        out[name] = e
+    return out
 
 
 def main():
     with tempfile.TemporaryDirectory() as wd:
-        funcs = disassemble(extract_code_object(wd))
+        per_co = [disassemble(co) for co in extract_code_objects(wd)]
+    funcs = collections.OrderedDict()
+    for d in per_co:
+        for sym, ins in d.items():
+            funcs.setdefault(sym, ins)      # out-of-line helpers that several translation units carry (fp6_mul_nl) are identical copies
     kernels, inst = {}, {}
     for sym, ins in funcs.items():
         name = short(sym)
         if not name.startswith("k_") or not ins:
             continue
+        if name.startswith("k_coop"):
+            continue                          # cooperative kernels: model_coop12 (call graph + step program)
         e = model_kernel(name, ins)
+        e.pop("weights")
         e["symbol"] = sym
         inst.setdefault(name, []).append(e)
     for name, es in inst.items():
@@ -196,6 +369,7 @@ def main():
     if "k_f12_cyclo_sqr_n" in kernels:
         e = kernels["k_f12_cyclo_sqr_n"]
         e["mads_per_proof_batch"] = e["mads_per_proof_launch"] * 39     # all 39 launches of a batch together (exact: 186 squarings)
+    kernels.update(model_coop12(funcs))
     out = {"_note": "v_mad_[iu]64_[iu]32 executed per proof (lane) and launch, from the gfx950 code object of libbn254_verify_amd.so; written by "
                     "tools/count_mads.py (loop trip counts and their sources: the `model` strings; n_public = %d)" % N_PUBLIC,
            "kernels": kernels}

@@ -33,6 +33,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_small -o run -- python3 $R/bench.py --batch-log2 12 --steps 20 --warmup 2 --no-cpu-baseline --no-rlc > $O/small.json 2> $O/small.err || fail "rocprof small" $O/small.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_small -o run -- python3 $R/bench.py --batch-log2 12 --steps 3 --warmup 1 --no-cpu-baseline --no-rlc > $O/pmc_small.json 2> $O/pmc_small.err || fail "pmc small" $O/pmc_small.err
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_small2 -o run -- python3 $R/bench.py --batch-log2 12 --steps 3 --warmup 1 --no-cpu-baseline --no-rlc > $O/pmc_small2.json 2> $O/pmc_small2.err || fail "pmc small2" $O/pmc_small2.err
+rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_int64_small -o run -- python3 $R/bench.py --batch-log2 12 --steps 3 --warmup 1 --no-cpu-baseline --no-rlc > $O/pmc_int64_small.json 2> $O/pmc_int64_small.err || fail "pmc int64 small" $O/pmc_int64_small.err
+rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_int64_plonk -o run -- python3 $R/tools/bench_plonk.py --steps 2 > $O/pmc_int64_plonk.json 2> $O/pmc_int64_plonk.err || fail "pmc int64 plonk" $O/pmc_int64_plonk.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rlc -o run -- python3 $R/tools/bench_rlc.py --batch-log2 20 --steps 2 --invalid-every 0 > $O/rlc_prof.txt 2> $O/rlc_prof.err || fail "rocprof rlc" $O/rlc_prof.err
 find $O -name "*kernel_trace.csv" -size +30M -delete
 cd $R

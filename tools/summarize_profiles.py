@@ -129,3 +129,21 @@ if os.path.exists(p):
     lines_ = [l for l in open(p) if l.startswith("plonk sub-batch")]
     if lines_:
         open(os.path.join(out, rnd + "_plonk_stage_times.txt"), "w").write("".join(lines_))
+
+# 64-bit integer VALU instructions per wavefront of the cooperative kernels (check of tools/count_mads.py's call-graph model)
+cc = {}
+for d_ in ("pmc_int64_small", "pmc_int64_plonk"):
+    for p in glob.glob(os.path.join(root, src, d_ + "/**/*counter_collection.csv"), recursive=True):
+        a = collections.defaultdict(lambda: collections.defaultdict(float)); n_ = collections.Counter(); waves = {}
+        for r in csv.DictReader(open(p)):
+            k = short(r["Kernel_Name"])
+            if "coop" not in k:
+                continue
+            a[k][r["Counter_Name"]] += float(r["Counter_Value"]); n_[(k, r["Counter_Name"])] += 1; waves[k] = int(r["Grid_Size"]) // 64
+        for k, v in a.items():
+            cc[k] = {c: x / n_[(k, c)] / waves[k] for c, x in v.items()}
+            cc[k]["wavefronts"] = waves[k]
+if cc:
+    cc["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU SQ_WAVES on batch 4096 (bench.py --batch-log2 12; tools/bench_plonk.py): "
+                   "instructions per wavefront and launch.  SQ_INSTS_VALU_INT64 = v_mad_[iu]64_[iu]32 + v_lshl_add_u64 + v_ashrrev_i64 (exact on the straight-line kernels)")
+    json.dump(cc, open(os.path.join(out, "coop12_pmc_counts.json"), "w"), indent=1, sort_keys=True)
