@@ -62,7 +62,7 @@ def test_rlc_adaptive_bypass(pkg, wl, L, monkeypatch):
     for i in range(10):
         assert pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC) == exp
         share, bypassed = pvk.rlc_state()
-        assert share > 0.9
+        assert share > 0.45          # 0.99 with groups of 32, 0.63 with groups of 8 (BN254_RLC_GROUP_LOG2): above the bypass threshold either way
         assert bypassed == (0, 1, 2, 3, 4, 5, 6, 7, 7, 8)[i], (i, bypassed)     # call 0 and call 8 are RLC passes
     # valid proofs only: the measuring passes pull the share down and the mode stays on
     n = len(exp)
