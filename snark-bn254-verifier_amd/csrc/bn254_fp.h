@@ -442,6 +442,127 @@ BN_HD Fp fp_pow_bits(const Fp& a, const uint8_t* bits, int nbits) {  // bits[0] 
   }
   return acc;
 }
-BN_HD Fp fp_inv(const Fp& a) { return fp_pow_bits(fp_reduce(fp_norm(a)), BN_EXP_PM2_BITS, BN_EXP_PM2_NBITS); }  // 0 -> 0
+BN_HD Fp fp_inv_fermat(const Fp& a) { return fp_pow_bits(fp_reduce(fp_norm(a)), BN_EXP_PM2_BITS, BN_EXP_PM2_NBITS); }  // 0 -> 0
+
+// ---- inversion by the binary extended GCD with approximated operands (T. Pornin, "Optimized Binary GCD for Modular Inversion", 2020, algorithm 2,
+// with k = 30 so that its divisions by 2^(k-1) are shifts by one 29-bit digit).  Invariants a = u y / C, b = v y / C (mod p), a, b >= 0, start
+// (a, u, b, v) = (y, C, p, 0).  Each of the 18 outer rounds runs 29 steps of the binary GCD on 60-bit stand-ins for a and b -- their 29 low bits
+// and the 31 bits below the top bit of the larger (exact values once both fit 62 bits) -- which yields the update factors f, g with
+// |f| + |g| <= 2^29; the factors are then applied to the full numbers (one multiply-accumulate pass each, the quotient by 2^29 exact) and to
+// u, v modulo p (one Montgomery digit retired per round, the same -1/p mod 2^29 as fp_dot).  18 * 29 = 522 >= 2 * 254 - 1 steps, so b ends as
+// gcd(y, p) = 1 and v = C / y; with y = x R and C = R^2 that is the Montgomery form of 1 / x.  y = 0 leaves v = 0: the inverse of 0 is 0, as
+// with the Fermat form.  About 17 k instructions instead of the 70 k of x^(p-2) (253 squarings + 109 products); fixed iteration counts, no
+// data-dependent branch.
+BN_HD int bn_clz64(uint64_t x) {  // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clzll((long long)x);
+#else
+  return __builtin_clzll(x);
+#endif
+}
+BN_HD void fp_unsigned_digits(int32_t d[BN_NL], const int32_t* balanced) {  // value >= 0 in balanced digits -> digits in [0, 2^29)
+  int32_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < BN_NL; i++) { int32_t t = balanced[i] + cy; d[i] = t & (int32_t)BN_MASK; cy = t >> BN_LB; }
+}
+BN_HD Fp fp_inv(const Fp& x) {
+  const Fp y = fp_canon(x);
+  int32_t a[BN_NL], b[BN_NL], u[BN_NL], v[BN_NL];
+  fp_unsigned_digits(a, y.v);
+  {
+    int32_t pl[BN_NL];
+#pragma unroll
+    for (int i = 0; i < BN_NL; i++) pl[i] = bn_p_limb(i);
+    fp_unsigned_digits(b, pl);
+  }
+  {
+    const Fp c = fp_from_limbs(BN_R2);
+#pragma unroll
+    for (int i = 0; i < BN_NL; i++) { u[i] = c.v[i]; v[i] = 0; }
+  }
+#pragma unroll 1
+  for (int round = 0; round < 18; round++) {
+    // the three digits from the highest position where a or b is non-zero (positions 2..8); none: both numbers are below 2^58
+    int32_t ah = 0, am = 0, al = 0, bh = 0, bm = 0, bl = 0, low = 0;   // low: the position of *l is 0 (three digits are the whole number)
+    bool found = false;
+#pragma unroll
+    for (int i = BN_NL - 1; i >= 2; i--) {
+      const bool take = !found && ((a[i] | b[i]) != 0);
+      ah = take ? a[i] : ah; am = take ? a[i - 1] : am; al = take ? a[i - 2] : al;
+      bh = take ? b[i] : bh; bm = take ? b[i - 1] : bm; bl = take ? b[i - 2] : bl;
+      low = take ? (i == 2 ? 1 : 0) : low;
+      found = found || take;
+    }
+    const uint64_t hiA = ((uint64_t)(uint32_t)ah << BN_LB) | (uint32_t)am, hiB = ((uint64_t)(uint32_t)bh << BN_LB) | (uint32_t)bm;
+    const int len = 64 - bn_clz64(hiA | hiB | 1);                    // 30..58 when found
+    const int sh = len - 31;                                         // -1..27
+    const uint64_t topA = sh >= 0 ? (hiA >> (sh & 63)) : ((hiA << 1) | ((uint32_t)al >> 28));
+    const uint64_t topB = sh >= 0 ? (hiB >> (sh & 63)) : ((hiB << 1) | ((uint32_t)bl >> 28));
+    const uint64_t lowA = ((uint64_t)(uint32_t)a[1] << BN_LB) | (uint32_t)a[0], lowB = ((uint64_t)(uint32_t)b[1] << BN_LB) | (uint32_t)b[0];
+    // exact stand-ins when the numbers fit 62 bits: fewer than three digits, or three digits with a top digit below 2^4
+    const bool exact3 = found && low != 0 && len <= 33;
+    uint64_t A = !found ? lowA : exact3 ? ((hiA << BN_LB) | (uint32_t)al) : ((topA << BN_LB) | (uint32_t)a[0]);
+    uint64_t B = !found ? lowB : exact3 ? ((hiB << BN_LB) | (uint32_t)bl) : ((topB << BN_LB) | (uint32_t)b[0]);
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+#pragma unroll 1
+    for (int j = 0; j < BN_LB; j++) {
+      const bool odd = (A & 1) != 0;
+      const bool swap = odd && A < B;
+      const uint64_t tA = swap ? B : A, tB = swap ? A : B;
+      const int32_t tf0 = swap ? f1 : f0, tg0 = swap ? g1 : g0, tf1 = swap ? f0 : f1, tg1 = swap ? g0 : g1;
+      A = (tA - (odd ? tB : 0)) >> 1; B = tB;
+      f0 = tf0 - (odd ? tf1 : 0); g0 = tg0 - (odd ? tg1 : 0);
+      f1 = tf1 << 1; g1 = tg1 << 1;
+    }
+    // (a, b) <- (a f0 + b g0, a f1 + b g1) / 2^29, made non-negative by negating the number together with its factors
+    int32_t na[BN_NL], nb[BN_NL];
+    {
+      int64_t ca = (int64_t)a[0] * f0 + (int64_t)b[0] * g0, cb = (int64_t)a[0] * f1 + (int64_t)b[0] * g1;
+      ca >>= BN_LB; cb >>= BN_LB;                                    // exact: the low 29 bits are zero
+#pragma unroll
+      for (int i = 1; i < BN_NL; i++) {
+        ca += (int64_t)a[i] * f0 + (int64_t)b[i] * g0; cb += (int64_t)a[i] * f1 + (int64_t)b[i] * g1;
+        na[i - 1] = (int32_t)((uint32_t)ca & BN_MASK); nb[i - 1] = (int32_t)((uint32_t)cb & BN_MASK);
+        ca >>= BN_LB; cb >>= BN_LB;
+      }
+      na[BN_NL - 1] = (int32_t)ca; nb[BN_NL - 1] = (int32_t)cb;     // 0 or -1 (the numbers stay below 2^254)
+    }
+    const bool nega = na[BN_NL - 1] < 0, negb = nb[BN_NL - 1] < 0;
+    {
+      int32_t ba = 0, bb = 0;
+#pragma unroll
+      for (int i = 0; i < BN_NL; i++) {
+        const int32_t ta = -na[i] - ba, tb = -nb[i] - bb;
+        const int32_t da = i < BN_NL - 1 ? (ta & (int32_t)BN_MASK) : ta, db = i < BN_NL - 1 ? (tb & (int32_t)BN_MASK) : tb;
+        ba = i < BN_NL - 1 ? ((ta >> BN_LB) & 1) : 0; bb = i < BN_NL - 1 ? ((tb >> BN_LB) & 1) : 0;
+        a[i] = nega ? da : na[i]; b[i] = negb ? db : nb[i];
+      }
+    }
+    f0 = nega ? -f0 : f0; g0 = nega ? -g0 : g0; f1 = negb ? -f1 : f1; g1 = negb ? -g1 : g1;
+    // (u, v) <- (u f0 + v g0, u f1 + v g1) / 2^29 mod p
+    {
+      int64_t cu = (int64_t)u[0] * f0 + (int64_t)v[0] * g0, cv = (int64_t)u[0] * f1 + (int64_t)v[0] * g1;
+      const int32_t qu = bn_sext29((uint32_t)cu * BN_PINV), qv = bn_sext29((uint32_t)cv * BN_PINV);
+      cu += (int64_t)qu * bn_p_limb(0); cv += (int64_t)qv * bn_p_limb(0);
+      cu >>= BN_LB; cv >>= BN_LB;                                    // exact
+      int32_t nu[BN_NL], nv[BN_NL];
+#pragma unroll
+      for (int i = 1; i < BN_NL; i++) {
+        cu += (int64_t)u[i] * f0 + (int64_t)v[i] * g0 + (int64_t)qu * bn_p_limb(i);
+        cv += (int64_t)u[i] * f1 + (int64_t)v[i] * g1 + (int64_t)qv * bn_p_limb(i);
+        nu[i - 1] = (int32_t)((uint32_t)cu & BN_MASK); nv[i - 1] = (int32_t)((uint32_t)cv & BN_MASK);
+        cu >>= BN_LB; cv >>= BN_LB;
+      }
+      nu[BN_NL - 1] = (int32_t)cu; nv[BN_NL - 1] = (int32_t)cv;
+#pragma unroll
+      for (int i = 0; i < BN_NL; i++) { u[i] = nu[i]; v[i] = nv[i]; }
+    }
+  }
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < BN_NL; i++) r.v[i] = v[i];
+  BN_SETB(r, 32.0, 1.0);     // |u|, |v| grow by at most p / 2 + ... per round: below 12 p after 18 rounds
+  return fp_reduce(fp_norm(r));
+}
 
 }  // namespace bn254

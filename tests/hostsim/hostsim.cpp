@@ -36,7 +36,7 @@ static void fp12_out(uint8_t* b, const Fp12& a) {
 }
 
 extern "C" {
-// op: 0 add 1 sub 2 mul 3 inv 5 neg 6 sqr 7 reduce(canon) 8 lincomb_reduce(9a - b) 9 is_zero -> o[31]
+// op: 0 add 1 sub 2 mul 3 inv (binary GCD) 4 inv (Fermat) 5 neg 6 sqr 7 reduce(canon) 8 lincomb_reduce(9a - b) 9 is_zero -> o[31]
 void hs_fp_op(int op, uint8_t* o, const uint8_t* a, const uint8_t* b, int inflate) {
   Fp x = fp_in(a, inflate), y = fp_in(b, -inflate), r = fp_zero();
   switch (op) {
@@ -44,6 +44,7 @@ void hs_fp_op(int op, uint8_t* o, const uint8_t* a, const uint8_t* b, int inflat
     case 1: r = fp_sub(x, y); break;
     case 2: r = fp_mul(x, y); break;
     case 3: r = fp_inv(x); break;
+    case 4: r = fp_inv_fermat(x); break;
     case 5: r = fp_neg(x); break;
     case 6: r = fp_sqr(x); break;
     case 7: r = fp_reduce(x); break;

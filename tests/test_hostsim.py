@@ -34,7 +34,16 @@ def test_fp(hostsim):
             assert fp(8, a, b, inf) == (9 * a - b) % P
             assert fp(9, a, 0, inf) == (1 if a % P == 0 else 0)
     for a in vals[:25]:
-        assert fp(3, a) == (pow(a, -1, P) if a else 0)
+        assert fp(3, a) == fp(4, a) == (pow(a, -1, P) if a else 0)
+    # the binary-GCD inversion (bn254_fp.h::fp_inv): every operand size its digit scan and its exact / approximated stand-ins distinguish
+    # (below 2^58, three digits with a small top digit, long), lazily reduced inputs, values next to 0 and p
+    inv_vals = [(1 << k) + d for k in (28, 29, 30, 57, 58, 59, 60, 61, 62, 63, 86, 87, 88, 116, 145, 232, 253) for d in (-1, 0, 1, 12345)]
+    inv_vals += [random.getrandbits(k) for k in range(1, 255) for _ in range(4)] + [P - 1 - random.getrandbits(k) for k in range(1, 200, 3)]
+    inv_vals += [random.randrange(P) for _ in range(1500)]
+    for i, a in enumerate(inv_vals):
+        a %= P
+        for inf in ((0, 1, 3) if i < 300 else (0,)):
+            assert fp(3, a, 0, inf) == (pow(a, -1, P) if a else 0), hex(a)
 
 
 def test_fp2_fp12(hostsim, O):

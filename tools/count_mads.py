@@ -91,6 +91,7 @@ def short(sym):
 # ---- loop models: a loop is recognised by the multiply-adds of one iteration --------------------------------------------------------------------
 FP_SQR, FP_MUL = 126, 162            # fp_sqr: 45 + 81; fp_mul: 81 + 81 (bn254_fp.h)
 INV_SET_BITS = PM2_BITS.count("1") - 1
+INV_GCD_ROUND_MADS = 90               # fp_inv: (a, b) and (u, v) updates of one round: 4 x 18 digit products + 2 x 9 for the Montgomery digit
 N_PUBLIC = 2                          # BASELINE configs[2]
 TRIPS_BY_KERNEL = {                   # loops whose trip count is a launch parameter: (kernel, mads of one iteration) -> trips, why
     ("k_g16_prepare", "window_outer"): (N_PUBLIC, "one pass per public input"),
@@ -147,6 +148,13 @@ def model_kernel(name, ins):
         elif name == "k_f12_cyclo_sqr_n":
             t, why = TRIPS_BY_KERNEL[(name, "cyclo_sqr")]
             weight_ranges.append((h, latches[-1], float(t))); notes.append("squaring loop x%.3f (%d mads per squaring): %s" % (t, c, why))
+        elif c == INV_GCD_ROUND_MADS and not inner:
+            # fp_inv (bn254_fp.h): 18 rounds; per round the 29-step stand-in loop (no multiply-adds: only the other instruction classes see it)
+            weight_ranges.append((h, latches[-1], 18.0))
+            for h2, l2 in loop_groups(ins, mads):
+                if h < h2 and l2[-1] < latches[-1] and count_in(mads, h2, l2[-1]) == 0:
+                    weight_ranges.append((h2, l2[-1], 29.0))
+            notes.append("binary-GCD inversion: 18 rounds of 29 steps (%d multiply-adds per round)" % c)
         elif own > 0:
             unmodelled.append("loop +0x%x..+0x%x (%d mads, %d of its own) counted once" % (h - ins[0][0], latches[-1] - ins[0][0], c, own))
     total = 0.0
