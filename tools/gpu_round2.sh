@@ -38,7 +38,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU SQ_WAVES -
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rlc -o run -- python3 $R/tools/bench_rlc.py --batch-log2 20 --steps 2 --invalid-every 0 > $O/rlc_prof.txt 2> $O/rlc_prof.err || fail "rocprof rlc" $O/rlc_prof.err
 find $O -name "*kernel_trace.csv" -size +30M -delete
 cd $R
-BN254_PLONK_TIMING=1 python tools/bench_plonk.py > $O/plonk.json 2> $O/plonk.err || fail plonk $O/plonk.err
+python tools/bench_plonk.py > $O/plonk.json 2> $O/plonk.err || fail plonk $O/plonk.err
 cut -c1-200 $O/plonk.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk -o run -- python3 $R/tools/bench_plonk.py --steps 3 > $O/prof_plonk.json 2> $O/prof_plonk.err || fail "rocprof plonk" $O/prof_plonk.err

@@ -124,11 +124,16 @@ for a_, b_ in (("small_coop12.txt", "_small_batches_coop12.txt"), ("small_coop.t
     p = os.path.join(root, src, a_)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, rnd + b_))
-p = os.path.join(root, src, "plonk.err")
+p = os.path.join(root, src, "plonk.json")
 if os.path.exists(p):
-    lines_ = [l for l in open(p) if l.startswith("plonk sub-batch")]
-    if lines_:
-        open(os.path.join(out, rnd + "_plonk_stage_times.txt"), "w").write("".join(lines_))
+    try:
+        st_ = json.load(open(p)).get("stages_ms")
+        if st_:
+            open(os.path.join(out, rnd + "_plonk_stage_times.txt"), "w").write(
+                "# tools/bench_plonk.py, batch 4096: durations (ms) of the last batch (bn254_plonk_last_timing: host stages and walls by the host clock, kernels by HIP events)\n"
+                + "".join("%-28s %.3f\n" % (k, v) for k, v in st_.items()))
+    except Exception:
+        pass
 
 # 64-bit integer VALU instructions per wavefront of the cooperative kernels (check of tools/count_mads.py's call-graph model)
 cc = {}
