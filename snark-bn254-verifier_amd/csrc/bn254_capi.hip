@@ -14,6 +14,9 @@
 #include <sys/random.h>
 #include <atomic>
 #include <thread>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <chrono>
 #include <cstdio>
 
@@ -165,6 +168,7 @@ struct PlonkCtx {
   hipStream_t stream = nullptr, aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t tk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // timing: digest MSM, scalar multiplications of stage 2, pairing check
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
+  std::vector<PlonkWork> work;        // host scratch per proof (kept across calls)
   int32_t *ws = nullptr, *part = nullptr;
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
@@ -239,13 +243,56 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   c.cap = need;
   return BN254_OK;
 }
+// Host threads of the PlonK stages: one process-wide pool, started on first use.  (Spawning and joining 16 threads costs ~0.4 ms, and a batch
+// has two host stages: 8 % of a 4096-proof batch.)  run(n, fn) executes fn(0) on the caller and fn(1..n-1) on pool threads and returns when all
+// are done; jobs of concurrent callers (the sub-batch workers of a large batch, other keys) share the queue.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool pool([] { unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; return hw > 32 ? 32u : hw; }());
+    return pool;
+  }
+  void run(unsigned n, const std::function<void(unsigned)>& fn) {
+    if (n <= 1) { fn(0); return; }
+    struct Job { std::mutex m; std::condition_variable c; unsigned left; } job;
+    job.left = n - 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (unsigned t = 1; t < n; t++)
+        q_.emplace_back([&job, &fn, t] { fn(t); std::lock_guard<std::mutex> l(job.m); if (--job.left == 0) job.c.notify_one(); });
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(job.m);
+    job.c.wait(lk, [&] { return job.left == 0; });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+
+ private:
+  explicit HostPool(unsigned n) { for (unsigned i = 0; i < n; i++) th_.emplace_back([this] { loop(); }); }
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;
+        f = std::move(q_.front()); q_.pop_front();
+      }
+      f();
+    }
+  }
+  std::mutex mu_; std::condition_variable cv_; std::deque<std::function<void()>> q_; std::vector<std::thread> th_; bool stop_ = false;
+};
 template <class F> static void plonk_parallel(size_t n, unsigned hw, F&& f) {
   if (hw == 0) hw = 1;
   if (n < 64) hw = 1;
   if (hw == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < hw; t++) th.emplace_back([&, t]() { for (size_t i = t; i < n; i += hw) f(i); });
-  for (auto& x : th) x.join();
+  HostPool::get().run(hw, [&](unsigned t) { for (size_t i = t; i < n; i += hw) f(i); });
 }
 
 
@@ -692,9 +739,10 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto t0 = now();
-  std::vector<PlonkWork> work(m);
-  memset(c.h_terms, 0, m * (size_t)T1 * sizeof(MsmTerm));
-  memset(c.h_flags, 0, m * (size_t)T1);
+  // per-proof scratch of the context (every field a stage reads is written by an earlier stage of the same call: no clearing needed); the term
+  // and flag rows are cleared by the host thread that fills them
+  if (c.work.size() < m) c.work.resize(m);
+  std::vector<PlonkWork>& work = c.work;
   // The KZG batching scalar of every proof: fresh, uniform and unpredictable to the prover, as the reference draws it
   // (Fr::random(&mut OsRng), plonk/kzg.rs:149-154).  It MUST be secret until the proof is fixed: the two opening quotients are bound by
   // no transcript, so a prover who knows lambda can shift them by (lambda D, -D) and cancel a wrong evaluation
@@ -717,6 +765,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
       FrM run = F.one;
       size_t k = 0;
       for (size_t i = t; i < m; i += hw, k++) {
+        memset(&c.h_terms[i * T1], 0, (size_t)T1 * sizeof(MsmTerm)); memset(&c.h_flags[i * T1], 0, (size_t)T1);
         work[i].lambda = F.from_be_reduce(rnd.data() + 48 * i, 48);
         work[i].status = s1[k].a(key, proofs + i * proof_stride, proof_stride, public_inputs + i * n_public * 32, n_public, work[i]);
         pre[k] = run;
@@ -731,7 +780,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
       }
     };
     if (hw == 1) slice(0);
-    else { std::vector<std::thread> th; for (unsigned t = 0; t < hw; t++) th.emplace_back(slice, t); for (auto& x : th) x.join(); }
+    else HostPool::get().run(hw, [&](unsigned t) { slice(t); });
   }
   auto t1_ = now();
   // ---- the linearised-polynomial digest on the GPU, back to the host for the folding transcript
@@ -747,9 +796,8 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   auto t2_ = now();
   // ---- stage 2 on the host threads: the terms of P0 (T2 of them) and of P1 (2) side by side, so that ONE launch does all scalar multiplications
   const int TT = T2 + 2;
-  memset(c.h_terms, 0, m * (size_t)TT * sizeof(MsmTerm));
-  memset(c.h_flags, 0, m * (size_t)TT);
   plonk_parallel(m, host_threads, [&](size_t i) {
+    memset(&c.h_terms[i * TT], 0, (size_t)TT * sizeof(MsmTerm)); memset(&c.h_flags[i * TT], 0, (size_t)TT);
     if (work[i].status == PL_OK) {
       work[i].pr.raw = proofs + i * proof_stride;
       plonk_stage2(key, proofs + i * proof_stride, work[i], &c.h_words[i * 16], c.h_inf[i] != 0, &c.h_terms[i * TT], &c.h_flags[i * TT], &c.h_terms[i * TT + T2]);
