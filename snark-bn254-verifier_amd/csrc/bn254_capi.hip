@@ -746,12 +746,17 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   // The KZG batching scalar of every proof: fresh, uniform and unpredictable to the prover, as the reference draws it
   // (Fr::random(&mut OsRng), plonk/kzg.rs:149-154).  It MUST be secret until the proof is fixed: the two opening quotients are bound by
   // no transcript, so a prover who knows lambda can shift them by (lambda D, -D) and cancel a wrong evaluation
-  // (tests/test_oracle_golden.py::test_kzg_batching_scalar_must_be_unpredictable).  48 bytes of getrandom(2) reduced mod r per proof.
-  std::vector<uint8_t> rnd(m * 48);
-  for (size_t got = 0; got < rnd.size();) {
-    ssize_t k = getrandom(rnd.data() + got, rnd.size() - got, 0);
-    if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
-    got += (size_t)k;
+  // (tests/test_oracle_golden.py::test_kzg_batching_scalar_must_be_unpredictable).  A ChaCha20 key and nonce from getrandom(2) per call;
+  // proof i takes the 384 bits of blocks 3i .. 3i+2 reduced mod r (the host threads expand them: 192 KB of getrandom per 4096 proofs took 0.7 ms).
+  ChaChaKey lam_key;
+  {
+    uint8_t seed[44];
+    for (size_t got = 0; got < sizeof seed;) {
+      ssize_t k = getrandom(seed + got, sizeof seed - got, 0);
+      if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
+      got += (size_t)k;
+    }
+    memcpy(lam_key.k, seed, 32); memcpy(lam_key.nonce, seed + 32, 12);
   }
   // ---- stage 1 on the host threads.  Every thread runs the first half of the stage for its proofs, inverts the products of their denominators
   // with ONE field inversion (Montgomery's trick across proofs; the inversion is a third of the stage's time per proof) and runs the second half.
@@ -766,7 +771,11 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
       size_t k = 0;
       for (size_t i = t; i < m; i += hw, k++) {
         memset(&c.h_terms[i * T1], 0, (size_t)T1 * sizeof(MsmTerm)); memset(&c.h_flags[i * T1], 0, (size_t)T1);
-        work[i].lambda = F.from_be_reduce(rnd.data() + 48 * i, 48);
+        {
+          uint32_t lw[12];
+          for (int j = 0; j < 3; j++) chacha20_block4(lw + 4 * j, lam_key, (uint32_t)(3 * i + j));
+          work[i].lambda = F.from_be_reduce((const uint8_t*)lw, 48);
+        }
         work[i].status = s1[k].a(key, proofs + i * proof_stride, proof_stride, public_inputs + i * n_public * 32, n_public, work[i]);
         pre[k] = run;
         if (work[i].status == PL_OK) run = F.mul(run, s1[k].acc);      // acc != 0: a product of non-zero denominators

@@ -176,11 +176,12 @@ def test_raw_proof_writer_reproduces_reference_fixtures(pkg, fixtures):
 
 
 def test_no_constant_kzg_batching_scalar_in_the_product():
-    """The PlonK path draws its batching scalars from getrandom(2); no literal scalar may come back."""
+    """The PlonK path keys its batching scalars with getrandom(2) on every call (a ChaCha20 key and nonce, expanded per proof); no literal
+    scalar may come back."""
     import re
     src = open(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", "bn254_capi.hip")).read()
     body = src[src.index("static int plonk_run("):src.index("int bn254_plonk_verify(const uint8_t* proof")]
-    assert "getrandom(" in body and "from_be_reduce(rnd.data()" in body
+    assert "getrandom(seed" in body and "chacha20_block4(lw" in body and "from_be_reduce((const uint8_t*)lw, 48)" in body
     assert not re.search(r"lambda\s*=\s*fr_ctx\(\)\.from_u64", src)
 
 
