@@ -229,7 +229,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   c.cap = 0;
   const size_t tmax = (size_t)plonk_stage2_terms(pvk->key) + 2 > (size_t)plonk_stage1_terms(pvk->key) ? plonk_stage2_terms(pvk->key) + 2 : plonk_stage1_terms(pvk->key);
   HIPCK(hipMalloc((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF));
-  HIPCK(hipMalloc((void**)&c.part, need * tmax * 27 * sizeof(int32_t)));
+  HIPCK(hipMalloc((void**)&c.part, need * tmax * 2 * 27 * sizeof(int32_t)));     // x 2: the split scalar-multiplication launch writes two partial results per term
   HIPCK(hipMalloc((void**)&c.terms, need * tmax * sizeof(MsmTerm)));
   HIPCK(hipMalloc((void**)&c.flags, need * tmax));
   HIPCK(hipMalloc((void**)&c.words, need * 16 * sizeof(uint32_t)));
@@ -823,8 +823,8 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipEventRecord(c.tk[2], c.stream));
   e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.stream);
   HIPCK(hipEventRecord(c.tk[3], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
-  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, TT, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[4], c.stream));
   e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);

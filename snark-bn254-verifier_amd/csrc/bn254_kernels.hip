@@ -414,10 +414,17 @@ k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32
 // lane g = t * n + i: term t of item i.  terms[g * 26]: 18 digits of the affine point, 8 little-endian words of the GLV-decomposed scalar.
 // Joint double-and-add with the complete formulas (bn254_rlc.h::g1_mul_glv_w): data-independent control, no special cases.
 // flags[g] bit 0: the point is the identity (the term contributes nothing), bits 1 / 2: signs.  Partial results: part[(t * 27 + k) * n + i].
+// SPLIT (small batches, where the launch lasts as long as one lane's chain of 128 double-and-add steps): two lanes per term -- the low and the
+// high 64 joint bit positions; the high lane doubles its result 64 more times (chain: 64 steps + 64 doublings, 0.69 of the unsplit chain) and writes
+// it n_terms rows further, where k_g1_sum_affine picks it up (`second` below).
+template <bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  if (g >= n * (uint32_t)n_terms) return;
+  const uint32_t g0 = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lanes = n * (uint32_t)n_terms;
+  if (g0 >= (SPLIT ? 2u : 1u) * lanes) return;
+  const uint32_t half = SPLIT ? (g0 >= lanes ? 1u : 0u) : 0u;
+  const uint32_t g = g0 - half * lanes;
   const uint32_t t = g / n, i = g - t * n;
   const int32_t* e = terms + ((size_t)i * n_terms + t) * 26;
   G1Aff P;
@@ -434,8 +441,17 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
 #pragma unroll
     for (int k = 0; k < 4; k++) { k1[k] = 0; k2[k] = 0; }
   }
-  G1Proj acc = g1_mul_glv_w<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0);
-  int32_t* o = part + (size_t)t * 27 * n + i;
+  G1Proj acc;
+  if constexpr (SPLIT) {
+    uint32_t h1[2] = {half ? k1[2] : k1[0], half ? k1[3] : k1[1]}, h2[2] = {half ? k2[2] : k2[0], half ? k2[3] : k2[1]};
+    acc = g1_mul_glv_w<2>(P, h1, (fl & 2) != 0, h2, (fl & 4) != 0);
+    if (half) {                                  // wave-uniform except in the one wavefront that straddles the two halves
+      for (int d = 0; d < 64; d++) acc = g1_dbl(acc);
+    }
+  } else {
+    acc = g1_mul_glv_w<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0);
+  }
+  int32_t* o = part + ((size_t)t + (size_t)half * (size_t)n_terms) * 27 * n + i;
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
 }
@@ -443,12 +459,14 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
 // flag byte (1 = identity) per item, for the host.  Otherwise the point goes to workspace elements (e_x, e_x + 1) as (x, y) or
 // (0, 1) for the identity, whose flag bit `inf_bit` is OR-ed into the (pending) status byte.
 __global__ void __launch_bounds__(256, 2)
-k_g1_sum_affine(const int32_t* __restrict__ part, int first, int n_terms, uint32_t n, uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf,
-                int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit) {
+k_g1_sum_affine(const int32_t* __restrict__ part, int first, int n_terms, int second /* 0, or the row distance of the split launch's high halves */, uint32_t n,
+                uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf, int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t ii = i < n ? i : n - 1;
   G1Proj L = g1_identity();
-  for (int c = first; c < first + n_terms; c++) {
+  const int total = second ? 2 * n_terms : n_terms;
+  for (int cc = 0; cc < total; cc++) {
+    const int c = cc < n_terms ? first + cc : first + (cc - n_terms) + second;
     const int32_t* o = part + (size_t)c * 27 * n + ii;
     G1Proj q;
 #pragma unroll
@@ -970,21 +988,38 @@ hipError_t bn254_launch_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n,
 }
 
 // ---- PlonK: G1 MSM stages and the two-fixed-pair pairing check -----------------------------------------------------------------------
+// small launches are split over two lanes per term (k_g1_scalar_mul<true>): below one wavefront per SIMD the launch time is one lane's chain.
+// Only while the split launch itself stays within one wavefront per SIMD (65536 lanes): two wavefronts that share a SIMD slow each other by about
+// 1.6 (they are not pure multiply-add streams), which is more than the 0.69 the shorter chain gains -- measured at 4096 PlonK proofs
+// (106 k lanes): 1.68 ms split against 1.45 ms.
+bool bn254_g1_msm_split(size_t n, int n_terms) {
+  static const int mode = [] { const char* e = getenv("BN254_MSM_SPLIT"); return e ? atoi(e) : -1; }();   // 0 / 1 force, default by size
+  if (mode >= 0) return mode != 0;
+  return n * (size_t)n_terms * 2 <= 65536;
+}
+static void launch_scalar_mul(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, bool split, hipStream_t s) {
+  const size_t lanes = n * (size_t)n_terms * (split ? 2 : 1);
+  const unsigned g1 = (unsigned)((lanes + 255) / 256);
+  if (split) hipLaunchKernelGGL(k_g1_scalar_mul<true>, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
+  else hipLaunchKernelGGL(k_g1_scalar_mul<false>, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
+}
+// part: 2 * n_terms * 27 * n dwords (the split launch writes the high halves n_terms rows after the low ones)
 hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
-  unsigned g1 = (unsigned)((n * (size_t)n_terms + 255) / 256);
-  hipLaunchKernelGGL(k_g1_scalar_mul, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
+  const bool split = bn254_g1_msm_split(n, n_terms);
+  launch_scalar_mul(terms, flags, n, n_terms, part, split, s);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, split ? n_terms : 0, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
   return hipGetLastError();
 }
-// the two halves of the above separately: ONE scalar-multiplication launch can feed several sums (PlonK: P0 and P1 of the KZG check)
+// the two halves of the above separately: ONE scalar-multiplication launch can feed several sums (PlonK: P0 and P1 of the KZG check); the sums
+// are told the launch's term count so that they find the high halves of a split launch
 hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, hipStream_t s) {
-  unsigned g1 = (unsigned)((n * (size_t)n_terms + 255) / 256);
-  hipLaunchKernelGGL(k_g1_scalar_mul, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
+  launch_scalar_mul(terms, flags, n, n_terms, part, bn254_g1_msm_split(n, n_terms), s);
   return hipGetLastError();
 }
-hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, part, first, count, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status, e_x, inf_bit);
+hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
+  const bool split = bn254_g1_msm_split(n, launch_terms);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, part, first, count, split ? launch_terms : 0, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status, e_x, inf_bit);
   return hipGetLastError();
 }
 // prod_t e(P_t, Q_t) == 1 for two key-side G2 points (line tables tab0, tab1) and per-item G1 points already in the workspace

@@ -139,8 +139,12 @@ def model_kernel(name, ins):
         elif 1700 <= c <= 1900 and inner:
             t, why = TRIPS_BY_KERNEL.get((name, "window_outer"), (1, "UNMODELLED outer window loop"))
             weight_ranges.append((h, latches[-1], float(t))); notes.append("outer window loop x%g: %s" % (t, why))
+        elif name == "k_g1_scalar_mul" and 1150 <= c <= 1350 and not inner:
+            weight_ranges.append((h, latches[-1], 64.0)); notes.append("64 doublings of the high half (%d mads each; split launch, high lanes only)" % c)
         elif 4300 <= c <= 4600 or (name in ("k_rlc_scale", "k_g1_scalar_mul") and 3000 <= c <= 3400):
             t, why = TRIPS_BY_KERNEL.get((name, "scalar_mul"), (1, "UNMODELLED scalar multiplication loop"))
+            if name == "k_g1_scalar_mul" and any(1150 <= g[2] <= 1350 for g in groups):
+                t, why = 64, "split launch: 64 joint bit positions per lane (low / high half of the GLV halves)"
             weight_ranges.append((h, latches[-1], float(t))); notes.append("2-bit window loop x%g (%d mads per window): %s" % (t, c, why))
         elif c == 224:
             t, why = TRIPS_BY_KERNEL.get((name, "fr_products"), (1, "UNMODELLED"))
@@ -371,6 +375,10 @@ def main():
             e["mads_per_proof_launch"] = (64 * a["mads_per_proof_launch"] + b["mads_per_proof_launch"]) / 65.0
             e["model"] = "64 launches with the squaring of f (%d mads) + the first step without (%d)" % (a["static_mads"], b["static_mads"])
             kernels[name] = e
+        elif name == "k_g1_scalar_mul":
+            # template instances: <false> one lane per term; <true> two lanes per term (the count is the HIGH lane's chain, the launch's duration)
+            for e in es:
+                kernels[name + ("_split" if "split launch" in e["model"] else "")] = e
         else:
             for i, e in enumerate(es):
                 kernels["%s#%d" % (name, i)] = e
