@@ -169,7 +169,7 @@ struct PlonkCtx {
   hipEvent_t tk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // timing: digest MSM, scalar multiplications of stage 2, pairing check
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
   std::vector<PlonkWork> work;        // host scratch per proof (kept across calls)
-  int32_t *ws = nullptr, *part = nullptr;
+  int32_t *ws = nullptr, *part = nullptr, *glv_tab = nullptr;   // glv_tab: scratch of the two-bit-window scalar multiplications (small batches)
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
   MsmTerm* h_terms = nullptr; uint8_t *h_flags = nullptr, *h_status = nullptr, *h_inf = nullptr; uint32_t* h_words = nullptr;
@@ -186,7 +186,7 @@ struct bn254_plonk_pvk {
   mutable std::map<int, PlonkDev> dev;
 };
 static void plonk_ctx_free(PlonkCtx& c) {
-  void* ptrs[] = {c.ws, c.part, c.terms, c.flags, c.words, c.inf, c.status};
+  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status};
   for (auto q : ptrs) if (q) (void)hipFree(q);
   void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words};
   for (auto q : hp) if (q) (void)hipHostFree(q);
@@ -222,14 +222,15 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   }
   size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
   if (need <= c.cap) return BN254_OK;
-  void* ptrs[] = {c.ws, c.part, c.terms, c.flags, c.words, c.inf, c.status};
+  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status};
   for (auto q : ptrs) if (q) (void)hipFree(q);
   void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words};
   for (auto q : hp) if (q) (void)hipHostFree(q);
-  c.cap = 0;
+  c.cap = 0; c.glv_tab = nullptr;
   const size_t tmax = (size_t)plonk_stage2_terms(pvk->key) + 2 > (size_t)plonk_stage1_terms(pvk->key) ? plonk_stage2_terms(pvk->key) + 2 : plonk_stage1_terms(pvk->key);
   HIPCK(hipMalloc((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF));
   HIPCK(hipMalloc((void**)&c.part, need * tmax * 2 * 27 * sizeof(int32_t)));     // x 2: the split scalar-multiplication launch writes two partial results per term
+  HIPCK(hipMalloc((void**)&c.glv_tab, (size_t)65536 * G1_GLV_TAB_BYTES_PER_LANE));   // 117 MB: the launches that use it have at most 65536 lanes
   HIPCK(hipMalloc((void**)&c.terms, need * tmax * sizeof(MsmTerm)));
   HIPCK(hipMalloc((void**)&c.flags, need * tmax));
   HIPCK(hipMalloc((void**)&c.words, need * 16 * sizeof(uint32_t)));
@@ -796,7 +797,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)T1, hipMemcpyHostToDevice, c.stream));   // GLV signs (bn254_plonk.hpp::put_term)
   HIPCK(hipEventRecord(c.tk[0], c.stream));
-  hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
+  hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_tab, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[1], c.stream));
   HIPCK(hipMemcpyAsync(c.h_words, c.words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
@@ -821,7 +822,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * TT * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)TT, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipEventRecord(c.tk[2], c.stream));
-  e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.stream);
+  e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_tab, c.stream);
   HIPCK(hipEventRecord(c.tk[3], c.stream));
   if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
   if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, TT, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);

@@ -83,9 +83,11 @@ struct RlcLaunchArgs {
 hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, hipStream_t s);
 hipError_t bn254_launch_gather_rows(uint8_t* dst, const uint8_t* src, size_t src_stride, uint32_t row_bytes, const uint32_t* idx, uint32_t m, hipStream_t s);
 hipError_t bn254_launch_scatter_status(uint8_t* status, const uint8_t* fb_status, const uint32_t* idx, uint32_t m, hipStream_t s);
-hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
+#define G1_GLV_TAB_BYTES_PER_LANE (16 * 28 * 4)
+size_t bn254_g1_msm_tab_lanes(size_t n, int n_terms);   // lanes of scratch (G1_GLV_TAB_BYTES_PER_LANE each) the launch can use for the two-bit-window form; 0: not used
+hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, uint32_t* out_words,
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
-hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, hipStream_t s);
+hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, hipStream_t s);
 hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
 bool bn254_g1_msm_split(size_t n, int n_terms);   // the scalar-multiplication launch uses two lanes per term (part needs 2 * n_terms rows)
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,

@@ -417,9 +417,33 @@ k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32
 // SPLIT (small batches, where the launch lasts as long as one lane's chain of 128 double-and-add steps): two lanes per term -- the low and the
 // high 64 joint bit positions; the high lane doubles its result 64 more times (chain: 64 steps + 64 doublings, 0.69 of the unsplit chain) and writes
 // it n_terms rows further, where k_g1_sum_affine picks it up (`second` below).
-template <bool SPLIT>
+// W2 (the same small launches): two bits of each half per step from a 15-entry table the lane builds in its own 1792 bytes of `glv_tab`
+// (bn254_rlc.h::g1_mul_glv_w2): 0.75 of the chain.
+struct DevGlvTab {
+  int32_t* base;   // this lane's 16 x 28 dwords
+  __device__ __forceinline__ void put(int i, const G1Proj& p) const {
+    const Fp x = fp_reduce(p.x), y = fp_reduce(p.y), z = fp_reduce(p.z);
+    int4* q = (int4*)(base + i * 28);
+    q[0] = make_int4(x.v[0], x.v[1], x.v[2], x.v[3]); q[1] = make_int4(x.v[4], x.v[5], x.v[6], x.v[7]); q[2] = make_int4(x.v[8], y.v[0], y.v[1], y.v[2]);
+    q[3] = make_int4(y.v[3], y.v[4], y.v[5], y.v[6]); q[4] = make_int4(y.v[7], y.v[8], z.v[0], z.v[1]); q[5] = make_int4(z.v[2], z.v[3], z.v[4], z.v[5]);
+    q[6] = make_int4(z.v[6], z.v[7], z.v[8], 0);
+  }
+  __device__ __forceinline__ G1Proj get(uint32_t i) const {
+    const int4* q = (const int4*)(base + i * 28);
+    const int4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+    G1Proj p;
+    p.x.v[0] = a.x; p.x.v[1] = a.y; p.x.v[2] = a.z; p.x.v[3] = a.w; p.x.v[4] = b.x; p.x.v[5] = b.y; p.x.v[6] = b.z; p.x.v[7] = b.w; p.x.v[8] = c.x;
+    p.y.v[0] = c.y; p.y.v[1] = c.z; p.y.v[2] = c.w; p.y.v[3] = d.x; p.y.v[4] = d.y; p.y.v[5] = d.z; p.y.v[6] = d.w; p.y.v[7] = e.x; p.y.v[8] = e.y;
+    p.z.v[0] = e.z; p.z.v[1] = e.w; p.z.v[2] = f.x; p.z.v[3] = f.y; p.z.v[4] = f.z; p.z.v[5] = f.w; p.z.v[6] = g.x; p.z.v[7] = g.y; p.z.v[8] = g.z;
+    BN_SETB(p.x, 1.01, 0.5); BN_SETB(p.y, 1.01, 0.5); BN_SETB(p.z, 1.01, 0.5);
+    return p;
+  }
+  __device__ __forceinline__ void fence() const { __threadfence_block(); }
+};
+#define G1_GLV_TAB_DWORDS (16 * 28)
+template <bool SPLIT, bool W2>
 __global__ void __launch_bounds__(256, 2)
-k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part) {
+k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part, int32_t* glv_tab) {
   const uint32_t g0 = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lanes = n * (uint32_t)n_terms;
   if (g0 >= (SPLIT ? 2u : 1u) * lanes) return;
@@ -444,12 +468,14 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
   G1Proj acc;
   if constexpr (SPLIT) {
     uint32_t h1[2] = {half ? k1[2] : k1[0], half ? k1[3] : k1[1]}, h2[2] = {half ? k2[2] : k2[0], half ? k2[3] : k2[1]};
-    acc = g1_mul_glv_w<2>(P, h1, (fl & 2) != 0, h2, (fl & 4) != 0);
+    if constexpr (W2) { DevGlvTab tab{glv_tab + (size_t)g0 * G1_GLV_TAB_DWORDS}; acc = g1_mul_glv_w2<2>(P, h1, (fl & 2) != 0, h2, (fl & 4) != 0, tab); }
+    else acc = g1_mul_glv_w<2>(P, h1, (fl & 2) != 0, h2, (fl & 4) != 0);
     if (half) {                                  // wave-uniform except in the one wavefront that straddles the two halves
       for (int d = 0; d < 64; d++) acc = g1_dbl(acc);
     }
   } else {
-    acc = g1_mul_glv_w<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0);
+    if constexpr (W2) { DevGlvTab tab{glv_tab + (size_t)g0 * G1_GLV_TAB_DWORDS}; acc = g1_mul_glv_w2<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0, tab); }
+    else acc = g1_mul_glv_w<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0);
   }
   int32_t* o = part + ((size_t)t + (size_t)half * (size_t)n_terms) * 27 * n + i;
 #pragma unroll
@@ -997,24 +1023,33 @@ bool bn254_g1_msm_split(size_t n, int n_terms) {
   if (mode >= 0) return mode != 0;
   return n * (size_t)n_terms * 2 <= 65536;
 }
-static void launch_scalar_mul(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, bool split, hipStream_t s) {
+// the two-bit-window form needs G1_GLV_TAB_BYTES_PER_LANE of scratch per lane and pays only where a lane's chain is the launch time
+size_t bn254_g1_msm_tab_lanes(size_t n, int n_terms) {
+  static const int mode = [] { const char* e = getenv("BN254_MSM_W2"); return e ? atoi(e) : 1; }();
+  const size_t lanes = n * (size_t)n_terms * (bn254_g1_msm_split(n, n_terms) ? 2 : 1);
+  return (mode != 0 && lanes <= 65536) ? lanes : 0;
+}
+static void launch_scalar_mul(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, bool split, hipStream_t s) {
   const size_t lanes = n * (size_t)n_terms * (split ? 2 : 1);
   const unsigned g1 = (unsigned)((lanes + 255) / 256);
-  if (split) hipLaunchKernelGGL(k_g1_scalar_mul<true>, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
-  else hipLaunchKernelGGL(k_g1_scalar_mul<false>, dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part);
+  const bool w2 = glv_tab != nullptr && bn254_g1_msm_tab_lanes(n, n_terms) != 0;
+  if (split && w2) hipLaunchKernelGGL((k_g1_scalar_mul<true, true>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
+  else if (split) hipLaunchKernelGGL((k_g1_scalar_mul<true, false>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
+  else if (w2) hipLaunchKernelGGL((k_g1_scalar_mul<false, true>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
+  else hipLaunchKernelGGL((k_g1_scalar_mul<false, false>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
 }
 // part: 2 * n_terms * 27 * n dwords (the split launch writes the high halves n_terms rows after the low ones)
-hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, uint32_t* out_words,
+hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, uint32_t* out_words,
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
   const bool split = bn254_g1_msm_split(n, n_terms);
-  launch_scalar_mul(terms, flags, n, n_terms, part, split, s);
+  launch_scalar_mul(terms, flags, n, n_terms, part, glv_tab, split, s);
   hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, split ? n_terms : 0, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
   return hipGetLastError();
 }
 // the two halves of the above separately: ONE scalar-multiplication launch can feed several sums (PlonK: P0 and P1 of the KZG check); the sums
 // are told the launch's term count so that they find the high halves of a split launch
-hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, hipStream_t s) {
-  launch_scalar_mul(terms, flags, n, n_terms, part, bn254_g1_msm_split(n, n_terms), s);
+hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, hipStream_t s) {
+  launch_scalar_mul(terms, flags, n, n_terms, part, glv_tab, bn254_g1_msm_split(n, n_terms), s);
   return hipGetLastError();
 }
 hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {

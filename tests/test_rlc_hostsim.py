@@ -86,6 +86,25 @@ def test_glv_weights(hostsim, O):
     assert bytes(o) == bytes(64) and bytes(wv) == bytes(32)
 
 
+def test_glv_two_bit_windows(hostsim, O):
+    """(+-k1 +- k2 lambda) P for 128-bit halves by the joint two-bit-window form PlonK's small launches use (15-entry table) against the oracle and
+    against the one-bit form; zero halves, all-ones halves, digits that hit every table entry."""
+    rng = random.Random(17)
+    g = O.g1_gen()
+    a, b = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
+    pts = [g, O.g1_mul(g, rng.randrange(1, R))]
+    M = (1 << 128) - 1
+    cases = [(0, 0), (1, 0), (0, 1), (3, 2), (M, M), (1 << 127, 1 << 126), (0x1b1b1b1b1b1b1b1b1b1b1b1b1b1b1b1b, 0xe4e4e4e4e4e4e4e4e4e4e4e4e4e4e4e4)]
+    cases += [(rng.getrandbits(128), rng.getrandbits(128)) for _ in range(6)]
+    for p in pts:
+        for k1, k2 in cases:
+            for signs in (0, 1, 2, 3):
+                hostsim.hs_g1_mul_glv_w2(a, b, p, k2.to_bytes(16, "big") + k1.to_bytes(16, "big"), signs)
+                w = ((-k1 if signs & 1 else k1) + (-k2 if signs & 2 else k2) * LAMBDA) % R
+                want = O.g1_mul(p, w) if w else bytes(64)
+                assert bytes(a) == want and bytes(b) == want, (hex(k1), hex(k2), signs)
+
+
 def _neg_g2(q):
     c = [int.from_bytes(q[32 * i:32 * i + 32], "big") for i in range(4)]
     return q[:64] + be((P - c[2]) % P) + be((P - c[3]) % P)

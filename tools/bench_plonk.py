@@ -40,13 +40,15 @@ def main():
     stage_ms, lanes = pvk.last_timing()
     km = json.load(open(os.path.join(ROOT, "profiles", "kernel_mads.json")))["kernels"]
     peak = 35.1e12
-    split = (lanes[1] * 2 <= 65536 or os.environ.get("BN254_MSM_SPLIT") == "1") and os.environ.get("BN254_MSM_SPLIT") != "0"          # bn254_g1_msm_split
-    e = km["k_g1_scalar_mul_split" if split else "k_g1_scalar_mul"]
-    sm = e["mads_per_proof_launch"]                                                            # split: the high lane's chain (64 steps + 64 doublings)
+    env = os.environ.get
+    split = (lanes[1] * 2 <= 65536 or env("BN254_MSM_SPLIT") == "1") and env("BN254_MSM_SPLIT") != "0"      # bn254_g1_msm_split
+    w2 = lanes[1] * (2 if split else 1) <= 65536 and env("BN254_MSM_W2", "1") != "0"                          # bn254_g1_msm_tab_lanes
+    e = km["k_g1_scalar_mul" + ("_split" if split else "") + ("_w2" if w2 else "")]
+    sm = e["mads_per_proof_launch"]                                                            # the longest lane's chain
     useful = km["k_g1_scalar_mul"]["mads_per_proof_launch"] * lanes[1]                          # the work of the unsplit algorithm
     ach = useful / (stage_ms["k_g1_scalar_mul_stage2"] * 1e-3)
     n_lanes = lanes[1] * (2 if split else 1)
-    roofline = {"bound": "valu", "kernel": "k_g1_scalar_mul" + ("<split>" if split else ""), "unit": "T mad/s", "peak": peak / 1e12, "achieved": ach / 1e12, "frac": ach / peak,
+    roofline = {"bound": "valu", "kernel": "k_g1_scalar_mul" + ("<split>" if split else "") + ("<two-bit windows>" if w2 else ""), "unit": "T mad/s", "peak": peak / 1e12, "achieved": ach / 1e12, "frac": ach / peak,
                 "avg_launch_ms": stage_ms["k_g1_scalar_mul_stage2"], "terms_per_launch": lanes[1], "lanes_per_launch": n_lanes, "mads_per_term_unsplit": km["k_g1_scalar_mul"]["mads_per_proof_launch"],
                 "longest_lane_chain_mads": sm, "traffic": None,
                 "note": "%d lanes = %.2f wavefronts per SIMD: the launch lasts as long as its longest lane's chain (%d multiply-adds); achieved = multiply-adds of the "

@@ -139,12 +139,19 @@ def model_kernel(name, ins):
         elif 1700 <= c <= 1900 and inner:
             t, why = TRIPS_BY_KERNEL.get((name, "window_outer"), (1, "UNMODELLED outer window loop"))
             weight_ranges.append((h, latches[-1], float(t))); notes.append("outer window loop x%g: %s" % (t, why))
+        elif name == "k_g1_scalar_mul" and 1950 <= c <= 2050 and not inner:
+            weight_ranges.append((h, latches[-1], 9.0)); notes.append("table of the two-bit windows: 9 sums i P1 + j P2 (%d mads each)" % c)
+        elif name == "k_g1_scalar_mul" and 40 <= c <= 60 and not inner:
+            weight_ranges.append((h, latches[-1], 3.0)); notes.append("table rows i P1, j P2 stored (x3)")
         elif name == "k_g1_scalar_mul" and 1150 <= c <= 1350 and not inner:
             weight_ranges.append((h, latches[-1], 64.0)); notes.append("64 doublings of the high half (%d mads each; split launch, high lanes only)" % c)
         elif 4300 <= c <= 4600 or (name in ("k_rlc_scale", "k_g1_scalar_mul") and 3000 <= c <= 3400):
             t, why = TRIPS_BY_KERNEL.get((name, "scalar_mul"), (1, "UNMODELLED scalar multiplication loop"))
-            if name == "k_g1_scalar_mul" and any(1150 <= g[2] <= 1350 for g in groups):
-                t, why = 64, "split launch: 64 joint bit positions per lane (low / high half of the GLV halves)"
+            if name == "k_g1_scalar_mul":
+                split = any(1150 <= g[2] <= 1350 and not [x for x in groups if x is not g and g[0] <= x[0] and x[1][-1] <= g[1][-1]] for g in groups)
+                w2 = c >= 4300          # two doublings + one addition per step (bn254_rlc.h::g1_mul_glv_w2): two bits of each half
+                t = (32 if split else 64) if w2 else (64 if split else 128)
+                why = "%s%d steps per lane%s" % ("two-bit windows: " if w2 else "", t, " (split launch: low / high half of the GLV halves)" if split else "")
             weight_ranges.append((h, latches[-1], float(t))); notes.append("2-bit window loop x%g (%d mads per window): %s" % (t, c, why))
         elif c == 224:
             t, why = TRIPS_BY_KERNEL.get((name, "fr_products"), (1, "UNMODELLED"))
@@ -378,7 +385,7 @@ def main():
         elif name == "k_g1_scalar_mul":
             # template instances: <false> one lane per term; <true> two lanes per term (the count is the HIGH lane's chain, the launch's duration)
             for e in es:
-                kernels[name + ("_split" if "split launch" in e["model"] else "")] = e
+                kernels[name + ("_split" if "split launch" in e["model"] else "") + ("_w2" if "two-bit windows" in e["model"] else "")] = e
         else:
             for i, e in enumerate(es):
                 kernels["%s#%d" % (name, i)] = e

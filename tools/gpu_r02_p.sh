@@ -8,7 +8,7 @@ run nocoop BN254_COOP=0
 run coop6 BN254_COOP_LANES=6
 run streams1 BN254_STREAMS=1
 run streams4 BN254_STREAMS=4
-run msm_nosplit BN254_MSM_SPLIT=0
+run msm_plain BN254_MSM_SPLIT=0 BN254_MSM_W2=0
 fi
 run rlc_g3s1 BN254_RLC_GROUP_LOG2=3 BN254_RLC_SHARE_LOG2=1 BN254_RLC_SHARE_MIN_LANES=1
 run rlc_g8s3 BN254_RLC_GROUP_LOG2=8 BN254_RLC_SHARE_LOG2=3 BN254_RLC_SHARE_MIN_LANES=1
