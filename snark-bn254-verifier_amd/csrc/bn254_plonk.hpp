@@ -120,8 +120,8 @@ struct Sha256 {
 struct FrM { uint64_t l[4]; };
 struct FrCtx {
   uint64_t m[4], inv; FrM one, r2, shift256;
-  FrCtx() {
-    for (int i = 0; i < 4; i++) m[i] = (uint64_t)BN_R_WORDS[2 * i] | ((uint64_t)BN_R_WORDS[2 * i + 1] << 32);
+  explicit FrCtx(const uint32_t* words = BN_R_WORDS) {   // the same arithmetic serves the base field (fp64_ctx below)
+    for (int i = 0; i < 4; i++) m[i] = (uint64_t)words[2 * i] | ((uint64_t)words[2 * i + 1] << 32);
     uint64_t x = 1; for (int i = 0; i < 6; i++) x *= 2 - m[0] * x;   // m[0]^-1 mod 2^64 (Newton)
     inv = ~x + 1;                                                    // -m^-1
     FrM t = {{1, 0, 0, 0}};
@@ -206,6 +206,18 @@ struct FrCtx {
   void to_words(uint32_t w[8], const FrM& a) const { FrM c = to_canon(a); for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)c.l[i]; w[2 * i + 1] = (uint32_t)(c.l[i] >> 32); } }
 };
 inline const FrCtx& fr_ctx() { static const FrCtx c; return c; }
+// Fp on 4 x 64-bit limbs for the host-side checks of proof points: a CIOS product costs a third of the 9 x 29-bit digit product the kernels'
+// representation needs on a CPU.  k261: 2^(261 + 256) mod p, so that mul(x, k261) = x 2^261 mod p -- the digit form's Montgomery factor.
+struct Fp64Ctx {
+  FrCtx F; FrM three, k261;
+  Fp64Ctx() : F(BN_P_WORDS) {
+    three = F.from_u64(3);
+    FrM t = F.one;                                         // 2^256 mod p
+    for (int i = 0; i < 261; i++) t = F.dbl_mod(t);        // 2^517 mod p
+    k261 = t;
+  }
+};
+inline const Fp64Ctx& fp64_ctx() { static const Fp64Ctx c; return c; }
 
 // ---------------------------------------------------------------- key and proof (plonk/converter.rs:18-178, proof.rs)
 enum { PLONK_MAX_QCP = 8, PLONK_MAX_CLAIMED = 16 };
@@ -216,6 +228,7 @@ struct PlonkKey {
   uint64_t cci[PLONK_MAX_QCP]; uint64_t n_cci;
   FrM wpow[PLONK_MAX_QCP];             // generator^(nb_public + cci[i]): the evaluation point of the i-th BSB22 Lagrange term
   uint8_t enc[8 + PLONK_MAX_QCP][64];  // uncompressed encodings of s1..3, ql, qr, qm, qo, qk, qcp[]: what the transcript binds
+  Sha256 gamma_mid;                    // SHA-256 state after "gamma" and those encodings: the key-side prefix of every proof's first challenge
 };
 inline uint64_t be64(const uint8_t* b) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = v << 8 | b[i]; return v; }
 // plonk/converter.rs:18-119.  G1 points: unchecked decompression (converter.rs:62-76); G2: converter.rs:113-133 in the reference's
@@ -242,6 +255,9 @@ inline int parse_plonk_vk(PlonkKey& vk, const uint8_t* b, size_t n) {
   vk.n_cci = be64(b + off); off += 8;
   if (vk.n_cci > PLONK_MAX_QCP || n < off + 8 * vk.n_cci) return DEC_MALFORMED;
   for (uint64_t i = 0; i < vk.n_cci; i++, off += 8) { vk.cci[i] = be64(b + off); vk.wpow[i] = F.pow_u64(vk.generator, vk.nb_public + vk.cci[i]); }
+  vk.gamma_mid.reset();
+  vk.gamma_mid.update("gamma", 5);
+  for (uint32_t i = 0; i < 8 + vk.n_qcp; i++) vk.gamma_mid.update(vk.enc[i], 64);
   return DEC_OK;
 }
 struct PlonkProof {
@@ -254,9 +270,20 @@ struct PlonkProof {
 enum { PL_OK = 1, PL_NOT_MEMBER = 2, PL_NOT_ON_CURVE = 3, PL_INPUT_LEN = 5, PL_MALFORMED = 6, PL_OPENING = 7, PL_PAIRING = 8, PL_BSB22 = 9, PL_INVERSE = 10 };
 // converter.rs:78-88: two field members (>= p rejected), then the curve equation
 inline int dec_g1_uncompressed_checked(G1Aff& o, const uint8_t* b) {
-  if (!be_lt_p(b) || !be_lt_p(b + 32)) return PL_NOT_MEMBER;
-  o.x = fp_from_be(b); o.y = fp_from_be(b + 32);
-  return g1_on_curve(o) ? PL_OK : PL_NOT_ON_CURVE;
+  const Fp64Ctx& C = fp64_ctx();
+  const FrCtx& F = C.F;
+  FrM x, y;
+  for (int i = 0; i < 4; i++) { x.l[i] = be64(b + (3 - i) * 8); y.l[i] = be64(b + 32 + (3 - i) * 8); }
+  if (F.geq_m(x) || F.geq_m(y)) return PL_NOT_MEMBER;
+  // y^2 == x^3 + 3 on 64-bit limbs (the all-zero encoding is not on the curve, as in bn254_curve.h::g1_on_curve)
+  const FrM xm = F.from_canon(x), ym = F.from_canon(y);
+  const bool on = F.eq(F.mul(ym, ym), F.add(F.mul(F.mul(xm, xm), xm), C.three));
+  // the kernels' form: x 2^261 mod p as balanced 29-bit digits
+  uint32_t wx[8], wy[8];
+  const FrM dx = F.mul(x, C.k261), dy = F.mul(y, C.k261);
+  for (int i = 0; i < 4; i++) { wx[2 * i] = (uint32_t)dx.l[i]; wx[2 * i + 1] = (uint32_t)(dx.l[i] >> 32); wy[2 * i] = (uint32_t)dy.l[i]; wy[2 * i + 1] = (uint32_t)(dy.l[i] >> 32); }
+  o.x = fp_from_words_raw(wx); o.y = fp_from_words_raw(wy);
+  return on ? PL_OK : PL_NOT_ON_CURVE;
 }
 // plonk/converter.rs:121-178
 inline int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
@@ -288,6 +315,7 @@ inline int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
 struct Challenge {
   Sha256 h;
   Challenge(const char* name, const uint8_t* prev) { h.update(name, strlen(name)); if (prev) h.update(prev, 32); }
+  explicit Challenge(const Sha256& mid) : h(mid) {}     // continue from a saved state (name and key-side bindings already absorbed)
   void bind(const void* d, size_t n) { h.update(d, n); }
   FrM finish(uint8_t digest[32]) { h.finish(digest); return fr_ctx().from_be_reduce(digest, 32); }
 };
@@ -399,8 +427,7 @@ inline int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proo
   const FrM one = F.one;
   // Fiat-Shamir (verify.rs:62-95, 319-362)
   uint8_t dg[32], db[32], da[32], dz[32];
-  Challenge cg("gamma", nullptr);
-  for (uint32_t i = 0; i < 8 + vk.n_qcp; i++) cg.bind(vk.enc[i], 64);
+  Challenge cg(vk.gamma_mid);                                             // "gamma" | s1..3, ql, qr, qm, qo, qk, qcp[] (parse_plonk_vk)
   cg.bind(inputs, 32 * n_inputs);                                         // the public inputs as stored (raw big-endian)
   cg.bind(proof, 192);                                                    // l, r, o
   gamma = cg.finish(dg);
