@@ -115,8 +115,10 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
 /* pre-allocate the per-device workspace for batches of up to n proofs and upload the key's tables */
 int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
 
-/* Groth16Verifier::verify (lib.rs:44-49) as one call: vk parsed on every call like the reference, one proof, one status
- * byte.  Runs on the GPU (device 0). */
+/* Groth16Verifier::verify (lib.rs:44-49) as one call: one proof, one status byte, vk given as bytes on every call like the
+ * reference.  The prepared form of the last four keys (exact byte match, per mode) is kept, so only the first call with a key pays
+ * its preparation (9 ms of an 11 ms call; 2 ms afterwards); BN254_KEY_CACHE=0 in the environment switches the cache off.
+ * bn254_plonk_verify does the same.  Runs on the GPU (device 0). */
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
 

@@ -223,3 +223,26 @@ def test_plonk_rejects_the_known_lambda_forgery(pkg, O, fixtures, L):
     st = pvk.verify_batch((proof + forged + tampered) * 20, ib * 60)
     assert st == bytes([1, 8, 8]) * 20
     pvk.close()
+
+
+def test_single_verify_key_cache(pkg, O, L):
+    """The single-proof entry keeps the prepared form of its last four keys (exact byte match): six keys in rotation (so entries are evicted and
+    re-prepared), both readings of the G2 root order under the same bytes, a valid and a rejected proof per key -- the answers never depend on
+    what the cache holds."""
+    keys = []
+    for k in range(6):
+        vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540100 + k, 2, 8, invalid_every=2, agree=True, threads=2)
+        keys.append((vk, proofs, inputs, exp))
+    for rnd in range(3):
+        for vk, proofs, inputs, exp in keys:
+            for i in (0, 1, 2, 3):
+                ins = [int.from_bytes(inputs[64 * i + 32 * j:64 * i + 32 * j + 32], "big") for j in range(2)]
+                for mode, omode in ((pkg.VK_REFERENCE, O.MODE_REFERENCE), (pkg.VK_GNARK, O.MODE_GNARK)):
+                    got = pkg.Groth16Verifier.verify(proofs[256 * i:256 * i + 256], vk, ins, mode)
+                    if rnd == 0:
+                        assert got == O.groth16_verify_many(proofs[256 * i:256 * i + 256], 256, vk, inputs[64 * i:64 * i + 64], 2, 1, omode)[0]
+                    if mode == pkg.VK_REFERENCE:
+                        assert got == exp[i]
+    # a key that does not parse is never cached and never confused with a cached one
+    bad = bytearray(keys[0][0]); bad[3] ^= 0xFF
+    assert pkg.Groth16Verifier.verify(keys[0][1][:256], bytes(bad[:100]), [1, 2]) == pkg.ERR_MALFORMED
