@@ -76,6 +76,8 @@ enum { BN254_VK_REFERENCE = 0, BN254_VK_GNARK = 1 };
  *     re-verified by the exact path, so the status bytes are those of the exact path except with probability <= 2^-120 per batch
  *     (a false ACCEPT).  Loader errors (member / curve / subgroup) are always exact.  The weights come from ChaCha20 keyed by
  *     getrandom(2) per call.  The call synchronises the stream once (to learn which groups failed).
+ *     The mode is a longer pipeline than the exact path and pays from about 200 000 proofs (2.0 x at 2^20): below that the flag is
+ *     ignored (BN254_RLC_MIN_BATCH in the environment moves the threshold; never below 64).
  *     Adaptive: an RLC pass costs about half an exact pass and every proof of a failed group pays the exact pass on top, so per
  *     (key, device) the share of proofs that fell back is tracked, and while it is above 0.45 the flag is ignored (the exact path
  *     runs: same status bytes) except for one measuring RLC pass every 8 calls.  BN254_RLC_ADAPTIVE=0 in the environment

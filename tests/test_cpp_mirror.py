@@ -46,7 +46,7 @@ def test_cpp_mirror_on_device(mirror_check, O, fixtures, tmp_path):
     for i, (p, q) in enumerate(cases):
         open(tmp_path / ("proof_%d.bin" % i), "wb").write(p)
         open(tmp_path / ("inputs_%d.bin" % i), "wb").write(b"".join(int(x).to_bytes(32, "big") for x in q))
-    r = subprocess.run([mirror_check, "gpu", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([mirror_check, "gpu", str(tmp_path)], capture_output=True, text=True, timeout=600, env=dict(os.environ, BN254_RLC_MIN_BATCH="64"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mirror_check gpu ok" in r.stdout
     lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l.startswith("plonk_batch")}

@@ -25,6 +25,7 @@ def L(pkg):
 def _rlc_always(monkeypatch):
     """The RLC tests want the RLC kernels to run on every call: switch the adaptive bypass off (test_rlc_adaptive_bypass switches it on)."""
     monkeypatch.setenv("BN254_RLC_ADAPTIVE", "0")
+    monkeypatch.setenv("BN254_RLC_MIN_BATCH", "64")       # by default the flag is honoured from 200 000 proofs (where the mode pays)
 
 
 @pytest.fixture(scope="module")

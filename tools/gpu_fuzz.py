@@ -3,6 +3,8 @@
 C ABI; every status byte is compared with the generator's prediction, a random sample of every batch with the CPU oracle, and the three
 execution paths (cooperative small-batch kernels, one-proof-per-lane kernels, RLC mode) with each other where more than one applies.
   python tools/gpu_fuzz.py [--cases 40] [--seed 1]"""
+import os
+os.environ.setdefault("BN254_RLC_MIN_BATCH", "64")      # run the RLC kernels on the small random batches too (default: from 200 000 proofs)
 import argparse, importlib, json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

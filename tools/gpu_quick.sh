@@ -1,15 +1,9 @@
 #!/bin/bash
-# quick GPU check: parity tests + bench without the CPU baseline
+# quick GPU check: parity suite, smoke, RLC against the exact path at three sizes
 set -o pipefail
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
-tail -3 gpurun_out/pytest_gpu.log
-python bench.py --no-cpu-baseline --steps 2 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err || { tail -20 gpurun_out/bench_quick.err; exit 1; }
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_quick.json'))
-print("value %.0f proofs/s  %.1f ms/step" % (d['value'], d['ms_per_step']))
-print("dominant", d['roofline']['kernel'], d['roofline']['avg_launch_ms'], "frac", round(d['roofline']['frac'],3))
-for k,v in d['kernels_ms'].items(): print("  %-22s %4d  %8.3f ms" % (k, v['launches'], v['total_ms']))
-print(d['phases_ms'])
-PY
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/quick_pytest.txt 2>&1; rc=$?
+tail -3 gpurun_out/quick_pytest.txt
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" || exit 1
+for b in 12 17 18; do timeout -k 10 300 python tools/bench_rlc.py --batch-log2 $b --steps 5 --invalid-every 0 2>/dev/null | tail -1 | cut -c1-330; done
