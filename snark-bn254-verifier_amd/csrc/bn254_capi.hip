@@ -415,6 +415,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       }
     }
     int parts = (!wide && n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
+    if (m <= bn254_coop_max_proofs()) parts = 1;              // one launch: the cooperative kernels take batches of this size whole
     while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
     const bool concurrent = !wide && n_streams > 1 && parts > 1;
     const bool split_small = m <= (size_t)G16_SPLIT_MAX_PROOFS;   // latency mode of bn254_launch_g16

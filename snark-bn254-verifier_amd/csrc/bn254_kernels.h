@@ -95,7 +95,7 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
 // cooperative layout for small batches (bn254_coop.hip): six lanes per proof, the whole Miller loop / final exponentiation in one launch
 #define COOP_T_ELEM 46          // = VE_S2: where the cooperative Miller loop leaves the running G2 point for k_g16_subgroup
 #define COOP_MAX_PROOFS 10240   // six-lane generation: above this the one-proof-per-lane kernels fill the GPU better
-#define COOP12_MAX_PROOFS 20480 // twelve-lane generation (four passes of 1024 wavefronts x 5 proofs: 9.3 ms against 12 ms of the lane kernels at 16384)
+#define COOP12_MAX_PROOFS 40960 // twelve-lane generation: passes of 1024 wavefronts x 5 proofs, 1.98 ms each: 8 passes = 15.9 ms against 17.5 ms of the lane kernels at 40960 (tools/bench_mid.py)
 hipError_t bn254_coop_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
                                  int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
 hipError_t bn254_coop_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);

@@ -55,7 +55,7 @@ def main():
                         "one-lane-per-term algorithm / launch time; peak = measured issue rate with full occupancy (profiles/r01_ubench_valu.txt)" % (n_lanes, n_lanes / 64 / 1024.0, int(sm))}
     pc = km.get("k_coop12_miller_fixed")
     pairing = None
-    if pc and args.batch <= 20480:
+    if pc and args.batch <= 40960:
         a2 = pc["mads_per_proof_launch"] * min(args.batch, 65536) / (stage_ms["pairing_check"] * 1e-3)
         pairing = {"kernel": "k_coop12_miller_fixed", "ms": stage_ms["pairing_check"], "mads_per_proof": pc["mads_per_proof_launch"], "achieved": a2 / 1e12, "frac": a2 / peak}
     m = min(args.cpu_sample, args.batch)
