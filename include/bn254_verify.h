@@ -191,7 +191,8 @@ int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned 
  * proofs (256 bytes each, A | B | C uncompressed) that satisfy gnark's equation, their public inputs, and the status the
  * verifier must return.  If invalid_every > 0 every invalid_every-th proof is corrupted, cycling through: public input
  * + 1 (REJECT), C + G1 (REJECT), A.y + 1 (NOT_ON_CURVE), B replaced by a twist point outside G2 (NOT_IN_SUBGROUP),
- * A.x >= p (NOT_MEMBER).  If agree != 0 the key is sampled so that BN254_VK_REFERENCE and BN254_VK_GNARK agree on it. */
+ * A.x >= p (NOT_MEMBER).  agree bit 0: the key is sampled so that BN254_VK_REFERENCE and BN254_VK_GNARK agree on it; bit 1:
+ * every proof with index = 3 (mod 7) gets a last public input that makes L = K0 + sum x_i K_i the identity (still a valid proof). */
 size_t bn254_synth_groth16_vk_len(size_t n_public);
 int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_every, int agree, int threads,
                         uint8_t* vk_out, uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected_status_out);

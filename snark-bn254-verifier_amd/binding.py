@@ -246,12 +246,13 @@ def proof_write_raw(a, b, c):
     return bytes(out)
 
 
-def synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=0):
+def synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=0, l_identity=False):
     """Deterministic synthetic gnark-format workload: (vk, proofs, inputs, expected_status) as bytes."""
     L = lib()
     vk = (C.c_uint8 * L.bn254_synth_groth16_vk_len(n_public))()
     proofs = (C.c_uint8 * max(256 * n, 1))()
     inputs = (C.c_uint8 * max(32 * n_public * n, 1))()
     exp = (C.c_uint8 * max(n, 1))()
-    _check(L.bn254_synth_groth16(seed, n_public, n, invalid_every, 1 if agree else 0, threads, vk, proofs, inputs, exp))
+    # l_identity: every proof with index = 3 mod 7 gets public inputs that make its public-input point L the identity (a valid proof)
+    _check(L.bn254_synth_groth16(seed, n_public, n, invalid_every, (1 if agree else 0) | (2 if l_identity else 0), threads, vk, proofs, inputs, exp))
     return bytes(vk), bytes(proofs)[:256 * n], bytes(inputs)[:32 * n_public * n], bytes(exp)[:n]

@@ -1124,9 +1124,10 @@ int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_ev
   auto same_half = [](const G2Aff& q) { return fp_is_large(q.y.c0) == fp_is_large(q.y.c1); };
   U256 alpha = fr_random(rng, true), beta, gamma, delta;
   G2Aff beta2, gamma2, delta2;
-  for (;;) { beta = fr_random(rng, true); beta2 = g2_mul_gen(*tabs, beta); if (!agree || !same_half(beta2)) break; }
-  for (;;) { gamma = fr_random(rng, true); gamma2 = g2_mul_gen(*tabs, gamma); if (!agree || !same_half(gamma2)) break; }
-  for (;;) { delta = fr_random(rng, true); delta2 = g2_mul_gen(*tabs, delta); if (!agree || same_half(delta2)) break; }
+  const bool agree_modes = (agree & 1) != 0;     // agree bit 1 (value 2): every proof with index = 3 mod 7 has L = the identity (see the worker)
+  for (;;) { beta = fr_random(rng, true); beta2 = g2_mul_gen(*tabs, beta); if (!agree_modes || !same_half(beta2)) break; }
+  for (;;) { gamma = fr_random(rng, true); gamma2 = g2_mul_gen(*tabs, gamma); if (!agree_modes || !same_half(gamma2)) break; }
+  for (;;) { delta = fr_random(rng, true); delta2 = g2_mul_gen(*tabs, delta); if (!agree_modes || same_half(delta2)) break; }
   std::vector<U256> kk(n_public + 1);
   for (auto& k : kk) k = fr_random(rng, true);
   // gnark-compressed vk: alpha1 | beta1 | beta2 | gamma2 | delta1 | delta2 | nK | K.. | 0 (no commitments) | 2 x G2 infinity
@@ -1167,6 +1168,15 @@ int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_ev
       U256 ell = kk[0];
       std::vector<U256> xs(n_public);
       for (size_t s = 0; s < n_public; s++) { xs[s] = fr_random(r, false); ell = fr_add(ell, fr_mul(xs[s], kk[s + 1])); }
+      if ((agree & 2) && n_public > 0 && i % 7 == 3) {
+        // L = K0 + sum x_s K_s = the identity: the last input cancels the rest (valid proofs whose public-input point is the point at infinity --
+        // bn::pairing_batch skips such a pair; the kernels replace its line by 1)
+        const size_t last = n_public - 1;
+        ell = fr_sub(ell, fr_mul(xs[last], kk[last + 1]));
+        U256 zero = {{0, 0, 0, 0}};
+        xs[last] = fr_mul(fr_sub(zero, ell), fr_inv(kk[last + 1]));
+        ell = zero;
+      }
       // c = (a b - alpha beta - gamma ell) / delta   =>   e(A,B) = e(alpha,beta) e(L,gamma) e(C,delta)
       U256 c = fr_mul(fr_sub(fr_sub(fr_mul(a, b), alpha_beta), fr_mul(gamma, ell)), delta_inv);
       G1Aff A = g1_to_affine(g1_mul_gen(*tabs, a));

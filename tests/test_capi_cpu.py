@@ -175,6 +175,22 @@ def test_raw_proof_writer_reproduces_reference_fixtures(pkg, fixtures):
     assert seen == 4
 
 
+def test_synth_identity_public_input_point_judged_by_oracle(pkg, O):
+    """Generator option: proofs whose public-input point L is the identity (the last input cancels K0 + the rest).  bn::pairing_batch skips a
+    pair with an identity operand; the oracle must accept these proofs, in both key modes, and they must differ from ordinary ones only in
+    their inputs."""
+    n = 16
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540077, 3, n, invalid_every=0, agree=True, threads=4, l_identity=True)
+    vk0, proofs0, inputs0, exp0 = pkg.synth_groth16(0xB2540077, 3, n, invalid_every=0, agree=True, threads=4)
+    assert vk == vk0 and exp == exp0 == bytes([pkg.ACCEPT]) * n
+    for i in range(n):
+        same = inputs[96 * i:96 * i + 96] == inputs0[96 * i:96 * i + 96]
+        assert same == (i % 7 != 3)
+        assert inputs[96 * i:96 * i + 64] == inputs0[96 * i:96 * i + 64]          # only the last input differs
+    for mode in (O.MODE_REFERENCE, O.MODE_GNARK):
+        assert O.groth16_verify_many(proofs, 256, vk, inputs, 3, n, mode) == exp
+
+
 def test_no_constant_kzg_batching_scalar_in_the_product():
     """The PlonK path keys its batching scalars with getrandom(2) on every call (a ChaCha20 key and nonce, expanded per proof); no literal
     scalar may come back."""

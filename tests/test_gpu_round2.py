@@ -247,3 +247,23 @@ def test_single_verify_key_cache(pkg, O, L):
     # a key that does not parse is never cached and never confused with a cached one
     bad = bytearray(keys[0][0]); bad[3] ^= 0xFF
     assert pkg.Groth16Verifier.verify(keys[0][1][:256], bytes(bad[:100]), [1, 2]) == pkg.ERR_MALFORMED
+
+
+def test_public_input_point_at_infinity_on_every_path(pkg, O, L):
+    """Valid proofs whose public-input point L is the identity (generator option l_identity): the pair (L, gamma) contributes nothing
+    (bn::pairing_batch skips it; the kernels keep f where the line would be multiplied in).  Through the cooperative kernels (4096 proofs),
+    the one-proof-per-lane kernels (45 000), the RLC mode and the single-proof entry; sampled against the oracle."""
+    for n_public in (1, 2, 5):
+        n = 45000 if n_public == 2 else 4096
+        vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540300 + n_public, n_public, n, invalid_every=11, agree=True, threads=16, l_identity=True)
+        pvk = pkg.PreparedVk(vk)
+        assert pvk.verify_batch(proofs, inputs, n) == exp
+        assert pvk.verify_batch(proofs[:256 * 4096], inputs[:32 * n_public * 4096], 4096) == exp[:4096]
+        assert pvk.verify_batch(proofs, inputs, n, flags=pkg.FLAG_RLC) == exp
+        idx = [i for i in range(200) if i % 7 == 3][:12] + [0, 1, 2]
+        sp = b"".join(proofs[256 * i:256 * i + 256] for i in idx); si = b"".join(inputs[32 * n_public * i:32 * n_public * (i + 1)] for i in idx)
+        assert O.groth16_verify_many(sp, 256, vk, si, n_public, len(idx), O.MODE_REFERENCE) == bytes(exp[i] for i in idx)
+        assert exp[3] == pkg.ACCEPT
+        ins = [int.from_bytes(inputs[32 * n_public * 3 + 32 * j:32 * n_public * 3 + 32 * j + 32], "big") for j in range(n_public)]
+        assert pkg.Groth16Verifier.verify(proofs[256 * 3:256 * 4], vk, ins) == pkg.ACCEPT
+        pvk.close()
