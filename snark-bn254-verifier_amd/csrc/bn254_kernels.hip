@@ -408,6 +408,50 @@ k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32
   if (i < n && (st & BN254_ST_PENDING) && l_inf) status[i] = st | BN254_ST_LINF;
 }
 
+// The same with EIGHT lanes per proof (small batches, where the launch lasts as long as one lane's chain of `chunks` additions): lane `sub` adds the
+// chunk sums sub, sub + 8, ..., the eight partial sums meet in LDS, lane 0 adds them to K0 and finishes: chunks / 8 + 8 additions in a row
+// instead of chunks.  256 threads = 32 proofs.
+__global__ void __launch_bounds__(256, 2)
+k_g16_msm_reduce8(const int32_t* __restrict__ part, int chunks, uint32_t n, int32_t* ws, uint8_t* __restrict__ status, const int32_t* __restrict__ k0) {
+  __shared__ int32_t sums[32 * 8 * 27];
+  const uint32_t p = blockIdx.x * 32u + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
+  const uint32_t pp = p < n ? p : n - 1;
+  G1Proj L = g1_identity();
+  for (int c = (int)sub; c < chunks; c += 8) {
+    const int32_t* o = part + (size_t)c * 27 * n + pp;
+    G1Proj q;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { q.x.v[l] = o[(size_t)l * n]; q.y.v[l] = o[(size_t)(9 + l) * n]; q.z.v[l] = o[(size_t)(18 + l) * n]; }
+    BN_SETB(q.x, 3.0, 0.5); BN_SETB(q.y, 3.0, 0.5); BN_SETB(q.z, 3.0, 0.5);
+    L = g1_add(L, q);
+  }
+  {
+    int32_t* o = sums + threadIdx.x * 27;
+    const Fp x = fp_reduce(L.x), y = fp_reduce(L.y), z = fp_reduce(L.z);
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { o[l] = x.v[l]; o[9 + l] = y.v[l]; o[18 + l] = z.v[l]; }
+  }
+  __syncthreads();
+  const bool lead = sub == 0 && p < n;
+  const uint8_t st = status[pp];
+  G1Aff K0; K0.x = uni_ld(k0); K0.y = uni_ld(k0 + BN_NL);
+  G1Proj T = g1_from_affine(K0);
+  for (int j = 0; j < 8; j++) {       // every lane runs the tail (no divergence); only the leading lane's result is stored
+    const int32_t* o = sums + ((threadIdx.x & ~7u) + j) * 27;
+    G1Proj q;
+#pragma unroll
+    for (int l = 0; l < BN_NL; l++) { q.x.v[l] = o[l]; q.y.v[l] = o[9 + l]; q.z.v[l] = o[18 + l]; }
+    BN_SETB(q.x, 1.01, 0.5); BN_SETB(q.y, 1.01, 0.5); BN_SETB(q.z, 1.01, 0.5);
+    T = g1_add(T, q);
+  }
+  const bool l_inf = g1_is_identity(T);
+  G1Aff La = g1_to_affine(T);
+  La.y = fp_select(l_inf, fp_one(), La.y);
+  DevWs w(ws, n, lead ? p : DEAD_LANE);
+  w.st(VE_LX, La.x); w.st(VE_LY, La.y);
+  if (lead && (st & BN254_ST_PENDING) && l_inf) status[p] = st | BN254_ST_LINF;
+}
+
 // =====================================================================================================================
 // variable-base G1 multi-scalar multiplication (PlonK: linearised-polynomial digest, folded digests and quotients)
 // =====================================================================================================================
@@ -850,7 +894,13 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     const int per = G16_WIDE_MSM_INPUTS_PER_LANE, chunks = (a.n_public + per - 1) / per;
     unsigned pg = (unsigned)(((size_t)n * chunks + 255) / 256);
     { ProfScope ps_(prof, KID_MSM_PARTIAL, s); hipLaunchKernelGGL(k_g16_msm_partial, dim3(pg), dim3(256), 0, s, a.inputs, a.n_public, n, per, chunks, (const uint8_t*)a.status, a.msm_tab, a.msm_part); }
-    BN_LAUNCH(KID_MSM_REDUCE, k_g16_msm_reduce, (const int32_t*)a.msm_part, chunks, n, a.ws, a.status, a.k0);
+    if (chunks >= 16 && a.n <= 65536) {
+      // eight lanes per proof: below one wavefront per SIMD the reduction is one lane's chain of additions
+      ProfScope ps_(prof, KID_MSM_REDUCE, s);
+      hipLaunchKernelGGL(k_g16_msm_reduce8, dim3((unsigned)((a.n + 31) / 32)), dim3(256), 0, s, (const int32_t*)a.msm_part, chunks, n, a.ws, a.status, a.k0);
+    } else {
+      BN_LAUNCH(KID_MSM_REDUCE, k_g16_msm_reduce, (const int32_t*)a.msm_part, chunks, n, a.ws, a.status, a.k0);
+    }
   }
   if (ev) (void)hipEventRecord(ev[1], s);
   if (coop) {

@@ -236,7 +236,7 @@ def test_plonk_batch_4096(pkg, O, fixtures):
     pvk.close()
 
 
-@pytest.mark.parametrize("n_public", [17, 40, 1024])
+@pytest.mark.parametrize("n_public", [17, 40, 300, 1024])
 def test_many_public_inputs_vs_oracle(pkg, O, n_public):
     """Keys with many public inputs (BASELINE configs[4]: 1024) take the wide MSM path: the inputs of one proof are summed by
     n_public/16 lanes and reduced.  Every status class, both key readings, the oracle on a prefix, and a wrong input count."""
