@@ -65,7 +65,7 @@ struct DevState {
   bool ready = false;
   int32_t *k0 = nullptr, *gtab = nullptr, *dtab = nullptr, *target = nullptr, *msm = nullptr;
   int32_t* ws = nullptr; size_t ws_cap = 0;                         // proofs the workspace can hold
-  int32_t* msm_part = nullptr; size_t msm_part_cap = 0;             // wide keys: partial sums of the public-input MSM (proofs it holds)
+  int32_t* msm_part = nullptr; size_t msm_part_cap = 0, msm_chunks = 0;             // wide keys: partial sums of the public-input MSM (proofs it holds)
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
   size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
   hipStream_t host_stream = nullptr, copy_stream = nullptr; std::vector<hipEvent_t> copy_ev;   // host-buffer entry: chunked copy/compute overlap
@@ -410,8 +410,10 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
         if (d->msm_part) HIPCK(hipFree(d->msm_part));
         d->msm_part = nullptr; d->msm_part_cap = 0;
         size_t chunks = (n_public + G16_WIDE_MSM_INPUTS_PER_LANE - 1) / G16_WIDE_MSM_INPUTS_PER_LANE;
-        HIPCK(hipMalloc((void**)&d->msm_part, chunks * 27 * need * sizeof(int32_t)));
-        d->msm_part_cap = need;
+        // comb tables: + the column digits of every scalar (22 x u16 per input, transposed so that the lanes of a wavefront read neighbours)
+        const size_t digits = pvk->host.msm_comb ? (size_t)G16_COMB_COLS * n_public * need * sizeof(uint16_t) : 0;
+        HIPCK(hipMalloc((void**)&d->msm_part, chunks * 27 * need * sizeof(int32_t) + digits));
+        d->msm_part_cap = need; d->msm_chunks = chunks;
       }
     }
     int parts = (!wide && n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
@@ -436,6 +438,8 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       a.strict_scalars = (flags & BN254_FLAG_STRICT_SCALARS) ? 1 : 0;
       a.part_of_larger = parts > 1 ? 1 : 0;
       a.msm_part = wide ? d->msm_part : nullptr;
+      a.msm_comb = pvk->host.msm_comb ? 1 : 0;
+      a.msm_digits = (wide && pvk->host.msm_comb) ? (uint16_t*)(d->msm_part + d->msm_chunks * 27 * d->msm_part_cap) : nullptr;
       if (split_small && parts == 1) {
         a.split_streams[0] = d->aux[1]; a.split_streams[1] = d->aux[2];
         a.split_ev[0] = d->fork_ev; a.split_ev[1] = d->join_ev[1]; a.split_ev[2] = d->join_ev[2];

@@ -6,6 +6,7 @@
 // Restates (paths relative to /root/reference/verifier/src): converter.rs:23-43 (flags), :62-76 (compressed G1),
 // :113-133 (compressed G2), groth16/converter.rs:28-89 (vk layout), groth16/verify.rs:70 (e(alpha,beta)).
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -156,7 +157,8 @@ struct G16Prepared {
   std::vector<int32_t> k0;               // 18
   std::vector<int32_t> gtab, dtab;       // BN_ATE_STEPS * FIXED_LINE_DWORDS
   std::vector<int32_t> target;           // 108
-  std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS
+  std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS; keys with many inputs (msm_comb): (n_k - 1) * 4096 * MSM_ENTRY_DWORDS
+  bool msm_comb = false;                 // the table is in comb form (build_comb_table): read by k_g16_msm_partial_comb only
   G1Aff alpha, k0_pt; G2Aff b_arg;       // kept for the RLC tables (prepare_g16_rlc): alpha, K[0] and the G2 argument of the target pairing
 };
 inline void put_fp2(int32_t* o, const Fp2& a) { fp_to_limbs(o, a.c0); fp_to_limbs(o + BN_NL, a.c1); }
@@ -195,6 +197,35 @@ inline void build_window_table(int32_t* out /* 32*255*MSM_ENTRY_DWORDS */, const
     fp_to_limbs(o, aff[e].x); fp_to_limbs(o + BN_NL, aff[e].y); o[18] = 0; o[19] = 0;
   }
 }
+// comb table of one base (keys with many public inputs): G16_COMB_TEETH = 12 teeth G16_COMB_COLS = 22 bit positions apart; entry [idx] =
+// sum over the set bits i of idx of 2^(22 i) * base, idx = 1..4095 (entry 0 unused).  A 256-bit scalar x is then
+//   x * base = sum_{c = 0..21} 2^c * entry[ bits c, c + 22, ..., c + 242 of x ]
+// i.e. 22 additions per input and 22 doublings that ALL inputs of a lane share, against 32 additions with the byte windows -- from a table
+// half the size (4095 entries per input instead of 8160) that takes half as long to build.  No entry is the identity: none of the 4095 sums
+// of powers 2^(22 i) is a multiple of r (checked in tests/test_capi_cpu.py).
+inline void build_comb_table(int32_t* out /* 4096 * MSM_ENTRY_DWORDS */, const G1Aff& base) {
+  G1Aff tooth[G16_COMB_TEETH];
+  {
+    G1Proj t = g1_from_affine(base);
+    G1Proj tp[G16_COMB_TEETH];
+    for (int i = 0; i < G16_COMB_TEETH; i++) { tp[i] = t; for (int d = 0; d < G16_COMB_COLS; d++) t = g1_dbl(t); }
+    g1_batch_to_affine(tooth, tp, G16_COMB_TEETH);
+  }
+  const size_t n = (size_t)1 << G16_COMB_TEETH;
+  std::vector<G1Proj> pts(n);
+  pts[0] = g1_from_affine(base);   // placeholder (entry 0 is never read); keeps the batch conversion free of the identity
+  for (size_t idx = 1; idx < n; idx++) {
+    const size_t lb = idx & (~idx + 1);
+    int i = 0; while (((size_t)1 << i) != lb) i++;
+    pts[idx] = idx == lb ? g1_from_affine(tooth[i]) : g1_add_mixed(pts[idx ^ lb], tooth[i]);
+  }
+  std::vector<G1Aff> aff(n);
+  g1_batch_to_affine(aff.data(), pts.data(), n);
+  for (size_t e = 0; e < n; e++) {
+    int32_t* o = out + e * MSM_ENTRY_DWORDS;
+    fp_to_limbs(o, aff[e].x); fp_to_limbs(o + BN_NL, aff[e].y); o[18] = 0; o[19] = 0;
+  }
+}
 // mode 0: reference-literal equation  e(A,B) e(L, gamma') e(C, -delta') == e(alpha, -beta')   (groth16/verify.rs:70-77, converter.rs:79)
 // mode 1: gnark                       e(A,B) e(L, -gamma) e(C, -delta)  == e(alpha, beta)
 inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
@@ -219,12 +250,21 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
   out.target.resize(12 * BN_NL);
   put_fp12(out.target.data(), t);
   size_t nb = out.n_k - 1;
-  out.msm.assign(nb * 32 * 255 * MSM_ENTRY_DWORDS, 0);
+  // keys with more than G16_WIDE_MSM_MIN_INPUTS inputs: comb tables (BN254_WIDE_COMB=0 keeps the byte-window form for comparison)
+  const char* ce = getenv("BN254_WIDE_COMB");
+  out.msm_comb = nb > (size_t)G16_WIDE_MSM_MIN_INPUTS && !(ce && atoi(ce) == 0);
+  const size_t per_base = (out.msm_comb ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 255) * MSM_ENTRY_DWORDS;
+  out.msm.assign(nb * per_base, 0);
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 16) hw = 16;
   if (nb < hw) hw = (unsigned)(nb ? nb : 1);
   std::vector<std::thread> th;
   for (unsigned t_ = 0; t_ < hw; t_++)
-    th.emplace_back([&, t_]() { for (size_t i = t_; i < nb; i += hw) build_window_table(out.msm.data() + i * 32 * 255 * MSM_ENTRY_DWORDS, vk.k[i + 1]); });
+    th.emplace_back([&, t_]() {
+      for (size_t i = t_; i < nb; i += hw) {
+        if (out.msm_comb) build_comb_table(out.msm.data() + i * per_base, vk.k[i + 1]);
+        else build_window_table(out.msm.data() + i * per_base, vk.k[i + 1]);
+      }
+    });
   for (auto& x : th) x.join();
   return true;
 }

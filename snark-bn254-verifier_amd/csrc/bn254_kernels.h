@@ -44,6 +44,8 @@ struct G16LaunchArgs {
   const int32_t* target;    // 108 dwords: the GT element the product must equal, w-power (k) order
   int inputs_match_key;     // n_public + 1 == len(vk.K)
   int strict_scalars = 0;   // BN254_FLAG_STRICT_SCALARS: inputs >= r -> NOT_MEMBER
+  int msm_comb = 0;         // msm_tab of a key with many inputs is in comb form
+  uint16_t* msm_digits = nullptr;   // comb form: G16_COMB_COLS * n_public * n column digits (scratch)
   int part_of_larger = 0;   // this launch is one of several sub-batches of a larger batch: never the cooperative (small-batch) kernels
   int32_t* msm_part;        // wide keys: ceil(n_public / G16_WIDE_MSM_INPUTS_PER_LANE) * 27 * n dwords of partial sums, else nullptr
   // small batches (n <= G16_SPLIT_MAX_PROOFS): two extra streams and three events (fork, join, join) let the three pairs run their
@@ -54,6 +56,8 @@ struct G16LaunchArgs {
 #define G16_SPLIT_MAX_PROOFS 16384
 #define G16_WIDE_MSM_MIN_INPUTS 16      // above this many public inputs the MSM runs as (proof, chunk) lanes + a reduction
 #define G16_WIDE_MSM_INPUTS_PER_LANE 16
+#define G16_COMB_TEETH 13               // comb tables of keys with many inputs (bn254_host.hpp::build_comb_table): 13 teeth x 20 columns >= 256 bits
+#define G16_COMB_COLS 20
 #define G16_WIDE_MSM_MAX_PROOFS 65536   // proofs per launch on the wide path (bounds the partial-sum buffer: 442 MB at 1024 inputs)
 // kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
 enum {

@@ -386,6 +386,54 @@ k_g16_msm_partial(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, 
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
 }
+// The same sum from COMB tables (bn254_host.hpp::build_comb_table; keys prepared with msm_comb): the lane walks the 22 columns from the top,
+// doubling its accumulator once per column and adding, for each of its inputs, the entry selected by bits c, c + 22, ..., c + 242 of the
+// scalar: 22 additions per input and 22 doublings per lane instead of 32 additions per input.
+// k_g16_comb_digits first turns every scalar (big-endian bytes: bit b of the integer is bit b % 8 of byte 31 - b / 8) into its 22 column digits,
+// stored transposed -- digits[(col * n_public + s) * n + i] -- so that the lanes of a wavefront (consecutive proofs) read consecutive u16.
+__global__ void __launch_bounds__(256)
+k_g16_comb_digits(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, uint16_t* __restrict__ digits) {
+  const size_t g = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (g >= (size_t)n * (size_t)n_public) return;
+  const uint32_t s = (uint32_t)(g / n), i = (uint32_t)(g - (size_t)s * n);
+  const uint8_t* sp = inputs + ((size_t)i * (size_t)n_public + s) * 32;
+  uint32_t w[8];   // w[k]: bits 32 k .. 32 k + 31 of the integer
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const uint8_t* q = sp + 28 - 4 * k; w[k] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3]; }
+  for (int col = 0; col < G16_COMB_COLS; col++) {
+    uint32_t idx = 0;
+#pragma unroll
+    for (int t = 0; t < G16_COMB_TEETH; t++) {
+      const int base = G16_COMB_COLS * t;                   // static; the bit is base + col: at most one word further
+      const int wi = base >> 5, sh = base & 31;
+      const uint64_t two = ((uint64_t)(wi + 1 < 8 ? w[wi + 1 < 8 ? wi + 1 : 7] : 0u) << 32) | w[wi < 8 ? wi : 7];
+      const uint32_t bit = wi < 8 ? (uint32_t)((two >> (sh + col)) & 1u) : 0u;
+      idx |= bit << t;
+    }
+    digits[((size_t)col * (size_t)n_public + s) * n + i] = (uint16_t)idx;
+  }
+}
+__global__ void __launch_bounds__(256, 2)
+k_g16_msm_partial_comb(const uint16_t* __restrict__ digits, int n_public, uint32_t n, int per, int chunks, const uint8_t* __restrict__ status,
+                       const int32_t* __restrict__ msm_tab, int32_t* __restrict__ part) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n * (uint32_t)chunks) return;
+  const uint32_t c = g / n, i = g - c * n;
+  G1Proj acc = g1_identity();
+  if (status[i] & BN254_ST_PENDING) {
+    const int s_begin = (int)(c * per), s_end = (int)min((uint32_t)n_public, (c + 1) * (uint32_t)per);
+    for (int col = G16_COMB_COLS - 1; col >= 0; col--) {
+      if (col != G16_COMB_COLS - 1) acc = g1_dbl(acc);
+      for (int s = s_begin; s < s_end; s++) {
+        const uint32_t idx = digits[((size_t)col * (size_t)n_public + s) * n + i];
+        if (idx != 0) acc = g1_add_mixed(acc, msm_entry(msm_tab, ((size_t)s << G16_COMB_TEETH) + idx));
+      }
+    }
+  }
+  int32_t* o = part + (size_t)c * 27 * n + i;
+#pragma unroll
+  for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
+}
 // L = K0 + sum of the chunk sums (complete projective additions), to affine, identity flag into the status byte
 __global__ void __launch_bounds__(256, 2)
 k_g16_msm_reduce(const int32_t* __restrict__ part, int chunks, uint32_t n, int32_t* ws, uint8_t* __restrict__ status, const int32_t* __restrict__ k0) {
@@ -893,7 +941,15 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     // inputs of one proof spread over `chunks` lanes, proofs in slices that fit the partial-sum buffer
     const int per = G16_WIDE_MSM_INPUTS_PER_LANE, chunks = (a.n_public + per - 1) / per;
     unsigned pg = (unsigned)(((size_t)n * chunks + 255) / 256);
-    { ProfScope ps_(prof, KID_MSM_PARTIAL, s); hipLaunchKernelGGL(k_g16_msm_partial, dim3(pg), dim3(256), 0, s, a.inputs, a.n_public, n, per, chunks, (const uint8_t*)a.status, a.msm_tab, a.msm_part); }
+    {
+      ProfScope ps_(prof, KID_MSM_PARTIAL, s);
+      if (a.msm_comb) {
+        const size_t scalars = (size_t)n * (size_t)a.n_public;
+        hipLaunchKernelGGL(k_g16_comb_digits, dim3((unsigned)((scalars + 255) / 256)), dim3(256), 0, s, a.inputs, a.n_public, n, a.msm_digits);
+        hipLaunchKernelGGL(k_g16_msm_partial_comb, dim3(pg), dim3(256), 0, s, (const uint16_t*)a.msm_digits, a.n_public, n, per, chunks, (const uint8_t*)a.status, a.msm_tab, a.msm_part);
+      }
+      else hipLaunchKernelGGL(k_g16_msm_partial, dim3(pg), dim3(256), 0, s, a.inputs, a.n_public, n, per, chunks, (const uint8_t*)a.status, a.msm_tab, a.msm_part);
+    }
     if (chunks >= 16 && a.n <= 65536) {
       // eight lanes per proof: below one wavefront per SIMD the reduction is one lane's chain of additions
       ProfScope ps_(prof, KID_MSM_REDUCE, s);

@@ -191,6 +191,17 @@ def test_synth_identity_public_input_point_judged_by_oracle(pkg, O):
         assert O.groth16_verify_many(proofs, 256, vk, inputs, 3, n, mode) == exp
 
 
+def test_comb_table_constants_never_vanish():
+    """The comb tables of keys with many public inputs (bn254_host.hpp::build_comb_table) hold idx-weighted sums of 2^(22 i) K for every non-empty
+    set of teeth; K has order r, so an entry is the identity only if that sum of powers is a multiple of r: none is.  12 x 22 >= 256 bits."""
+    import re
+    hdr = open(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", "bn254_kernels.h")).read()
+    teeth = int(re.search(r"#define G16_COMB_TEETH (\d+)", hdr).group(1)); cols = int(re.search(r"#define G16_COMB_COLS (\d+)", hdr).group(1))
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    assert teeth * cols >= 256
+    assert all(sum(((idx >> i) & 1) << (cols * i) for i in range(teeth)) % R for idx in range(1, 1 << teeth))
+
+
 def test_no_constant_kzg_batching_scalar_in_the_product():
     """The PlonK path keys its batching scalars with getrandom(2) on every call (a ChaCha20 key and nonce, expanded per proof); no literal
     scalar may come back."""
