@@ -133,6 +133,14 @@ def model_kernel(name, ins):
             weight_ranges.append((h, latches[0], float(INV_SQUARINGS)))
             weight_ranges.append((latches[0] + 1, latches[1], float(INV_SET_BITS)))
             notes.append("Fermat inversion: %d squarings + %d products" % (INV_SQUARINGS, INV_SET_BITS))
+        elif name == "k_g16_msm_partial_comb":
+            # comb tables (bn254_kernels.hip): 20 columns x 16 inputs per lane; the compiler lays the column loop out as a doubling region followed
+            # by the input loop, so the two pieces are weighted directly: 19 doublings (none in the top column), 320 table additions unless the
+            # 13-bit column digit is zero
+            if 1700 <= c <= 1900:
+                weight_ranges.append((h, latches[-1], 320.0 * 8191.0 / 8192.0)); notes.append("320 table additions (%d mads each) unless the column digit is zero" % c)
+            elif 1150 <= c <= 1350 and not any(r[0] <= h and latches[-1] <= r[1] or h <= r[0] and r[1] <= latches[-1] for r in weight_ranges if r[2] == 19.0):
+                weight_ranges.append((h, latches[-1], 19.0)); notes.append("19 doublings (%d mads each)" % c)
         elif 1700 <= c <= 1900 and not inner:
             weight_ranges.append((h, latches[-1], 32.0 * 255.0 / 256.0))
             notes.append("byte-window loop: 32 windows per scalar, table addition (%d mads) unless the byte is zero" % c)
@@ -392,6 +400,13 @@ def main():
     if "k_f12_cyclo_sqr_n" in kernels:
         e = kernels["k_f12_cyclo_sqr_n"]
         e["mads_per_proof_batch"] = e["mads_per_proof_launch"] * 39     # all 39 launches of a batch together (exact: 186 squarings)
+    # keys with many public inputs: one lane per (proof, 16-input chunk); the per-proof figure is for BASELINE configs[4] (1024 inputs: 64 lanes)
+    for name in ("k_g16_msm_partial", "k_g16_msm_partial_comb"):
+        if name in kernels:
+            e = kernels[name]
+            e["mads_per_lane"] = e["mads_per_proof_launch"]; e["lanes_per_proof"] = 64
+            e["mads_per_proof_launch"] = e["mads_per_lane"] * 64
+            e["model"] += "; per proof = 64 lanes (1024 public inputs, 16 per lane)"
     kernels.update(model_coop12(funcs))
     out = {"_note": "v_mad_[iu]64_[iu]32 executed per proof (lane) and launch, from the gfx950 code object of libbn254_verify_amd.so; written by "
                     "tools/count_mads.py (loop trip counts and their sources: the `model` strings; n_public = %d)" % N_PUBLIC,
