@@ -45,4 +45,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk -o run -- 
 cd $R
 python bench.py --n-public 1024 --batch-log2 12 --steps 5 --warmup 1 --cpu-sample 128 > $O/cfg5.json 2> $O/cfg5.err || fail cfg5 $O/cfg5.err
 cut -c1-200 $O/cfg5.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -o run -- python3 $R/bench.py --n-public 1024 --batch-log2 12 --steps 5 --warmup 1 --no-cpu-baseline --no-rlc > $O/prof_cfg5.json 2> $O/prof_cfg5.err || fail "rocprof cfg5" $O/prof_cfg5.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_INT64 --output-format csv -d $O/pmc_cfg5 -o run -- python3 $R/bench.py --n-public 1024 --batch-log2 12 --steps 1 --warmup 0 --no-cpu-baseline --no-rlc > $O/pmc_cfg5.json 2> $O/pmc_cfg5.err || fail "pmc cfg5" $O/pmc_cfg5.err
+cd $R
 echo "round 2 GPU script done"

@@ -152,3 +152,23 @@ if cc:
     cc["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU SQ_WAVES on batch 4096 (bench.py --batch-log2 12; tools/bench_plonk.py): "
                    "instructions per wavefront and launch.  SQ_INSTS_VALU_INT64 = v_mad_[iu]64_[iu]32 + v_lshl_add_u64 + v_ashrrev_i64 (exact on the straight-line kernels)")
     json.dump(cc, open(os.path.join(out, "coop12_pmc_counts.json"), "w"), indent=1, sort_keys=True)
+
+# 1024 public inputs (BASELINE configs[4]): kernel trace and SQ counters
+kernel_stats("prof_cfg5/**/*kernel_trace.csv", rnd + "_cfg5_kernel_stats.csv",
+             "rocprofv3 --kernel-trace --stats -- python3 bench.py --n-public 1024 --batch-log2 12 --steps 5 --warmup 1 (6 batches of 4096 proofs, 1024 public inputs, comb tables)")
+pc = glob.glob(os.path.join(root, src, "pmc_cfg5/**/*counter_collection.csv"), recursive=True)
+if pc:
+    a = collections.defaultdict(lambda: collections.defaultdict(float)); n_ = collections.Counter(); waves = {}
+    for r in csv.DictReader(open(pc[0])):
+        k = short(r["Kernel_Name"])
+        if not k.startswith("k_"):
+            continue
+        a[k][r["Counter_Name"]] += float(r["Counter_Value"]); n_[(k, r["Counter_Name"])] += 1; waves[k] = int(r["Grid_Size"]) // 64
+    with open(os.path.join(out, rnd + "_cfg5_pmc_summary.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_INT64 "
+                "-- python3 bench.py --n-public 1024 --batch-log2 12 --steps 1 --warmup 0\n")
+        f.write("kernel,waves,valu_active_frac,wait_any_frac,valu_insts_per_wave,int64_insts_per_wave\n")
+        for k, v in sorted(a.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
+            wc = v["SQ_WAVE_CYCLES"] or 1
+            f.write("%s,%d,%.3f,%.3f,%.0f,%.0f\n" % (k, waves[k], v["SQ_ACTIVE_INST_VALU"] / wc, v["SQ_WAIT_ANY"] / wc,
+                                                      v["SQ_INSTS_VALU"] / n_[(k, "SQ_INSTS_VALU")] / waves[k], v["SQ_INSTS_VALU_INT64"] / n_[(k, "SQ_INSTS_VALU_INT64")] / waves[k]))
