@@ -1111,6 +1111,29 @@ int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2
   return BN254_OK;
 }
 
+// host-only probe of the comb tables of keys with many public inputs: x * P from build_comb_table(P) and the column digits the kernels use
+int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]) {
+  if (!p64 || !x32 || !out64) return set_err(BN254_E_BAD_ARG, "bad argument");
+  G1Aff P; P.x = fp_from_be(p64); P.y = fp_from_be(p64 + 32);
+  if (!g1_on_curve(P)) return set_err(BN254_E_BAD_ARG, "not a curve point");
+  std::vector<int32_t> tab(((size_t)1 << G16_COMB_TEETH) * MSM_ENTRY_DWORDS);
+  build_comb_table(tab.data(), P);
+  uint32_t w[8];
+  for (int k = 0; k < 8; k++) { const uint8_t* q = x32 + 28 - 4 * k; w[k] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3]; }
+  G1Proj acc = g1_identity();
+  for (int col = G16_COMB_COLS - 1; col >= 0; col--) {
+    acc = g1_dbl(acc);
+    const uint32_t idx = g16_comb_digit(w, col);
+    if (idx) {
+      G1Aff e; e.x = fp_from_limbs(tab.data() + (size_t)idx * MSM_ENTRY_DWORDS); e.y = fp_from_limbs(tab.data() + (size_t)idx * MSM_ENTRY_DWORDS + BN_NL);
+      acc = g1_add_mixed(acc, e);
+    }
+  }
+  if (g1_is_identity(acc)) { memset(out64, 0, 64); return BN254_OK; }
+  enc_g1_uncompressed(out64, g1_to_affine(acc));
+  return BN254_OK;
+}
+
 // ---------------------------------------------------------------- synthetic workload generator
 size_t bn254_synth_groth16_vk_len(size_t n_public) { return 292 + 32 * (n_public + 1) + 4 + 128; }
 

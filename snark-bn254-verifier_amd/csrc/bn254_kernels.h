@@ -58,6 +58,20 @@ struct G16LaunchArgs {
 #define G16_WIDE_MSM_INPUTS_PER_LANE 16
 #define G16_COMB_TEETH 13               // comb tables of keys with many inputs (bn254_host.hpp::build_comb_table): 13 teeth x 20 columns >= 256 bits
 #define G16_COMB_COLS 20
+// column digit of a scalar given as eight 32-bit words (w[k]: bits 32 k .. 32 k + 31): bit t of the digit is bit col + G16_COMB_COLS * t of the scalar
+// (bits from 256 up are zero).  Shared by k_g16_comb_digits and the host-side check (bn254_dbg_comb_mul).
+static inline __host__ __device__ uint32_t g16_comb_digit(const uint32_t w[8], int col) {
+  uint32_t idx = 0;
+#pragma unroll
+  for (int t = 0; t < G16_COMB_TEETH; t++) {
+    const int base = G16_COMB_COLS * t;                   // static; the bit is base + col: at most one word further
+    const int wi = base >> 5, sh = base & 31;
+    const uint64_t two = ((uint64_t)(wi + 1 < 8 ? w[wi + 1 < 8 ? wi + 1 : 7] : 0u) << 32) | w[wi < 8 ? wi : 7];
+    const uint32_t bit = wi < 8 ? (uint32_t)((two >> (sh + col)) & 1u) : 0u;
+    idx |= bit << t;
+  }
+  return idx;
+}
 #define G16_WIDE_MSM_MAX_PROOFS 65536   // proofs per launch on the wide path (bounds the partial-sum buffer: 442 MB at 1024 inputs)
 // kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
 enum {

@@ -401,15 +401,7 @@ k_g16_comb_digits(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, 
 #pragma unroll
   for (int k = 0; k < 8; k++) { const uint8_t* q = sp + 28 - 4 * k; w[k] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3]; }
   for (int col = 0; col < G16_COMB_COLS; col++) {
-    uint32_t idx = 0;
-#pragma unroll
-    for (int t = 0; t < G16_COMB_TEETH; t++) {
-      const int base = G16_COMB_COLS * t;                   // static; the bit is base + col: at most one word further
-      const int wi = base >> 5, sh = base & 31;
-      const uint64_t two = ((uint64_t)(wi + 1 < 8 ? w[wi + 1 < 8 ? wi + 1 : 7] : 0u) << 32) | w[wi < 8 ? wi : 7];
-      const uint32_t bit = wi < 8 ? (uint32_t)((two >> (sh + col)) & 1u) : 0u;
-      idx |= bit << t;
-    }
+    const uint32_t idx = g16_comb_digit(w, col);
     digits[((size_t)col * (size_t)n_public + s) * n + i] = (uint16_t)idx;
   }
 }

@@ -191,6 +191,24 @@ def test_synth_identity_public_input_point_judged_by_oracle(pkg, O):
         assert O.groth16_verify_many(proofs, 256, vk, inputs, 3, n, mode) == exp
 
 
+def test_comb_table_multiplication_vs_oracle(pkg, O):
+    """x * P from the comb table of P and the kernels' column digits (host probe) equals the oracle's scalar multiplication, for scalars that are
+    raw 256-bit values (used modulo r like bn::Fr), all-ones, single bits at tooth and word boundaries, zero."""
+    import random
+    L = pkg.lib()
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = random.Random(3)
+    g = O.g1_gen()
+    for p in (g, O.g1_mul(g, rng.randrange(1, R))):
+        xs = [0, 1, 2, R - 1, R, R + 5, (1 << 256) - 1, (1 << 255), (1 << 240) + (1 << 20), (1 << 19) | (1 << 39) | (1 << 259 - 20)]
+        xs += [1 << b for b in (19, 20, 31, 32, 63, 64, 199, 200, 239, 240, 255)] + [rng.getrandbits(256) for _ in range(6)]
+        for x in xs:
+            out = (C.c_uint8 * 64)()
+            assert L.bn254_dbg_comb_mul(p, x.to_bytes(32, "big"), out) == 0
+            k = x % R
+            assert bytes(out) == (O.g1_mul(p, k) if k else bytes(64)), hex(x)
+
+
 def test_comb_table_constants_never_vanish():
     """The comb tables of keys with many public inputs (bn254_host.hpp::build_comb_table) hold idx-weighted sums of 2^(22 i) K for every non-empty
     set of teeth; K has order r, so an entry is the identity only if that sum of powers is a multiple of r: none is.  12 x 22 >= 256 bits."""
