@@ -88,7 +88,8 @@ typedef struct bn254_g16_pvk bn254_g16_pvk;
 
 /* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
  * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
- * Miller-loop line tables for the two fixed G2 arguments, fixed-base window tables for vk.K.  Host work; no GPU needed. */
+ * Miller-loop line tables for the two fixed G2 arguments, fixed-base tables for vk.K (byte windows, 650 KB per input; keys with more
+ * than 16 inputs: comb tables, 655 KB per input, 2.2 s for 1024 inputs on 8 host threads).  Host work; no GPU needed. */
 int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out);
 void bn254_groth16_vk_free(bn254_g16_pvk* pvk);
 /* number of public inputs the key expects (len(vk.K) - 1) */
