@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Concurrency soak on one GPU: host threads that share prepared keys and hammer, side by side, the Groth16 batch entry at several sizes (cooperative
-and one-proof-per-lane kernels), the single-proof entry (prepared-key cache, five keys through four slots), the RLC flag and the PlonK batch entry
+and one-proof-per-lane kernels), the single-proof entry (prepared-key cache, five keys through four slots), the RLC flag, a 300-input key (comb tables) and the PlonK batch entry
 (thread pool, per-context scratch).  Every answer is compared with the generator's expected statuses / the first answer.
   python tools/gpu_soak_mixed.py [seconds]"""
 import importlib, json, os, random, sys, threading, time
@@ -24,6 +24,8 @@ for i in range(1500):
         q = bytearray(q); q[rng.randrange(64)] ^= 1 << rng.randrange(8); q = bytes(q)
     pp.append(p); pi.append(q)
 ppb, pib = b"".join(pp), b"".join(pi)
+wide = pkg.synth_groth16(0xB2540C00, 300, 3000, invalid_every=9, agree=True, threads=16)     # comb tables, chunked MSM, eight-lane reduction
+wide_pvk = pkg.PreparedVk(wide[0])
 plonk = pkg.PreparedPlonkVk(pl_vk)
 plonk_ref = plonk.verify_batch(ppb, pib)
 assert plonk_ref.count(bytes([pkg.ACCEPT])) == 1200
@@ -59,6 +61,18 @@ def g16_single(seed):
         note("g16_single")
 
 
+def g16_wide(seed):
+    r = random.Random(seed)
+    vk_w, pr, inp, ex = wide
+    while time.time() < stop and not errors:
+        n = r.choice([1, 40, 777, 3000])
+        off = r.randrange(0, 3000 - n + 1)
+        st = wide_pvk.verify_batch(pr[256 * off:256 * (off + n)], inp[9600 * off:9600 * (off + n)], n)
+        if st != ex[off:off + n]:
+            errors.append(("g16 wide", n, off))
+        note("g16_wide")
+
+
 def plonk_batches(seed):
     r = random.Random(seed)
     while time.time() < stop and not errors:
@@ -70,7 +84,7 @@ def plonk_batches(seed):
         note("plonk_batch")
 
 
-th = [threading.Thread(target=g16_batches, args=(1,)), threading.Thread(target=g16_batches, args=(2,)), threading.Thread(target=g16_single, args=(3,)),
+th = [threading.Thread(target=g16_batches, args=(1,)), threading.Thread(target=g16_batches, args=(2,)), threading.Thread(target=g16_single, args=(3,)), threading.Thread(target=g16_wide, args=(6,)),
       threading.Thread(target=plonk_batches, args=(4,)), threading.Thread(target=plonk_batches, args=(5,))]
 for t in th: t.start()
 for t in th: t.join()
