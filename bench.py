@@ -10,9 +10,13 @@ child process, before this process has imported torch or touched a GPU -- relays
 A step = one pass of the whole hot path (parse + checks + public-input MSM, G2 subgroup test, 3-pair Miller loop, final
 exponentiation, status bytes) over one batch of synthetic gnark-format proofs that are ALREADY RESIDENT IN HBM, followed by
 the one collective of the path: the all_gather of the accept/reject bytes (RCCL over xGMI; a no-op at N = 1).
-Workload at N = 1: BASELINE.json configs[2], batch 2^20, 2 public inputs, 1/16 of the proofs invalid (5 failure classes).
-For N > 1 every rank verifies its own 2^20-proof shard of an N * 2^20 batch (weak scaling, no data-path communication).
+Workload: BASELINE.json configs[2], ONE batch of 2^20 proofs, 2 public inputs, 1/16 of the proofs invalid (5 failure classes).
+For N > 1 that batch is sharded: rank r verifies the contiguous range sharding.shard_bounds(2^20, N, r) -- 2^19 / 2^18 / 2^17 proofs per
+GPU at N = 2 / 4 / 8 -- with no data-path communication: STRONG scaling, `global_batch` stays 2^20.  Every rank
+generates only its own range of the proof stream (bn254_synth_groth16_range).  --weak keeps 2^batch-log2 proofs PER GPU instead.
 After the timed region the statuses are compared with the generator's expected statuses: a wrong answer aborts the bench.
+At N = 1 the line also carries `configs`: the other BASELINE configurations (batch 4096, PlonK 4096, 1024 public inputs x 4096, the
+host-buffer entry at 2^20, single-proof latency), each timed in this run with its own roofline and status check.
 
 One JSON line on rank 0:
   roofline      the binding bound of this path, the integer VALU: 32x32+64-bit multiply-adds of the dominant kernel kind (static count
@@ -37,7 +41,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_PROOF = 321      # 256 B proof + 64 B public inputs in, 1 B status out
+def algo_bytes_per_proof(n_public):
+    """256 B proof + 32 B per public input in, 1 B status out (321 B at 2 inputs, 33 025 B at 1024)."""
+    return 256 + 32 * n_public + 1
+
+
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_MAD_PER_S = 35.1e12   # measured v_mad_u64_u32 lane-rate, profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64)
 METRIC = "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X"
@@ -49,7 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-log2", type=int, default=20, help="proofs per GPU = 2^this (default: BASELINE 2^20)")
+    ap.add_argument("--batch-log2", type=int, default=20, help="the (global) batch = 2^this proofs (default: BASELINE 2^20), sharded over the GPUs")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 2^batch-log2 proofs PER GPU (the global batch grows with --gpus)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations, N = 1 only)")
     ap.add_argument("--n-public", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="proofs timed on the host per cpu_baseline row")
@@ -80,16 +90,6 @@ def self_launch(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------------
 # workload
 # ---------------------------------------------------------------------------------------------------------------------------
-def rotate_shard(proofs, inputs, expected, n, n_public, rank):
-    """Every rank shares the key (same seed); rank r > 0 takes the same proof stream rotated by (r * 7919) mod n so that shards
-    are not byte-identical.  Returns (proofs, inputs, expected)."""
-    k = (rank * 7919) % n if rank > 0 else 0
-    if k == 0:
-        return proofs, inputs, expected
-    sz = 32 * n_public
-    return proofs[256 * k:] + proofs[:256 * k], inputs[sz * k:] + inputs[:sz * k], expected[k:] + expected[:k]
-
-
 class GpuVerifier:
     """The product path on one GPU: inputs resident in HBM, verify_batch_device on the current stream."""
 
@@ -142,17 +142,20 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
     """The rank logic of the bench: workload (shared key, rotated shard), warm-up, K timed steps each ending in the status
     all_gather, max-over-ranks timing, correctness check of the local and the gathered statuses, JSON line on rank 0.
     make_verifier(vk, proofs, inputs, local_rank) -> object with step()/sync()/timer()/... (GpuVerifier, or a stand-in in the
-    gloo CPU test); synth(seed, n_public, n, threads) -> (vk, proofs, inputs, expected)."""
+    gloo CPU test); synth(seed, n_public, first, n, threads) -> (vk, proofs, inputs, expected) for the proofs [first, first + n) of the
+    stream (the key is the same for every range)."""
     import torch
     import torch.distributed as dist
     sharding = importlib.import_module("snark-bn254-verifier_amd.sharding")
 
-    n = 1 << args.batch_log2                      # per-GPU shard
-    n_total = n * world
+    # strong scaling (default): ONE batch of 2^batch_log2 proofs, rank r takes the contiguous range shard_bounds(n_total, world, r);
+    # --weak: 2^batch_log2 proofs per rank, rank r = range [r n, (r + 1) n) of the same stream
+    n_total = (1 << args.batch_log2) * (world if args.weak else 1)
+    lo, hi = sharding.shard_bounds(n_total, world, rank)
+    n = hi - lo                                   # this rank's shard
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    vk, proofs, inputs, expected = synth(SEED, args.n_public, n, threads)
-    proofs, inputs, expected = rotate_shard(proofs, inputs, expected, n, args.n_public, rank)
+    vk, proofs, inputs, expected = synth(SEED, args.n_public, lo, n, threads)
     gen_s = time.time() - t0
     v = make_verifier(vk, proofs, inputs, local_rank)
 
@@ -210,7 +213,6 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
     # correctness of the timed work: this rank's shard, and its slice of the gathered vector
     got = v.status_bytes()
     assert got == expected, "rank %d: statuses differ from the expected statuses" % rank
-    lo, hi = sharding.shard_bounds(n_total, world, rank)
     assert full.numel() == n_total, "gathered vector has the wrong length"
     assert bytes(full[lo:hi].cpu().numpy().tobytes()) == expected, "gathered statuses are wrong"
 
@@ -218,21 +220,23 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = n_total * args.steps / elapsed
-        headline = (args.n_public, args.batch_log2, bool(args.rlc)) == (2, 20, False)
+        headline = (args.n_public, args.batch_log2, bool(args.rlc), bool(args.weak)) == (2, 20, False, False)
+        algo = algo_bytes_per_proof(args.n_public)
         out = {
-            "metric": METRIC if headline else "Groth16 verifies/sec (%d pub-inputs) at batch=2^%d%s" % (args.n_public, args.batch_log2, ", RLC batch mode" if args.rlc else ""),
+            "metric": METRIC if headline else "Groth16 verifies/sec (%d pub-inputs) at batch=2^%d%s%s" % (args.n_public, args.batch_log2, " per GPU" if args.weak else "", ", RLC batch mode" if args.rlc else ""),
             "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: batch 2^%d Groth16 proofs per GPU, %d public inputs, gnark-format bytes, 1/16 invalid"
-                                   % (4 if args.n_public == 1024 else 2, args.batch_log2, args.n_public),
+            "config": {"workload": "BASELINE configs[%d]: %s of 2^%d Groth16 proofs%s, %d public inputs, gnark-format bytes, 1/16 invalid"
+                                   % (4 if args.n_public == 1024 else 2, "batches" if args.weak else "ONE batch", args.batch_log2,
+                                      " per GPU" if args.weak else (" sharded over %d GPUs (contiguous ranges)" % world if world > 1 else ""), args.n_public),
                        "batch_per_gpu": n, "global_batch": n_total, "n_public": args.n_public, "vk_mode": "reference",
                        "mode": "rlc (random linear combination, exact fallback)" if args.rlc else "exact",
-                       "parallelism": "independent proof shards x%d + all_gather of status bytes" % world,
+                       "parallelism": "independent contiguous proof shards x%d + all_gather of status bytes" % world,
                        "gather_ms": gather_ms, "gen_seconds": round(gen_s, 1)},
-            "hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_proof": ALGO_BYTES_PER_PROOF, "achieved": value / world * ALGO_BYTES_PER_PROOF / 1e9,
-                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value / world * ALGO_BYTES_PER_PROOF / 1e9 / HBM_PEAK_GBPS,
-                             "note": "SURVEY.md 8(d): 256 B proof + 64 B inputs in, 1 B status out; the path is arithmetic-bound"},
+            "hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_proof": algo, "achieved": value / world * algo / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value / world * algo / 1e9 / HBM_PEAK_GBPS,
+                             "note": "SURVEY.md 8(d): 256 B proof + 32 B per public input in, 1 B status out; the path is arithmetic-bound"},
             "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},
             "phases_ms": {k: sum(x) / len(x) for k, x in phase_ms.items()},
         }
@@ -240,7 +244,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
             dom = max(prof, key=lambda k: prof[k][1])
             out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, concurrent=per_launch < n)
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
-            out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown)
+            out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown, algo)
         emit(json.dumps(out))
     return out
 
@@ -292,7 +296,7 @@ def _valu_whole_path(breakdown, proofs_per_s_per_gpu):
             "kernels_without_count": missing}
 
 
-def _traffic_whole_path(breakdown):
+def _traffic_whole_path(breakdown, algo):
     """HBM bytes per proof over the whole path: per kernel kind, counter bytes per proof and launch (profiles/pmc_traffic.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) x its launches per batch."""
     t = _load_json("pmc_traffic.json")
@@ -305,7 +309,7 @@ def _traffic_whole_path(breakdown):
             missing.append(k)
             continue
         total += cnt * (e["read_bytes_per_proof"] + e["write_bytes_per_proof"])
-    return {"counter_bytes_per_proof": total, "algorithmic_bytes_per_proof": ALGO_BYTES_PER_PROOF, "ratio": total / ALGO_BYTES_PER_PROOF,
+    return {"counter_bytes_per_proof": total, "algorithmic_bytes_per_proof": algo, "ratio": total / algo,
             "kernels_without_counters": missing}
 
 
@@ -349,8 +353,10 @@ def _host_buffer_line(args, pkg, vk, proofs, inputs, expected, local_rank):
     n = len(expected)
     pvk.verify_batch(proofs, inputs, n, 256, args.n_public, local_rank)     # warm-up (allocations, pinned staging)
     t = time.perf_counter()
-    st = pvk.verify_batch(proofs, inputs, n, 256, args.n_public, local_rank)
-    dt = time.perf_counter() - t
+    reps = 2
+    for _ in range(reps):
+        st = pvk.verify_batch(proofs, inputs, n, 256, args.n_public, local_rank)
+    dt = (time.perf_counter() - t) / reps
     assert st == expected
     pvk.close()
     return {"value": n / dt, "unit": "proofs/s", "ms": dt * 1e3, "note": "bn254_groth16_verify_batch on pageable host buffers: H2D of proofs and inputs, compute, D2H of status"}
@@ -388,6 +394,177 @@ def _rlc_line(args, pkg, local_rank):
     return row
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# `configs`: the other BASELINE configurations, timed in the same run (N = 1, rank 0), each with its status check and roofline
+# ---------------------------------------------------------------------------------------------------------------------------
+class _Cfg:
+    """argparse-like carrier for GpuVerifier"""
+    def __init__(self, n_public, rlc=False):
+        self.n_public, self.rlc = n_public, rlc
+
+
+def device_config(pkg, local_rank, label, n_public, n, steps, warmup, seed, oracle_sample):
+    """A Groth16 batch through the same device-resident entry point as the headline: synthetic workload (1/16 invalid), inputs resident,
+    K timed steps between synchronisations, statuses against the generator's prediction and -- on a strided sample -- against the oracle."""
+    import torch
+    t0 = time.time()
+    vk, proofs, inputs, expected = pkg.synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=min(16, os.cpu_count() or 1))
+    gen_s = time.time() - t0
+    t0 = time.time()
+    v = GpuVerifier(_Cfg(n_public), pkg, vk, proofs, inputs, local_rank)
+    prep_s = time.time() - t0
+    v.select_kernels(None)
+    for _ in range(max(1, warmup)):
+        v.step()
+    v.sync()
+    breakdown, per_launch = v.kernel_profile()
+    dom = max(breakdown, key=lambda k: breakdown[k][1])
+    v.select_kernels([dom])
+    v.sync()
+    prof = (0, 0.0)
+    t = time.perf_counter()
+    for _ in range(steps):
+        v.step()
+        kp, per_launch = v.kernel_profile()
+        if dom in kp:
+            prof = (prof[0] + kp[dom][0], prof[1] + kp[dom][1])
+    v.sync()
+    dt = (time.perf_counter() - t) / steps
+    got = v.status_bytes()
+    assert got == expected, "%s: statuses differ from the expected statuses" % label
+    checked = 0
+    if oracle_sample:
+        from oracle import oracle as O
+        O.build(); O.lib(); O.set_threads(min(16, len(os.sched_getaffinity(0))))
+        idx = list(range(0, n, max(1, n // oracle_sample)))[:oracle_sample]
+        sz = 32 * n_public
+        sp = b"".join(proofs[256 * i:256 * i + 256] for i in idx); si = b"".join(inputs[sz * i:sz * i + sz] for i in idx)
+        ref = O.groth16_verify_many(sp, 256, vk, si, n_public, len(idx), O.MODE_REFERENCE)
+        assert bytes(got[i] for i in idx) == ref, "%s: statuses differ from the oracle" % label
+        checked = len(idx)
+    algo = algo_bytes_per_proof(n_public)
+    value = n / dt
+    out = {"workload": label, "value": value, "unit": "proofs/s", "ms_per_step": dt * 1e3, "steps": steps, "batch": n, "n_public": n_public,
+           "status_check": "all %d statuses == generator's; %d strided proofs == oracle" % (n, checked),
+           "roofline": _valu_roofline(dom, prof, per_launch, concurrent=per_launch < n),
+           "valu_whole_path": _valu_whole_path(breakdown, value),
+           "hbm_roofline": {"algorithmic_bytes_per_proof": algo, "achieved": value * algo / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value * algo / 1e9 / HBM_PEAK_GBPS},
+           "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},
+           "gen_seconds": round(gen_s, 2), "key_prepare_and_upload_seconds": round(prep_s, 2)}
+    v.pvk.close()
+    del v
+    torch.cuda.empty_cache()
+    return out
+
+
+def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
+    """BASELINE configs[3]: PlonK batch (the reference's 4 fixtures + mutated copies, every 8th proof invalid), host buffers in, status bytes
+    out.  Statuses of the first cpu_sample proofs against the oracle; cpu_baseline = the oracle's PlonK verifier on one core."""
+    import random
+    from oracle import oracle as O
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    vk = open(os.path.join(ROOT, "tests", "golden", "plonk_vk.bin"), "rb").read()
+    base = [(bytes.fromhex(f["raw_proof"]), b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"])) for f in fx.values() if f["variant"] == "plonk"]
+    rng = random.Random(4)
+    proofs, inputs = [], []
+    for i in range(batch):
+        p, q = base[i % len(base)]
+        if i % 8 == 7:
+            q = bytearray(q); q[rng.randrange(64)] ^= 1 << rng.randrange(8); q = bytes(q)
+        proofs.append(p); inputs.append(q)
+    pb, ib = b"".join(proofs), b"".join(inputs)
+    pvk = pkg.PreparedPlonkVk(vk)
+    for _ in range(warmup):
+        st = pvk.verify_batch(pb, ib)
+    t = time.perf_counter()
+    for _ in range(steps):
+        st = pvk.verify_batch(pb, ib)
+    dt = time.perf_counter() - t
+    # the dominant GPU kernel against the VALU peak: the merged k_g1_scalar_mul launch of stage 2 (one lane per scalar multiplication,
+    # multiply-adds per lane from the code object: tools/count_mads.py), and the pairing check on the cooperative kernel
+    stage_ms, lanes = pvk.last_timing()
+    km = (_load_json("kernel_mads.json") or {}).get("kernels", {})
+    peak = VALU_PEAK_MAD_PER_S
+    env = os.environ.get
+    roofline = pairing = None
+    if "k_g1_scalar_mul" in km and stage_ms.get("k_g1_scalar_mul_stage2", 0) > 0:
+        split = (lanes[1] * 2 <= 65536 or env("BN254_MSM_SPLIT") == "1") and env("BN254_MSM_SPLIT") != "0"      # bn254_g1_msm_split
+        w2 = lanes[1] * (2 if split else 1) <= 65536 and env("BN254_MSM_W2", "1") != "0"                          # bn254_g1_msm_tab_lanes
+        e = km["k_g1_scalar_mul" + ("_split" if split else "") + ("_w2" if w2 else "")]
+        sm = e["mads_per_proof_launch"]                                                            # the longest lane's chain
+        useful = km["k_g1_scalar_mul"]["mads_per_proof_launch"] * lanes[1]                          # the work of the unsplit algorithm
+        ach = useful / (stage_ms["k_g1_scalar_mul_stage2"] * 1e-3)
+        n_lanes = lanes[1] * (2 if split else 1)
+        roofline = {"bound": "valu", "kernel": "k_g1_scalar_mul" + ("<split>" if split else "") + ("<two-bit windows>" if w2 else ""), "unit": "T mad/s", "peak": peak / 1e12, "achieved": ach / 1e12, "frac": ach / peak,
+                    "avg_launch_ms": stage_ms["k_g1_scalar_mul_stage2"], "terms_per_launch": lanes[1], "lanes_per_launch": n_lanes, "mads_per_term_unsplit": km["k_g1_scalar_mul"]["mads_per_proof_launch"],
+                    "longest_lane_chain_mads": sm, "traffic": None,
+                    "note": "%d lanes = %.2f wavefronts per SIMD: the launch lasts as long as its longest lane's chain (%d multiply-adds); achieved = multiply-adds of the "
+                            "one-lane-per-term algorithm / launch time; peak = measured issue rate with full occupancy (profiles/r01_ubench_valu.txt)" % (n_lanes, n_lanes / 64 / 1024.0, int(sm))}
+        pc = km.get("k_coop12_miller_fixed")
+        if pc and batch <= 40960 and stage_ms.get("pairing_check", 0) > 0:
+            a2 = pc["mads_per_proof_launch"] * min(batch, 65536) / (stage_ms["pairing_check"] * 1e-3)
+            pairing = {"kernel": "k_coop12_miller_fixed", "ms": stage_ms["pairing_check"], "mads_per_proof": pc["mads_per_proof_launch"], "achieved": a2 / 1e12, "frac": a2 / peak}
+    m = min(cpu_sample, batch)
+    t = time.perf_counter()
+    ref = bytes(O.plonk_verify(proofs[i], vk, [int.from_bytes(inputs[i][:32], "big"), int.from_bytes(inputs[i][32:], "big")]) for i in range(m))
+    cdt = time.perf_counter() - t
+    assert st[:m] == ref, "PlonK: GPU statuses differ from the oracle"
+    assert st.count(bytes([pkg.ACCEPT])) == batch - batch // 8
+    pvk.close()
+    return {"workload": "BASELINE configs[3]: PlonK batch %d, 904-byte proofs (the reference's fixtures + mutations), 2 public inputs, 1/8 invalid; host buffers in, status bytes out" % batch,
+            "value": batch * steps / dt, "unit": "proofs/s", "ms_per_step": dt * 1e3 / steps, "steps": steps, "batch": batch,
+            "status_check": "first %d statuses == oracle; %d ACCEPT of %d" % (m, batch - batch // 8, batch),
+            "roofline": roofline, "pairing_check": pairing, "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "hbm_roofline": {"algorithmic_bytes_per_proof": 904 + 64 + 1, "achieved": batch * steps / dt * 969 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": batch * steps / dt * 969 / 1e9 / HBM_PEAK_GBPS},
+            "cpu_baseline": {"value": m / cdt, "unit": "proofs/s", "cores": 1, "kind": "port", "sample": "first %d proofs, %.1f s" % (m, cdt)}}
+
+
+def single_proof_config(pkg):
+    """BASELINE configs[0] shape: the reference-shaped entry points, one proof per call (key bytes on every call as lib.rs:44-49; the prepared
+    form of the last keys is cached by the library)."""
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540042, 2, 4, invalid_every=0, agree=True, threads=2)
+    ins = [int.from_bytes(inputs[32 * i:32 * i + 32], "big") for i in range(2)]
+    out = {"workload": "BASELINE configs[0]: Groth16Verifier::verify / PlonkVerifier::verify, one proof per call, vk bytes per call"}
+    t = time.perf_counter()
+    st = pkg.Groth16Verifier.verify(proofs[:256], vk, ins)
+    out["groth16_first_call_ms"] = (time.perf_counter() - t) * 1e3
+    reps = 20
+    t = time.perf_counter()
+    for _ in range(reps):
+        st = pkg.Groth16Verifier.verify(proofs[:256], vk, ins)
+    out["groth16_verify_ms"] = (time.perf_counter() - t) / reps * 1e3
+    assert st == pkg.ACCEPT
+    bad = bytearray(proofs[:256]); bad[200] ^= 1
+    assert pkg.Groth16Verifier.verify(bytes(bad), vk, ins) != pkg.ACCEPT
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
+    pvkb = open(os.path.join(ROOT, "tests", "golden", "plonk_vk.bin"), "rb").read()
+    f = [f for f in fx.values() if f["variant"] == "plonk"][0]
+    pp, pi = bytes.fromhex(f["raw_proof"]), [int(x) for x in f["public_inputs"]]
+    pkg.PlonkVerifier.verify(pp, pvkb, pi)
+    t = time.perf_counter()
+    for _ in range(reps):
+        st = pkg.PlonkVerifier.verify(pp, pvkb, pi)
+    out["plonk_verify_ms"] = (time.perf_counter() - t) / reps * 1e3
+    assert st == pkg.ACCEPT
+    out["status_check"] = "valid proof ACCEPT, tampered proof not; the reference's PlonK fixture ACCEPT"
+    return out
+
+
+def other_configs(args, pkg, local_rank, resident_value, keep):
+    """The `configs` block of the bench line."""
+    cfg = {}
+    cfg["batch4096"] = device_config(pkg, local_rank, "BASELINE configs[1]: batch 4096 Groth16 proofs, 2 public inputs, inputs resident", 2, 4096, 20, 2, 0xB2540001, 64)
+    cfg["plonk4096"] = plonk_config(pkg, 4096, 5, 1, 32)
+    cfg["groth16_1024x4096"] = device_config(pkg, local_rank, "BASELINE configs[4]: batch 4096 Groth16 proofs, 1024 public inputs, inputs resident", 1024, 4096, 5, 1, 0xB2540004, 16)
+    hb = _host_buffer_line(args, pkg, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"], local_rank)
+    hb["workload"] = "the headline batch through bn254_groth16_verify_batch on pageable host buffers (PCIe-inclusive; never `value`)"
+    hb["ratio_to_resident"] = hb["value"] / resident_value
+    cfg["host_buffers_2^%d" % args.batch_log2] = hb
+    cfg["single_proof"] = single_proof_config(pkg)
+    return cfg
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -415,8 +592,8 @@ def main(argv=None):
         keep.update(vk=vk, proofs=proofs, inputs=inputs)
         return GpuVerifier(args, pkg, vk, proofs, inputs, lr)
 
-    def synth(seed, n_public, n, threads):
-        r = pkg.synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=threads)
+    def synth(seed, n_public, first, n, threads):
+        r = pkg.synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=threads, first=first)
         keep["expected0"] = r[3]
         return r
 
@@ -424,12 +601,15 @@ def main(argv=None):
     out = run_rank(args, make, "nccl", rank, world, local_rank, synth, emit=lines.append)
     if rank == 0:
         if world == 1:
-            if args.host_buffers:
+            headline = (args.n_public, args.batch_log2, bool(args.rlc), bool(args.weak)) == (2, 20, False, False)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = _cpu_baseline(args, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"])
+            if headline and not args.no_configs:
+                out["configs"] = other_configs(args, pkg, local_rank, out["value"], keep)
+            elif args.host_buffers:
                 out["host_buffers"] = _host_buffer_line(args, pkg, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"], local_rank)
             if not args.no_rlc and not args.rlc and args.n_public <= 8:
                 out["rlc_mode"] = _rlc_line(args, pkg, local_rank)
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = _cpu_baseline(args, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"])
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

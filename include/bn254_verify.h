@@ -77,11 +77,11 @@ enum { BN254_VK_REFERENCE = 0, BN254_VK_GNARK = 1 };
  *     (a false ACCEPT).  Loader errors (member / curve / subgroup) are always exact.  The weights come from ChaCha20 keyed by
  *     getrandom(2) per call.  The call synchronises the stream once (to learn which groups failed).
  *     The mode is a longer pipeline than the exact path and pays from about 200 000 proofs (2.0 x at 2^20): below that the flag is
- *     ignored (BN254_RLC_MIN_BATCH in the environment moves the threshold; never below 64).
+ *     ignored (bn254_set_rlc_params, or BN254_RLC_MIN_BATCH in the environment when the library is loaded, moves the threshold; never below 64).
  *     Adaptive: an RLC pass costs about half an exact pass and every proof of a failed group pays the exact pass on top, so per
  *     (key, device) the share of proofs that fell back is tracked, and while it is above 0.45 the flag is ignored (the exact path
- *     runs: same status bytes) except for one measuring RLC pass every 8 calls.  BN254_RLC_ADAPTIVE=0 in the environment
- *     switches this off; bn254_groth16_rlc_state reports the tracked share (-1: no RLC pass yet) and the number of bypassed calls. */
+ *     runs: same status bytes) except for one measuring RLC pass every 8 calls.  bn254_set_rlc_params(-1, 0, -1) (or
+ *     BN254_RLC_ADAPTIVE=0 in the environment at load time) switches this off; bn254_groth16_rlc_state reports the tracked share (-1: no RLC pass yet) and the number of bypassed calls. */
 enum { BN254_FLAG_STRICT_SCALARS = 1u, BN254_FLAG_RLC = 2u };
 
 typedef struct bn254_g16_pvk bn254_g16_pvk;
@@ -107,6 +107,11 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
 int bn254_groth16_verify_batch_multi(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride,
                                      const uint8_t* public_inputs, size_t n_public, size_t n, uint8_t* status,
                                      uint64_t device_mask, unsigned flags);
+/* The shard plan bn254_groth16_verify_batch_multi follows (host arithmetic, no GPU): devices[k] = the k-th set bit of device_mask, its shard
+ * the contiguous range [first[k], first[k] + count[k]) of the batch -- balanced, the first n % w shards one proof longer, the partition of
+ * SURVEY.md section 8(e) (2^20 proofs over 8 GPUs = 131 072 each).  device_count = number of devices the caller has (a set bit at or
+ * above it is BN254_E_BAD_ARG). */
+int bn254_shard_plan(size_t n, uint64_t device_mask, int device_count, int devices[64], size_t first[64], size_t count[64], int* n_shards);
 
 /* Same, with proofs / public_inputs / status already resident in the memory of `device` (the bench path: inputs in
  * HBM when the timed region starts).  hip_stream is a hipStream_t (NULL = default stream); the call only enqueues
@@ -182,6 +187,11 @@ void bn254_set_profiling(int enabled);
 void bn254_set_profile_kernels(unsigned mask);
 int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]);
 int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallback_share, unsigned* bypassed_calls);   /* BN254_FLAG_RLC, adaptive use */
+/* Knobs of BN254_FLAG_RLC (process-wide, atomics; a negative argument leaves that knob alone): the batch size from which the flag is honoured
+ * (default 200 000, never below 64), the adaptive bypass on / off, and the lanes a launch part must keep for its proofs to share Miller-loop
+ * accumulators (default 65536).  The environment variables BN254_RLC_MIN_BATCH / BN254_RLC_ADAPTIVE / BN254_RLC_SHARE_MIN_LANES give the
+ * initial values and are read once, when the library is loaded. */
+void bn254_set_rlc_params(long min_batch, int adaptive, long share_min_lanes);
 const char* bn254_groth16_kernel_name(int i);                 /* phase names */
 int bn254_groth16_num_kernel_kinds(void);
 const char* bn254_groth16_kernel_kind_name(int i);
@@ -197,6 +207,10 @@ int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned 
 size_t bn254_synth_groth16_vk_len(size_t n_public);
 int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_every, int agree, int threads,
                         uint8_t* vk_out, uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected_status_out);
+/* proofs [first, first + n) of the same stream (proof i depends on (seed, i) only), written to positions 0 .. n-1: a rank of a sharded job
+ * generates just its own contiguous shard; the key is the same for every range */
+int bn254_synth_groth16_range(uint64_t seed, size_t n_public, size_t first, size_t n, int invalid_every, int agree, int threads,
+                              uint8_t* vk_out, uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected_status_out);
 
 /* ---- probes of the device arithmetic, used by the GPU parity tests (tests/test_gpu_*.py) ---------------------------
  * Each runs one lane per item on `device` and copies the result back.  Fp12 layout: 12 x 32 bytes in tower order

@@ -32,11 +32,33 @@ def build(verbose=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process, whatever the import order.  The library needs `libamdhip64.so.7` (soname); a PyTorch-ROCm wheel bundles
+    its own copy of that runtime and asks for it as `libamdhip64.so` (no version), so the dynamic loader only recognises the two requests as
+    the same object when torch's copy is mapped FIRST.  Mapped the other way round the process ends up with two runtimes and the second one
+    sees no devices (the library then answers BN254_E_NO_DEVICE).  So when a torch with a bundled runtime is installed and not yet imported,
+    its copy is mapped here, before the library -- without importing torch.  A host without torch (the C++ / Rust case) is not affected."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(lib_path()):
             raise Bn254Error("libbn254_verify_amd.so is not built (run __graft_entry__.build()); there is no fallback path")
+        _share_torch_hip_runtime()
         L = C.CDLL(lib_path())
         L.bn254_last_error.restype = C.c_char_p
         L.bn254_version.restype = C.c_char_p
@@ -58,6 +80,8 @@ def lib():
         L.bn254_groth16_last_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.bn254_synth_groth16.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.bn254_synth_groth16_vk_len.argtypes = [C.c_size_t]
+        L.bn254_synth_groth16_range.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bn254_shard_plan.argtypes = [C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.bn254_plonk_vk_prepare.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.bn254_plonk_vk_free.argtypes = [C.c_void_p]
         L.bn254_plonk_vk_num_public.argtypes = [C.c_void_p]
@@ -67,6 +91,8 @@ def lib():
         L.bn254_groth16_kernel_kind_name.restype = C.c_char_p
         L.bn254_groth16_kernel_kind_name.argtypes = [C.c_int]
         L.bn254_set_profile_kernels.argtypes = [C.c_uint]
+        L.bn254_set_rlc_params.argtypes = [C.c_long, C.c_int, C.c_long]
+        L.bn254_set_rlc_params.restype = None
         L.bn254_groth16_kernel_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
@@ -81,6 +107,12 @@ def set_profile_kernels(names=None):
     kinds = kernel_kinds()
     mask = 0xffffffff if names is None else sum(1 << kinds.index(x) for x in names)
     lib().bn254_set_profile_kernels(mask)
+
+
+def set_rlc_params(min_batch=-1, adaptive=-1, share_min_lanes=-1):
+    """Knobs of FLAG_RLC (bn254_set_rlc_params; -1 leaves a knob alone): batch size from which the flag is honoured, adaptive bypass, lanes a
+    launch part must keep for shared Miller-loop accumulators."""
+    lib().bn254_set_rlc_params(min_batch, adaptive, share_min_lanes)
 
 
 def _check(rc):
@@ -246,13 +278,21 @@ def proof_write_raw(a, b, c):
     return bytes(out)
 
 
-def synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=0, l_identity=False):
-    """Deterministic synthetic gnark-format workload: (vk, proofs, inputs, expected_status) as bytes."""
+def shard_plan(n, device_mask, device_count):
+    """[(device, first, count)] of bn254_groth16_verify_batch_multi's shards (bn254_shard_plan: host arithmetic, no GPU)."""
+    devs = (C.c_int * 64)(); first = (C.c_size_t * 64)(); cnt = (C.c_size_t * 64)(); k = C.c_int(0)
+    _check(lib().bn254_shard_plan(n, device_mask, device_count, devs, first, cnt, C.byref(k)))
+    return [(devs[i], first[i], cnt[i]) for i in range(k.value)]
+
+
+def synth_groth16(seed, n_public, n, invalid_every=16, agree=True, threads=0, l_identity=False, first=0):
+    """Deterministic synthetic gnark-format workload: (vk, proofs, inputs, expected_status) as bytes.  first: global index of the first
+    proof (proof i of the stream depends on (seed, i) only, so a rank can generate its own shard)."""
     L = lib()
     vk = (C.c_uint8 * L.bn254_synth_groth16_vk_len(n_public))()
     proofs = (C.c_uint8 * max(256 * n, 1))()
     inputs = (C.c_uint8 * max(32 * n_public * n, 1))()
     exp = (C.c_uint8 * max(n, 1))()
     # l_identity: every proof with index = 3 mod 7 gets public inputs that make its public-input point L the identity (a valid proof)
-    _check(L.bn254_synth_groth16(seed, n_public, n, invalid_every, (1 if agree else 0) | (2 if l_identity else 0), threads, vk, proofs, inputs, exp))
+    _check(L.bn254_synth_groth16_range(seed, n_public, first, n, invalid_every, (1 if agree else 0) | (2 if l_identity else 0), threads, vk, proofs, inputs, exp))
     return bytes(vk), bytes(proofs)[:256 * n], bytes(inputs)[:32 * n_public * n], bytes(exp)[:n]

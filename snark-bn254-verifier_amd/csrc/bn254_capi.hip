@@ -20,6 +20,7 @@
 #include <memory>
 #include <chrono>
 #include <cstdio>
+#include <stdexcept>
 
 static_assert(BN254_REJECT == BN254_ST_REJECT && BN254_ACCEPT == BN254_ST_ACCEPT && BN254_ERR_NOT_MEMBER == BN254_ST_NOT_MEMBER &&
               BN254_ERR_NOT_ON_CURVE == BN254_ST_NOT_ON_CURVE && BN254_ERR_NOT_IN_SUBGROUP == BN254_ST_NOT_IN_SUBGROUP &&
@@ -31,11 +32,17 @@ static thread_local std::string g_err;
 static std::atomic<int> g_profiling{0};
 static std::atomic<unsigned> g_prof_mask{0xffffffffu};
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+// Knobs of the RLC batch mode.  Initial values come from the environment, read ONCE when the library is loaded (getenv racing a host's
+// setenv is undefined behaviour); afterwards only bn254_set_rlc_params changes them.
+static long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+#define RLC_MIN_BATCH 64            // below this the mode has no groups to speak of
+#define RLC_PAYS_FROM 200000        // the mode is a longer pipeline (~18 ms whatever the size): measured 0.12 x at 4096, 0.45 x at 16384, 0.94 x at 2^17, 2.0 x at 2^20
+static std::atomic<long> g_rlc_min_batch{[] { long v = env_long("BN254_RLC_MIN_BATCH", RLC_PAYS_FROM); return v < RLC_MIN_BATCH ? (long)RLC_MIN_BATCH : v; }()};
+static std::atomic<int> g_rlc_adaptive{env_long("BN254_RLC_ADAPTIVE", 1) != 0 ? 1 : 0};
+static std::atomic<long> g_rlc_share_min_lanes{env_long("BN254_RLC_SHARE_MIN_LANES", 65536)};
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(BN254_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 // BN254_FLAG_RLC: per (key, device) buffers of the random-linear-combination batch mode (bn254_rlc.h)
-#define RLC_MIN_BATCH 64            // below this the mode has no groups to speak of
-#define RLC_PAYS_FROM 200000        // the mode is a longer pipeline (~18 ms whatever the size): measured 0.12 x at 4096, 0.45 x at 16384, 0.94 x at 2^17, 2.0 x at 2^20
 struct RlcDev {
   bool ready = false;
   int32_t *btab = nullptr, *tab = nullptr, *one = nullptr;            // key-side tables (uploaded once)
@@ -68,7 +75,8 @@ struct DevState {
   int32_t* msm_part = nullptr; size_t msm_part_cap = 0, msm_chunks = 0;             // wide keys: partial sums of the public-input MSM (proofs it holds)
   uint8_t *st_proofs = nullptr, *st_inputs = nullptr, *st_status = nullptr;  // staging for the host-buffer entry point
   size_t st_proofs_cap = 0, st_inputs_cap = 0, st_status_cap = 0;
-  hipStream_t host_stream = nullptr, copy_stream = nullptr; std::vector<hipEvent_t> copy_ev;   // host-buffer entry: chunked copy/compute overlap
+  hipStream_t host_stream = nullptr, copy_stream = nullptr;   // host-buffer entry: copy / compute overlap
+  uint8_t* pin[3] = {nullptr, nullptr, nullptr}; size_t pin_cap = 0; hipEvent_t pin_ev[3] = {nullptr, nullptr, nullptr};   // ring of pinned pieces (HOST_RING)
   hipEvent_t busy_ev = nullptr; bool busy_valid = false;
   hipEvent_t ev[5]; bool ev_ready = false; bool ev_recorded = false;
   hipStream_t aux[4]; hipEvent_t fork_ev, join_ev[4]; bool aux_ready = false;  // concurrent sub-batches (see g16_enqueue)
@@ -120,6 +128,21 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
     HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_BYTES_PER_PROOF));
     d.ws_cap = cap;
   }
+  // keys with many public inputs: partial sums (and comb digits) of the public-input MSM, for the proofs of one launch.  Sized HERE (reserve /
+  // the entry points call ensure_dev before they enqueue), so that the enqueue path itself never allocates or frees
+  if (pvk->host.n_k - 1 > (size_t)G16_WIDE_MSM_MIN_INPUTS) {
+    const size_t n_public = pvk->host.n_k - 1;
+    const size_t need = n < (size_t)G16_WIDE_MSM_MAX_PROOFS ? (n + 255) / 256 * 256 : (size_t)G16_WIDE_MSM_MAX_PROOFS;
+    if (need > d.msm_part_cap) {
+      if (d.msm_part) HIPCK(hipFree(d.msm_part));
+      d.msm_part = nullptr; d.msm_part_cap = 0;
+      const size_t chunks = (n_public + G16_WIDE_MSM_INPUTS_PER_LANE - 1) / G16_WIDE_MSM_INPUTS_PER_LANE;
+      // comb tables: + the column digits of every scalar (G16_COMB_COLS x u16 per input, transposed so that the lanes of a wavefront read neighbours)
+      const size_t digits = pvk->host.msm_comb ? (size_t)G16_COMB_COLS * n_public * need * sizeof(uint16_t) : 0;
+      HIPCK(hipMalloc((void**)&d.msm_part, chunks * 27 * need * sizeof(int32_t) + digits));
+      d.msm_part_cap = need; d.msm_chunks = chunks;
+    }
+  }
   if (g_profiling.load() && !d.ev_ready) {
     for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i]));
     const int cap = 1024;  // launches per sub-batch: ~720
@@ -147,7 +170,7 @@ static void dev_free(DevState& d) {
   if (d.busy_ev) (void)hipEventDestroy(d.busy_ev);
   if (d.host_stream) (void)hipStreamDestroy(d.host_stream);
   if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
-  for (auto& e : d.copy_ev) (void)hipEventDestroy(e);
+  for (int i = 0; i < 3; i++) { if (d.pin[i]) (void)hipHostFree(d.pin[i]); if (d.pin_ev[i]) (void)hipEventDestroy(d.pin_ev[i]); }
   rlc_dev_free(d.rlc);
 }
 static int grow(uint8_t** p, size_t* cap, size_t need) {
@@ -224,25 +247,40 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   }
   size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
   if (need <= c.cap) return BN254_OK;
-  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status};
-  for (auto q : ptrs) if (q) (void)hipFree(q);
-  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words};
-  for (auto q : hp) if (q) (void)hipHostFree(q);
-  c.cap = 0; c.glv_tab = nullptr;
-  const size_t tmax = (size_t)plonk_stage2_terms(pvk->key) + 2 > (size_t)plonk_stage1_terms(pvk->key) ? plonk_stage2_terms(pvk->key) + 2 : plonk_stage1_terms(pvk->key);
-  HIPCK(hipMalloc((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF));
-  HIPCK(hipMalloc((void**)&c.part, need * tmax * 2 * 27 * sizeof(int32_t)));     // x 2: the split scalar-multiplication launch writes two partial results per term
-  HIPCK(hipMalloc((void**)&c.glv_tab, (size_t)65536 * G1_GLV_TAB_BYTES_PER_LANE));   // 117 MB: the launches that use it have at most 65536 lanes
-  HIPCK(hipMalloc((void**)&c.terms, need * tmax * sizeof(MsmTerm)));
-  HIPCK(hipMalloc((void**)&c.flags, need * tmax));
-  HIPCK(hipMalloc((void**)&c.words, need * 16 * sizeof(uint32_t)));
-  HIPCK(hipMalloc((void**)&c.inf, need));
-  HIPCK(hipMalloc((void**)&c.status, need));
-  HIPCK(hipHostMalloc((void**)&c.h_terms, need * tmax * sizeof(MsmTerm), hipHostMallocDefault));
-  HIPCK(hipHostMalloc((void**)&c.h_flags, need * tmax, hipHostMallocDefault));
-  HIPCK(hipHostMalloc((void**)&c.h_status, need, hipHostMallocDefault));
-  HIPCK(hipHostMalloc((void**)&c.h_inf, need, hipHostMallocDefault));
-  HIPCK(hipHostMalloc((void**)&c.h_words, need * 16 * sizeof(uint32_t), hipHostMallocDefault));
+  // drop the old buffers and forget them BEFORE anything is allocated: if an allocation below fails the context is left empty (cap = 0, every
+  // pointer null), never with a stale pointer that a later call or plonk_ctx_free would free a second time
+  auto drop = [&c] {
+    void** dp[] = {(void**)&c.ws, (void**)&c.part, (void**)&c.glv_tab, (void**)&c.terms, (void**)&c.flags, (void**)&c.words, (void**)&c.inf, (void**)&c.status};
+    for (auto q : dp) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    void** hp[] = {(void**)&c.h_terms, (void**)&c.h_flags, (void**)&c.h_status, (void**)&c.h_inf, (void**)&c.h_words};
+    for (auto q : hp) { if (*q) (void)hipHostFree(*q); *q = nullptr; }
+    c.cap = 0;
+  };
+  drop();
+  const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
+  const size_t tmax = (size_t)(TT > T1 ? TT : T1);
+  // scratch of the two-bit-window scalar multiplications: only launches of at most 65536 lanes use it (bn254_g1_msm_tab_lanes)
+  size_t tab_lanes = bn254_g1_msm_tab_lanes(need, T1);
+  if (bn254_g1_msm_tab_lanes(need, TT) > tab_lanes) tab_lanes = bn254_g1_msm_tab_lanes(need, TT);
+  // smaller batches on the same context may use it where `need` proofs do not: a context of this capacity sees every batch size up to `need`
+  if (tab_lanes == 0 && bn254_g1_msm_tab_lanes(1, T1) != 0) tab_lanes = 65536;
+  hipError_t e = hipSuccess;
+  auto dm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes ? bytes : 1); };
+  auto hm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipHostMalloc(q, bytes ? bytes : 1, hipHostMallocDefault); };
+  dm((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF);
+  dm((void**)&c.part, need * tmax * 2 * 27 * sizeof(int32_t));     // x 2: the split scalar-multiplication launch writes two partial results per term
+  if (tab_lanes) dm((void**)&c.glv_tab, tab_lanes * (size_t)G1_GLV_TAB_BYTES_PER_LANE);   // at most 65536 lanes = 117 MB
+  dm((void**)&c.terms, need * tmax * sizeof(MsmTerm));
+  dm((void**)&c.flags, need * tmax);
+  dm((void**)&c.words, need * 16 * sizeof(uint32_t));
+  dm((void**)&c.inf, need);
+  dm((void**)&c.status, need);
+  hm((void**)&c.h_terms, need * tmax * sizeof(MsmTerm));
+  hm((void**)&c.h_flags, need * tmax);
+  hm((void**)&c.h_status, need);
+  hm((void**)&c.h_inf, need);
+  hm((void**)&c.h_words, need * 16 * sizeof(uint32_t));
+  if (e != hipSuccess) { drop(); return set_err(BN254_E_HIP, std::string("PlonK context allocation: ") + hipGetErrorString(e)); }
   c.cap = need;
   return BN254_OK;
 }
@@ -257,17 +295,29 @@ class HostPool {
   }
   void run(unsigned n, const std::function<void(unsigned)>& fn) {
     if (n <= 1) { fn(0); return; }
-    struct Job { std::mutex m; std::condition_variable c; unsigned left; } job;
+    struct Job { std::mutex m; std::condition_variable c; unsigned left; bool failed = false; } job;
     job.left = n - 1;
     {
       std::lock_guard<std::mutex> lk(mu_);
       for (unsigned t = 1; t < n; t++)
-        q_.emplace_back([&job, &fn, t] { fn(t); std::lock_guard<std::mutex> l(job.m); if (--job.left == 0) job.c.notify_one(); });
+        q_.emplace_back([&job, &fn, t] {
+          try { fn(t); } catch (...) { std::lock_guard<std::mutex> l(job.m); job.failed = true; }   // a pool thread must not die with the job still counted
+          std::lock_guard<std::mutex> l(job.m);
+          if (--job.left == 0) job.c.notify_one();
+        });
     }
     cv_.notify_all();
+    // the queued lambdas reference `job` and `fn` on this frame: whatever fn(0) does -- including throwing -- the frame must outlive them
+    struct Wait {
+      Job& j;
+      ~Wait() { std::unique_lock<std::mutex> lk(j.m); j.c.wait(lk, [this] { return j.left == 0; }); }
+    } wait{job};
     fn(0);
-    std::unique_lock<std::mutex> lk(job.m);
-    job.c.wait(lk, [&] { return job.left == 0; });
+    {
+      std::unique_lock<std::mutex> lk(job.m);
+      job.c.wait(lk, [&] { return job.left == 0; });
+      if (job.failed) throw std::runtime_error("a host-pool slice failed");
+    }
   }
   ~HostPool() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -406,16 +456,9 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
     const bool wide = n_public + 1 == pvk->host.n_k && n_public > (size_t)G16_WIDE_MSM_MIN_INPUTS;
     const size_t max_launch = wide ? (size_t)G16_WIDE_MSM_MAX_PROOFS : (size_t)G16_MAX_LAUNCH;
     if (wide) {
-      size_t need = m < max_launch ? (m + 255) / 256 * 256 : max_launch;
-      if (need > d->msm_part_cap) {
-        if (d->msm_part) HIPCK(hipFree(d->msm_part));
-        d->msm_part = nullptr; d->msm_part_cap = 0;
-        size_t chunks = (n_public + G16_WIDE_MSM_INPUTS_PER_LANE - 1) / G16_WIDE_MSM_INPUTS_PER_LANE;
-        // comb tables: + the column digits of every scalar (22 x u16 per input, transposed so that the lanes of a wavefront read neighbours)
-        const size_t digits = pvk->host.msm_comb ? (size_t)G16_COMB_COLS * n_public * need * sizeof(uint16_t) : 0;
-        HIPCK(hipMalloc((void**)&d->msm_part, chunks * 27 * need * sizeof(int32_t) + digits));
-        d->msm_part_cap = need; d->msm_chunks = chunks;
-      }
+      // the partial-sum buffer was sized by ensure_dev (bn254_groth16_reserve or the entry point itself): this path only enqueues
+      const size_t need = m < max_launch ? (m + 255) / 256 * 256 : max_launch;
+      if (need > d->msm_part_cap) return set_err(BN254_E_BAD_ARG, "workspace of a key with many public inputs is smaller than the batch: bn254_groth16_reserve first");
     }
     int parts = (!wide && n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
     if (m <= bn254_coop_max_proofs()) parts = 1;              // one launch: the cooperative kernels take batches of this size whole
@@ -526,8 +569,8 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
       ra.counter_base = (uint32_t)(off + lo);
       // sharing needs enough lanes to fill the GPU; small parts keep one proof per lane
       int log2_share = log2_share_env < log2_group ? log2_share_env : log2_group;
-      const char* ml = getenv("BN254_RLC_SHARE_MIN_LANES");
-      const size_t min_lanes = ml ? (size_t)atol(ml) : 65536;
+      const long ml = g_rlc_share_min_lanes.load();
+      const size_t min_lanes = ml < 1 ? 1 : (size_t)ml;
       while (log2_share > 0 && (a.n >> log2_share) < min_lanes) log2_share--;
       ra.plan = rlc_plan((uint32_t)a.n, log2_group, log2_share);
       ra.grp_status = r.grp_status + grp_off; grp_off += ((size_t)ra.plan.groups + 255) / 256 * 256;
@@ -581,24 +624,26 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
 #define RLC_BYPASS_SHARE 0.45f
 #define RLC_PROBE_EVERY 8
 static bool rlc_bypass(RlcDev& r) {
-  const char* e = getenv("BN254_RLC_ADAPTIVE");      // read per call (as BN254_RLC_SHARE_MIN_LANES): tests switch it
-  const bool adaptive = !e || atoi(e) != 0;
+  const bool adaptive = g_rlc_adaptive.load() != 0;   // bn254_set_rlc_params
   if (!adaptive || !r.have_obs || r.fb_share <= RLC_BYPASS_SHARE) { r.bypassed = 0; return false; }
   if (r.bypassed + 1 >= RLC_PROBE_EVERY) { r.bypassed = 0; return false; }
   r.bypassed++; r.bypassed_total++;
   return true;
 }
-// one batch on `user`: waits for the previous batch of this (key, device), runs the exact or the RLC pipeline, records busy_ev
+// does a batch of this shape qualify for the RLC mode at all (the adaptive bypass, rlc_bypass, is decided separately, once per call)
+static bool rlc_eligible(const bn254_g16_pvk* pvk, size_t n_public, size_t n, unsigned flags) {
+  return (flags & BN254_FLAG_RLC) && n_public + 1 == pvk->host.n_k && n_public <= (size_t)RLC_MAX_PUBLIC && n >= (size_t)g_rlc_min_batch.load();
+}
+// one batch on `user`: waits for the previous batch of this (key, device), runs the exact or the RLC pipeline, records busy_ev.
+// use_rlc: -1 = decide here; 0 / 1 = the caller (the host-buffer entry, which must know before it cuts the batch into chunks) has decided
 static int g16_enqueue(const bn254_g16_pvk* pvk, DevState* d, int device, const void* d_proofs, size_t proof_stride, const void* d_inputs,
-                       size_t n_public, size_t n, void* d_status, hipStream_t user, unsigned flags) {
+                       size_t n_public, size_t n, void* d_status, hipStream_t user, unsigned flags, int use_rlc = -1) {
   if (d->busy_valid) HIPCK(hipStreamWaitEvent(user, d->busy_ev, 0));
   int rc;
-  // BN254_FLAG_RLC is honoured where it pays: from RLC_PAYS_FROM proofs (BN254_RLC_MIN_BATCH in the environment overrides, read per call: the
-  // tests run the mode on small batches); smaller batches take the exact path -- same status bytes
-  size_t rlc_from = RLC_PAYS_FROM;
-  if (const char* e = getenv("BN254_RLC_MIN_BATCH")) { long v = atol(e); rlc_from = v < RLC_MIN_BATCH ? (size_t)RLC_MIN_BATCH : (size_t)v; }
-  const bool rlc = (flags & BN254_FLAG_RLC) && n_public + 1 == pvk->host.n_k && n_public <= (size_t)RLC_MAX_PUBLIC && n >= rlc_from;
-  if (rlc && !rlc_bypass(d->rlc)) rc = g16_enqueue_rlc(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
+  // BN254_FLAG_RLC is honoured where it pays: from RLC_PAYS_FROM proofs (bn254_set_rlc_params / BN254_RLC_MIN_BATCH at load time move the
+  // threshold: the tests run the mode on small batches); smaller batches take the exact path -- same status bytes
+  const bool rlc = use_rlc >= 0 ? use_rlc != 0 : (rlc_eligible(pvk, n_public, n, flags) && !rlc_bypass(d->rlc));
+  if (rlc) rc = g16_enqueue_rlc(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
   else rc = g16_enqueue_exact(pvk, d, d_proofs, proof_stride, d_inputs, n_public, n, d_status, user, flags);
   if (rc) return rc;
   HIPCK(hipEventRecord(d->busy_ev, user));
@@ -617,6 +662,12 @@ int bn254_groth16_verify_batch_device(const bn254_g16_pvk* pvk, const void* d_pr
   int rc = ensure_dev(pvk, *d, device, n);
   if (rc) return rc;
   return g16_enqueue(pvk, d, device, d_proofs, proof_stride, d_inputs, n_public, n, d_status, (hipStream_t)hip_stream, flags);
+}
+
+void bn254_set_rlc_params(long min_batch, int adaptive, long share_min_lanes) {
+  if (min_batch >= 0) g_rlc_min_batch.store(min_batch < RLC_MIN_BATCH ? (long)RLC_MIN_BATCH : min_batch);
+  if (adaptive >= 0) g_rlc_adaptive.store(adaptive ? 1 : 0);
+  if (share_min_lanes >= 0) g_rlc_share_min_lanes.store(share_min_lanes < 1 ? 1 : share_min_lanes);
 }
 
 int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallback_share, unsigned* bypassed_calls) {
@@ -657,9 +708,36 @@ int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned 
   return BN254_OK;
 }
 
-// Host buffers: the batch is cut into chunks; the copy of chunk k + 1 (on the copy stream) overlaps the kernels of chunk k (on the
-// compute stream), only stream-scoped synchronisation, one status copy at the end.  The device lock is held for the whole call:
-// the staging buffers belong to this batch until its statuses are back.
+// Host buffers.  The caller's memory is pageable, and a hipMemcpyAsync from pageable memory is neither asynchronous nor fast (the runtime stages
+// it through its own bounce buffer while the calling thread waits).  So the library keeps a ring of three PINNED pieces per (key, device): host
+// threads copy piece i + 1 of the caller's buffers into the ring while piece i travels to the device (a true asynchronous copy on the copy
+// stream) and the previous compute chunk runs; a compute chunk (2^17 proofs first, so that the exposed copy is short, then 2^18) waits on the
+// GPU for the event of its last piece.  Only stream-scoped synchronisation, one status copy at the end.  The device lock is held for the whole
+// call: the staging buffers belong to this batch until its statuses are back.
+#define HOST_RING 3
+static int host_ring_ensure(DevState& d, size_t piece_bytes) {
+  if (piece_bytes <= d.pin_cap) return BN254_OK;
+  for (int i = 0; i < HOST_RING; i++) {
+    if (d.pin[i]) HIPCK(hipHostFree(d.pin[i]));
+    d.pin[i] = nullptr;
+  }
+  d.pin_cap = 0;
+  for (int i = 0; i < HOST_RING; i++) {
+    HIPCK(hipHostMalloc((void**)&d.pin[i], piece_bytes, hipHostMallocDefault));
+    if (!d.pin_ev[i]) HIPCK(hipEventCreateWithFlags(&d.pin_ev[i], hipEventDisableTiming));
+  }
+  d.pin_cap = piece_bytes;
+  return BN254_OK;
+}
+static void parallel_copy(uint8_t* dst, const uint8_t* src, size_t bytes) {
+  static const unsigned hw = [] { unsigned v = std::thread::hardware_concurrency(); const char* e = getenv("BN254_HOST_COPY_THREADS"); if (e) v = (unsigned)atoi(e); return v < 1 ? 1u : (v > 8 ? 8u : v); }();
+  if (bytes < ((size_t)4 << 20) || hw == 1) { memcpy(dst, src, bytes); return; }
+  const size_t per = ((bytes + hw - 1) / hw + 4095) & ~(size_t)4095;
+  HostPool::get().run(hw, [&](unsigned t) {
+    const size_t lo = (size_t)t * per;
+    if (lo < bytes) memcpy(dst + lo, src + lo, bytes - lo < per ? bytes - lo : per);
+  });
+}
 int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                                size_t n_public, size_t n, uint8_t* status, int device, unsigned flags) {
   if (!pvk || (n && (!proofs || !status)) || proof_stride < 256 || (n && n_public && !public_inputs) || (flags & ~3u)) return set_err(BN254_E_BAD_ARG, "bad argument");
@@ -668,46 +746,84 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
   std::lock_guard<std::mutex> lk(d->mu);
   int rc = ensure_dev(pvk, *d, device, n);
   if (rc) return rc;
-  size_t pb = n * proof_stride, ib = n * n_public * 32;
+  const size_t in_row = n_public * 32, row = proof_stride + in_row;
+  size_t pb = n * proof_stride, ib = n * in_row;
   if ((rc = grow(&d->st_proofs, &d->st_proofs_cap, pb)) || (rc = grow(&d->st_inputs, &d->st_inputs_cap, ib ? ib : 32)) ||
       (rc = grow(&d->st_status, &d->st_status_cap, n)))
     return rc;
   if (!d->host_stream) { HIPCK(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking)); }
   static const size_t hchunk = [] { const char* e = getenv("BN254_HOST_CHUNK_LOG2"); int v = e ? atoi(e) : 18; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
-  // the RLC mode forms its groups over the whole batch it is handed: keep it in one piece
-  const size_t step = (flags & BN254_FLAG_RLC) ? n : hchunk;
-  size_t ci = 0;
-  for (size_t off = 0; off < n; off += step, ci++) {
-    const size_t m = n - off < step ? n - off : step;
-    if (ci >= d->copy_ev.size()) { hipEvent_t e; HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->copy_ev.push_back(e); }
-    HIPCK(hipMemcpyAsync(d->st_proofs + off * proof_stride, proofs + off * proof_stride, m * proof_stride, hipMemcpyHostToDevice, d->copy_stream));
-    if (ib) HIPCK(hipMemcpyAsync(d->st_inputs + off * n_public * 32, public_inputs + off * n_public * 32, m * n_public * 32, hipMemcpyHostToDevice, d->copy_stream));
-    HIPCK(hipEventRecord(d->copy_ev[ci], d->copy_stream));
-    HIPCK(hipStreamWaitEvent(d->host_stream, d->copy_ev[ci], 0));
-    rc = g16_enqueue(pvk, d, device, d->st_proofs + off * proof_stride, proof_stride, d->st_inputs + off * n_public * 32, n_public, m, d->st_status + off, d->host_stream, flags);
+  // copy pieces: about 20 MB of the caller's bytes each (65536 proofs at 2 public inputs), a multiple of 256 proofs
+  static const size_t piece_bytes_target = [] { const char* e = getenv("BN254_HOST_PIECE_MB"); long v = e ? atol(e) : 20; return (size_t)(v < 1 ? 1 : v) << 20; }();
+  size_t piece = piece_bytes_target / row / 256 * 256;
+  if (piece < 256) piece = 256;
+  if (piece > n) piece = (n + 255) / 256 * 256;
+  if ((rc = host_ring_ensure(*d, piece * row))) return rc;
+  // the RLC mode forms its groups over the whole batch it is handed: keep it in one piece -- but only when this call really runs the mode
+  // (same predicate as g16_enqueue, the adaptive bypass included, decided ONCE here); a flag that will be ignored keeps the chunked
+  // copy / compute overlap
+  const int use_rlc = (rlc_eligible(pvk, n_public, n, flags) && !rlc_bypass(d->rlc)) ? 1 : 0;
+  size_t copied = 0, computed = 0, slot_uses = 0;
+  // the first chunk is short (its copy is the only exposed one) unless the batch is small anyway
+  size_t c_end = use_rlc ? n : (n > hchunk ? (hchunk / 2 < n ? hchunk / 2 : n) : n);
+  while (computed < n) {
+    hipEvent_t last = nullptr;
+    while (copied < c_end) {
+      const size_t m = c_end - copied < piece ? c_end - copied : piece;
+      const int slot = (int)(slot_uses % HOST_RING);
+      if (slot_uses >= HOST_RING) HIPCK(hipEventSynchronize(d->pin_ev[slot]));     // the piece that used this slot has left for the device
+      parallel_copy(d->pin[slot], proofs + copied * proof_stride, m * proof_stride);
+      if (in_row) parallel_copy(d->pin[slot] + m * proof_stride, public_inputs + copied * in_row, m * in_row);
+      HIPCK(hipMemcpyAsync(d->st_proofs + copied * proof_stride, d->pin[slot], m * proof_stride, hipMemcpyHostToDevice, d->copy_stream));
+      if (in_row) HIPCK(hipMemcpyAsync(d->st_inputs + copied * in_row, d->pin[slot] + m * proof_stride, m * in_row, hipMemcpyHostToDevice, d->copy_stream));
+      HIPCK(hipEventRecord(d->pin_ev[slot], d->copy_stream));
+      last = d->pin_ev[slot];
+      slot_uses++; copied += m;
+    }
+    if (last) HIPCK(hipStreamWaitEvent(d->host_stream, last, 0));
+    rc = g16_enqueue(pvk, d, device, d->st_proofs + computed * proof_stride, proof_stride, d->st_inputs + computed * in_row, n_public, c_end - computed,
+                     d->st_status + computed, d->host_stream, flags, use_rlc);
     if (rc) return rc;
+    computed = c_end;
+    c_end = n - c_end < hchunk ? n : c_end + hchunk;
   }
   HIPCK(hipMemcpyAsync(status, d->st_status, n, hipMemcpyDeviceToHost, d->host_stream));
   HIPCK(hipStreamSynchronize(d->host_stream));
   return BN254_OK;
 }
 
+// The shard plan of a multi-device batch: the devices selected by device_mask in ascending order, shard k = the
+// contiguous range [first[k], first[k] + count[k]) of the batch on devices[k]; balanced, the first n % w shards one proof longer (the same
+// rule as sharding.shard_bounds of the multi-process job).  Host arithmetic only: needs no GPU, device_count is the caller's.
+int bn254_shard_plan(size_t n, uint64_t device_mask, int device_count, int devices[64], size_t first[64], size_t count[64], int* n_shards) {
+  if (!device_mask || !devices || !first || !count || !n_shards) return set_err(BN254_E_BAD_ARG, "bad argument");
+  int w = 0;
+  for (int b = 0; b < 64; b++)
+    if ((device_mask >> b) & 1) {
+      if (b >= device_count) return set_err(BN254_E_BAD_ARG, "device_mask selects a device that does not exist");
+      devices[w++] = b;
+    }
+  const size_t base = n / (size_t)w, rem = n % (size_t)w;
+  for (int r = 0; r < w; r++) { first[r] = (size_t)r * base + ((size_t)r < rem ? (size_t)r : rem); count[r] = base + ((size_t)r < rem ? 1 : 0); }
+  *n_shards = w;
+  return BN254_OK;
+}
+
 int bn254_groth16_verify_batch_multi(const bn254_g16_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                                      size_t n_public, size_t n, uint8_t* status, uint64_t device_mask, unsigned flags) {
   if (!pvk || !device_mask) return set_err(BN254_E_BAD_ARG, "bad argument");
-  std::vector<int> devs;
-  for (int b = 0; b < 64; b++) if ((device_mask >> b) & 1) devs.push_back(b);
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return set_err(BN254_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-  for (int dv : devs) if (dv >= cnt) return set_err(BN254_E_BAD_ARG, "device_mask selects a device that does not exist");
-  const size_t w = devs.size();
+  int devs[64], nsh = 0; size_t los[64], cnts[64];
+  int prc = bn254_shard_plan(n, device_mask, cnt, devs, los, cnts, &nsh);
+  if (prc) return prc;
+  const size_t w = (size_t)nsh;
   if (w == 1) return bn254_groth16_verify_batch(pvk, proofs, proof_stride, public_inputs, n_public, n, status, devs[0], flags);
-  // contiguous balanced shards (the first n % w devices get one more proof), one host thread per device
+  // one host thread per device drives its shard
   std::vector<int> rcs(w, BN254_OK); std::vector<std::string> errs(w);
   std::vector<std::thread> th;
-  const size_t base = n / w, rem = n % w;
   for (size_t r = 0; r < w; r++) {
-    const size_t lo = r * base + (r < rem ? r : rem), cntp = base + (r < rem ? 1 : 0);
+    const size_t lo = los[r], cntp = cnts[r];
     th.emplace_back([&, r, lo, cntp]() {
       if (!cntp) return;
       rcs[r] = bn254_groth16_verify_batch(pvk, proofs + lo * proof_stride, proof_stride, public_inputs ? public_inputs + lo * n_public * 32 : nullptr, n_public, cntp,
@@ -1139,6 +1255,12 @@ size_t bn254_synth_groth16_vk_len(size_t n_public) { return 292 + 32 * (n_public
 
 int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_every, int agree, int threads, uint8_t* vk_out,
                         uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected) {
+  return bn254_synth_groth16_range(seed, n_public, 0, n, invalid_every, agree, threads, vk_out, proofs_out, inputs_out, expected);
+}
+// proofs [first, first + n) of the stream bn254_synth_groth16 generates for `seed` (proof i is a function of (seed, i) alone), written to
+// positions 0 .. n-1 of the output buffers: a rank of a sharded job generates its own contiguous shard only
+int bn254_synth_groth16_range(uint64_t seed, size_t n_public, size_t first, size_t n, int invalid_every, int agree, int threads, uint8_t* vk_out,
+                              uint8_t* proofs_out, uint8_t* inputs_out, uint8_t* expected) {
   if (!vk_out || (n && (!proofs_out || !expected)) || (n && n_public && !inputs_out)) return set_err(BN254_E_BAD_ARG, "bad argument");
   static GenTables* tabs = nullptr;
   static std::mutex tmu;
@@ -1190,7 +1312,8 @@ int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_ev
   if ((size_t)threads > n) threads = (int)n;
   G1Aff g1gen; g1gen.x = fp_one(); g1gen.y = fp_add(fp_one(), fp_one());
   auto worker = [&](int tid) {
-    for (size_t i = tid; i < n; i += threads) {
+    for (size_t li = tid; li < n; li += threads) {
+      const size_t i = first + li;   // global index: seeds the proof and selects its class
       SplitMix64 r{seed * 0x9e3779b97f4a7c15ull + 0x1000 + i};
       U256 a = fr_random(r, true), b = fr_random(r, true);
       U256 ell = kk[0];
@@ -1216,17 +1339,17 @@ int bn254_synth_groth16(uint64_t seed, size_t n_public, size_t n, int invalid_ev
       if (cls == 1) { Cp = g1_add_mixed(Cp, g1gen); st = BN254_REJECT; }
       if (cls == 3) { B = bad_b[(i / (size_t)invalid_every) % bad_b.size()]; st = BN254_ERR_NOT_IN_SUBGROUP; }
       G1Aff C = g1_is_identity(Cp) ? g1gen : g1_to_affine(Cp);
-      uint8_t* p = proofs_out + 256 * i;
+      uint8_t* p = proofs_out + 256 * li;
       enc_g1_uncompressed(p, A); enc_g2_uncompressed(p + 64, B); enc_g1_uncompressed(p + 192, C);
-      for (size_t s = 0; s < n_public; s++) u256_to_be(inputs_out + (i * n_public + s) * 32, xs[s]);
+      for (size_t s = 0; s < n_public; s++) u256_to_be(inputs_out + (li * n_public + s) * 32, xs[s]);
       if (cls == 0 && n_public > 0) {  // x_0 + 1 (as raw integer; stays below 2^256)
-        U256 one = {{1, 0, 0, 0}}, t; u256_add(t, xs[0], one); u256_to_be(inputs_out + i * n_public * 32, t); st = BN254_REJECT;
+        U256 one = {{1, 0, 0, 0}}, t; u256_add(t, xs[0], one); u256_to_be(inputs_out + li * n_public * 32, t); st = BN254_REJECT;
       }
       if (cls == 2) {  // A.y + 1 mod p: off the curve (y+1 = -y only for y = (p-1)/2)
         Fp y1 = fp_add(A.y, fp_one()); fp_to_be(p + 32, y1); st = BN254_ERR_NOT_ON_CURVE;
       }
       if (cls == 4) { memset(p, 0xff, 32); st = BN254_ERR_NOT_MEMBER; }  // A.x = 2^256 - 1 >= p
-      expected[i] = st;
+      expected[li] = st;
     }
   };
   std::vector<std::thread> th;

@@ -157,7 +157,7 @@ struct G16Prepared {
   std::vector<int32_t> k0;               // 18
   std::vector<int32_t> gtab, dtab;       // BN_ATE_STEPS * FIXED_LINE_DWORDS
   std::vector<int32_t> target;           // 108
-  std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS; keys with many inputs (msm_comb): (n_k - 1) * 4096 * MSM_ENTRY_DWORDS
+  std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS; keys with many inputs (msm_comb): (n_k - 1) * (1 << G16_COMB_TEETH) = 8192 entries of MSM_ENTRY_DWORDS each
   bool msm_comb = false;                 // the table is in comb form (build_comb_table): read by k_g16_msm_partial_comb only
   G1Aff alpha, k0_pt; G2Aff b_arg;       // kept for the RLC tables (prepare_g16_rlc): alpha, K[0] and the G2 argument of the target pairing
 };
@@ -197,13 +197,13 @@ inline void build_window_table(int32_t* out /* 32*255*MSM_ENTRY_DWORDS */, const
     fp_to_limbs(o, aff[e].x); fp_to_limbs(o + BN_NL, aff[e].y); o[18] = 0; o[19] = 0;
   }
 }
-// comb table of one base (keys with many public inputs): G16_COMB_TEETH = 12 teeth G16_COMB_COLS = 22 bit positions apart; entry [idx] =
-// sum over the set bits i of idx of 2^(22 i) * base, idx = 1..4095 (entry 0 unused).  A 256-bit scalar x is then
-//   x * base = sum_{c = 0..21} 2^c * entry[ bits c, c + 22, ..., c + 242 of x ]
-// i.e. 22 additions per input and 22 doublings that ALL inputs of a lane share, against 32 additions with the byte windows -- from a table
-// half the size (4095 entries per input instead of 8160) that takes half as long to build.  No entry is the identity: none of the 4095 sums
-// of powers 2^(22 i) is a multiple of r (checked in tests/test_capi_cpu.py).
-inline void build_comb_table(int32_t* out /* 4096 * MSM_ENTRY_DWORDS */, const G1Aff& base) {
+// comb table of one base (keys with many public inputs): G16_COMB_TEETH = 13 teeth G16_COMB_COLS = 20 bit positions apart (13 x 20 = 260 >= 256
+// bits); entry [idx] = sum over the set bits i of idx of 2^(20 i) * base, idx = 1..8191 (entry 0 unused).  A 256-bit scalar x is then
+//   x * base = sum_{c = 0..19} 2^c * entry[ bits c, c + 20, ..., c + 240 of x ]
+// i.e. 20 additions per input and 20 doublings that ALL inputs of a lane share, against 32 additions with the byte windows -- from a table
+// of the same size (8192 entries per input against 8160).  No entry is the identity: none of the 8191 sums of powers 2^(20 i), i < 13, is a
+// multiple of r (they are below 2^241 < r, and tests/test_capi_cpu.py::test_comb_table_constants_never_vanish checks it from the header's parameters).
+inline void build_comb_table(int32_t* out /* (1 << G16_COMB_TEETH) * MSM_ENTRY_DWORDS */, const G1Aff& base) {
   G1Aff tooth[G16_COMB_TEETH];
   {
     G1Proj t = g1_from_affine(base);

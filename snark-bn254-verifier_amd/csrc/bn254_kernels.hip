@@ -386,10 +386,10 @@ k_g16_msm_partial(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, 
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
 }
-// The same sum from COMB tables (bn254_host.hpp::build_comb_table; keys prepared with msm_comb): the lane walks the 22 columns from the top,
-// doubling its accumulator once per column and adding, for each of its inputs, the entry selected by bits c, c + 22, ..., c + 242 of the
-// scalar: 22 additions per input and 22 doublings per lane instead of 32 additions per input.
-// k_g16_comb_digits first turns every scalar (big-endian bytes: bit b of the integer is bit b % 8 of byte 31 - b / 8) into its 22 column digits,
+// The same sum from COMB tables (bn254_host.hpp::build_comb_table; keys prepared with msm_comb): the lane walks the G16_COMB_COLS = 20 columns
+// from the top, doubling its accumulator once per column and adding, for each of its inputs, the entry selected by bits c, c + 20, ..., c + 240 of
+// the scalar (G16_COMB_TEETH = 13 bits): 20 additions per input and 20 doublings per lane instead of 32 additions per input.
+// k_g16_comb_digits first turns every scalar (big-endian bytes: bit b of the integer is bit b % 8 of byte 31 - b / 8) into its 20 column digits,
 // stored transposed -- digits[(col * n_public + s) * n + i] -- so that the lanes of a wavefront (consecutive proofs) read consecutive u16.
 __global__ void __launch_bounds__(256)
 k_g16_comb_digits(const uint8_t* __restrict__ inputs, int n_public, uint32_t n, uint16_t* __restrict__ digits) {

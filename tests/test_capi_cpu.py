@@ -210,13 +210,14 @@ def test_comb_table_multiplication_vs_oracle(pkg, O):
 
 
 def test_comb_table_constants_never_vanish():
-    """The comb tables of keys with many public inputs (bn254_host.hpp::build_comb_table) hold idx-weighted sums of 2^(22 i) K for every non-empty
-    set of teeth; K has order r, so an entry is the identity only if that sum of powers is a multiple of r: none is.  12 x 22 >= 256 bits."""
+    """The comb tables of keys with many public inputs (bn254_host.hpp::build_comb_table) hold the sums of 2^(cols * i) K over every non-empty
+    set of teeth; K has order r, so an entry is the identity only if that sum of powers is a multiple of r: none is.  The parameters are read
+    from the header (13 teeth x 20 columns >= 256 bits: 8191 sums, all below 2^241 < r)."""
     import re
     hdr = open(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", "bn254_kernels.h")).read()
     teeth = int(re.search(r"#define G16_COMB_TEETH (\d+)", hdr).group(1)); cols = int(re.search(r"#define G16_COMB_COLS (\d+)", hdr).group(1))
     R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-    assert teeth * cols >= 256
+    assert teeth * cols >= 256 and (teeth, cols) == (13, 20)
     assert all(sum(((idx >> i) & 1) << (cols * i) for i in range(teeth)) % R for idx in range(1, 1 << teeth))
 
 

@@ -78,57 +78,115 @@ class _StandIn:
     def status_bytes(self): return bytes(self.status.numpy().tobytes())
 
 
-def _bench_worker(rank, world, port, q):
+def _bench_worker(rank, world, port, q, weak):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
     pkg = importlib.import_module("snark-bn254-verifier_amd")
-    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch-log2", "6"])
-    table = {}
+    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch-log2", "6"] + (["--weak"] if weak else []))
+    table, asked = {}, []
 
-    def synth(seed, n_public, n, threads):
-        vk, proofs, inputs, exp = pkg.synth_groth16(seed, n_public, n, invalid_every=4, agree=True, threads=2)
+    def synth(seed, n_public, first, n, threads):
+        asked.append((first, n))
+        vk, proofs, inputs, exp = pkg.synth_groth16(seed, n_public, n, invalid_every=4, agree=True, threads=2, first=first)
         for i in range(n):
             table[proofs[256 * i:256 * i + 256]] = exp[i]
         return vk, proofs, inputs, exp
 
-    lines = []
-    bench.run_rank(args, lambda vk, proofs, inputs, lr: _StandIn(table, proofs), "gloo", rank, world, rank, synth, emit=lines.append)
+    lines, fulls = [], []
+
+    class Recording(_StandIn):
+        pass
+
+    def make(vk, proofs, inputs, lr):
+        return Recording(table, proofs)
+
+    # keep the gathered vector of the last step: run_rank checks this rank's slice; the test checks the WHOLE order on rank 0
+    sh = importlib.import_module("snark-bn254-verifier_amd.sharding")
+    orig = sh.gather_status
+
+    def spy(local, n, w):
+        full = orig(local, n, w)
+        fulls.append(bytes(full.numpy().tobytes()))
+        return full
+
+    sh.gather_status = spy
+    bench.run_rank(args, make, "gloo", rank, world, rank, synth, emit=lines.append)
     if rank == 0:
-        q.put(lines)
+        q.put((lines, asked, fulls[-1]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_bench_rank_logic_under_gloo():
-    import json
-    world = 2
+def _run_bench_ranks(world, weak):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q, weak)) for r in range(world)]
     for p in procs:
         p.start()
-    lines = q.get(timeout=180)
+    res = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+def test_bench_rank_logic_under_gloo_strong_scaling():
+    """BASELINE configs[2] / SURVEY.md section 8(e): ONE batch, contiguous shards; `--gpus 2` halves the per-GPU batch."""
+    import json
+    lines, asked, full = _run_bench_ranks(2, weak=False)
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * 64 and out["config"]["batch_per_gpu"] == 64
-    assert out["scaling"] == "weak" and out["steps"] == 2 and out["value"] > 0 and "gather_ms" in out["config"]
-    assert out["hbm_roofline"]["algorithmic_bytes_per_proof"] == 321
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["config"]["batch_per_gpu"] == 32
+    assert out["scaling"] == "strong" and out["steps"] == 2 and out["value"] > 0 and "gather_ms" in out["config"]
+    assert out["hbm_roofline"]["algorithmic_bytes_per_proof"] == 256 + 32 * 2 + 1
+    assert asked == [(0, 32)]                       # rank 0 generated exactly its own contiguous range
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    whole = pkg.synth_groth16(__import__("bench").SEED, 2, 64, invalid_every=4, agree=True, threads=2)[3]
+    assert full == whole                            # gathered order = the order of the unsharded batch
 
 
-def test_bench_rotation_changes_the_shard():
-    sys.path.insert(0, ROOT)
-    import bench
-    proofs = b"".join(bytes([i]) * 256 for i in range(8)); inputs = b"".join(bytes([i]) * 64 for i in range(8)); exp = bytes(range(8))
-    p1, i1, e1 = bench.rotate_shard(proofs, inputs, exp, 8, 2, 1)
-    k = 7919 % 8
-    assert e1 == exp[k:] + exp[:k] and p1[:256] == bytes([k]) * 256 and i1[:64] == bytes([k]) * 64
-    assert bench.rotate_shard(proofs, inputs, exp, 8, 2, 0) == (proofs, inputs, exp)
+def test_bench_rank_logic_under_gloo_weak_scaling():
+    import json
+    lines, asked, full = _run_bench_ranks(2, weak=True)
+    out = json.loads(lines[0])
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 128 and out["config"]["batch_per_gpu"] == 64
+    assert asked == [(0, 64)] and len(full) == 128
+
+
+def test_strong_scaling_shard_sizes():
+    """2^20 over 2 / 4 / 8 GPUs = 2^19 / 2^18 / 2^17 proofs per GPU, contiguous (131 072 at N = 8)."""
+    sh = importlib.import_module("snark-bn254-verifier_amd.sharding")
+    for w in (1, 2, 4, 8):
+        b = [sh.shard_bounds(1 << 20, w, r) for r in range(w)]
+        assert [hi - lo for lo, hi in b] == [(1 << 20) // w] * w
+        assert [lo for lo, _ in b] == [r * ((1 << 20) // w) for r in range(w)]
+
+
+def test_verify_batch_multi_planner_matches_the_rank_sharding():
+    """bn254_shard_plan (the single-process multi-GPU entry's planner, host arithmetic) cuts the batch exactly like sharding.shard_bounds."""
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    sh = importlib.import_module("snark-bn254-verifier_amd.sharding")
+    for n in (0, 1, 7, 4096, (1 << 20) + 777):
+        for mask, cnt in ((0b1, 1), (0b11, 2), (0b10110, 8), (0xff, 8)):
+            plan = pkg.shard_plan(n, mask, cnt)
+            devs = [b for b in range(64) if (mask >> b) & 1]
+            assert [d for d, _, _ in plan] == devs
+            assert [(f, f + c) for _, f, c in plan] == [sh.shard_bounds(n, len(devs), r) for r in range(len(devs))]
+    assert [c for _, _, c in pkg.shard_plan(1 << 20, 0xff, 8)] == [131072] * 8
+    with pytest.raises(pkg.Bn254Error):
+        pkg.shard_plan(100, 0b100, 2)               # device 2 of a 2-device host
+    with pytest.raises(pkg.Bn254Error):
+        pkg.shard_plan(100, 0, 8)
+
+
+def test_synth_range_is_a_slice_of_the_stream():
+    pkg = importlib.import_module("snark-bn254-verifier_amd")
+    a = pkg.synth_groth16(77, 2, 96, invalid_every=4, agree=True, threads=2)
+    b = pkg.synth_groth16(77, 2, 40, invalid_every=4, agree=True, threads=3, first=50)
+    assert a[0] == b[0] and a[1][256 * 50:256 * 90] == b[1] and a[2][64 * 50:64 * 90] == b[2] and a[3][50:90] == b[3]
 
 
 def test_bench_self_launches_its_ranks():

@@ -233,6 +233,9 @@ def test_plonk_batch_4096(pkg, O, fixtures):
     reps = 4096 // len(cases)
     big = pvk.verify_batch(b"".join(c[0] for c in cases) * reps, b"".join(c[1] for c in cases) * reps)
     assert big == small * reps
+    # ... and the small run's statuses are the ORACLE's, case by case (not only self-consistent)
+    exp = bytes(O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) for c in cases)
+    assert small == exp and len(set(exp)) >= 3
     pvk.close()
 
 
@@ -395,17 +398,28 @@ def test_batch_4096_properties(pkg, O, L):
     pvk.close()
 
 
-def test_batch_65536_expected_statuses(pkg, L):
+def _oracle_sample(O, vk, proofs, inputs, n_public, idx, mode=None):
+    """The oracle's verdicts on the proofs idx of a batch (strided samples of the big runs)."""
+    sz = 32 * n_public
+    sp = b"".join(proofs[256 * j:256 * j + 256] for j in idx); si = b"".join(inputs[sz * j:sz * j + sz] for j in idx)
+    return O.groth16_verify_many(sp, 256, vk, si, n_public, len(idx), O.MODE_REFERENCE if mode is None else mode)
+
+
+def test_batch_65536_expected_statuses(pkg, O, L):
     n = 1 << 16
     vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540003, 2, n, invalid_every=16, agree=True, threads=16)
     pvk = pkg.PreparedVk(vk)
     st = pvk.verify_batch(proofs, inputs)
     assert st == exp
     assert st.count(bytes([1])) == n - n // 16
+    # not only the generator's word for it: the oracle on 256 proofs spread over the batch (stride 255 meets every failure class)
+    idx = list(range(0, n, 255))[:256] + [n - 1]
+    assert _oracle_sample(O, vk, proofs, inputs, 2, idx) == bytes(st[j] for j in idx)
+    assert len(set(st[j] for j in idx)) == 5
     pvk.close()
 
 
-def test_full_size_batch_two_chunks(pkg, L):
+def test_full_size_batch_two_chunks(pkg, O, L):
     """BASELINE's full batch size and beyond: 2^20 + 777 proofs run as two workspace chunks (and sub-batch streams); the status
     vector must be the generator's (every 16th proof invalid, cycling through the five failure classes)."""
     n = (1 << 20) + 777
@@ -414,6 +428,36 @@ def test_full_size_batch_two_chunks(pkg, L):
     st = pvk.verify_batch(proofs, inputs)
     assert len(st) == n and st == exp
     assert st.count(bytes([pkg.ACCEPT])) == n - n // 16
+    # the oracle on a strided 256-proof sample of the full-size batch, the second chunk's 777 proofs included
+    idx = list(range(0, 1 << 20, 4111))[:248] + list(range((1 << 20) + 7, n, 97))[:8]
+    assert len(idx) == 256 and _oracle_sample(O, vk, proofs, inputs, 2, idx) == bytes(st[j] for j in idx)
+    assert len(set(st[j] for j in idx)) == 5
+    pvk.close()
+
+
+def test_config5_full_size_4096_x_1024_inputs(pkg, O, L):
+    """BASELINE configs[4] at its full size: 4096 proofs x 1024 public inputs (262 144 MSM lanes, 168 MB of comb digits) against the generator's
+    statuses, the oracle on 24 strided proofs."""
+    n, n_public = 4096, 1024
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540051, n_public, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert st == exp and set(exp) == {0, 1, 2, 3, 4}
+    idx = list(range(3, n, 171))[:24]          # stride 171: indices 15 mod 16 (the invalid ones) come up with every class
+    assert _oracle_sample(O, vk, proofs, inputs, n_public, idx) == bytes(st[j] for j in idx)
+    assert len(set(st[j] for j in idx)) >= 3
+    pvk.close()
+
+
+def test_wide_msm_slicing_70000_x_40_inputs(pkg, O, L):
+    """More proofs than one wide-MSM launch holds (G16_WIDE_MSM_MAX_PROOFS = 65536): the batch runs in slices that reuse the partial-sum buffer."""
+    n, n_public = 70000, 40
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540052, n_public, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert st == exp
+    idx = list(range(0, n, 2917))[:24] + [65535, 65536, 65551, n - 1]      # both sides of the slice boundary
+    assert _oracle_sample(O, vk, proofs, inputs, n_public, idx) == bytes(st[j] for j in idx)
     pvk.close()
 
 

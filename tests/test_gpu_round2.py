@@ -22,10 +22,13 @@ def L(pkg):
 
 
 @pytest.fixture(autouse=True)
-def _rlc_always(monkeypatch):
-    """The RLC tests want the RLC kernels to run on every call: switch the adaptive bypass off (test_rlc_adaptive_bypass switches it on)."""
-    monkeypatch.setenv("BN254_RLC_ADAPTIVE", "0")
-    monkeypatch.setenv("BN254_RLC_MIN_BATCH", "64")       # by default the flag is honoured from 200 000 proofs (where the mode pays)
+def _rlc_always(pkg):
+    """The RLC tests want the RLC kernels to run on every call: switch the adaptive bypass off (test_rlc_adaptive_bypass switches it on) and
+    honour the flag from 64 proofs (by default from 200 000, where the mode pays).  bn254_set_rlc_params, not the environment: the library
+    reads its environment once, when it is loaded."""
+    pkg.set_rlc_params(min_batch=64, adaptive=0, share_min_lanes=65536)
+    yield
+    pkg.set_rlc_params(min_batch=200000, adaptive=1, share_min_lanes=65536)
 
 
 @pytest.fixture(scope="module")
@@ -52,11 +55,11 @@ def test_rlc_statuses_identical_to_exact(pkg, O, wl, L):
         pvk.close()
 
 
-def test_rlc_adaptive_bypass(pkg, wl, L, monkeypatch):
+def test_rlc_adaptive_bypass(pkg, wl, L):
     """With most groups failing (every 8th proof invalid, groups of 32) the flag stops paying: after the first RLC pass has measured the
     fallback share the next calls run the exact path (same status bytes), with a measuring RLC pass every 8 calls; a mostly valid
     workload on the same key brings the mode back."""
-    monkeypatch.setenv("BN254_RLC_ADAPTIVE", "1")
+    pkg.set_rlc_params(adaptive=1)
     vk, proofs, inputs, exp = wl
     pvk = pkg.PreparedVk(vk)
     assert pvk.rlc_state() == (-1.0, 0)
@@ -82,15 +85,9 @@ def test_rlc_shared_accumulator_layout(pkg, O, wl, L):
     (by default it is used from 2^19 proofs per launch), same status bytes as the exact path."""
     vk, proofs, inputs, exp = wl
     pvk = pkg.PreparedVk(vk)
-    old = {k: os.environ.get(k) for k in ("BN254_RLC_SHARE_MIN_LANES",)}
-    try:
-        os.environ["BN254_RLC_SHARE_MIN_LANES"] = "1"
-        for n in (len(exp), 1000, 257, 67):
-            assert pvk.verify_batch(proofs[:256 * n], inputs[:64 * n], n, flags=pkg.FLAG_RLC) == exp[:n], n
-    finally:
-        for k, v in old.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+    pkg.set_rlc_params(share_min_lanes=1)
+    for n in (len(exp), 1000, 257, 67):
+        assert pvk.verify_batch(proofs[:256 * n], inputs[:64 * n], n, flags=pkg.FLAG_RLC) == exp[:n], n
     pvk.close()
 
 
@@ -111,6 +108,28 @@ def test_rlc_all_valid_all_invalid_and_sizes(pkg, O, L):
     # wrong number of public inputs under the flag: exact semantics (INPUT_LEN)
     assert pvk.verify_batch(proofs[:256 * 100], inputs[:32 * 100], 100, n_public=1, flags=pkg.FLAG_RLC) == bytes([pkg.ERR_INPUT_LEN]) * 100
     pvk.close()
+
+
+def test_rlc_default_threshold_large_batch(pkg, O, L):
+    """The flag at its DEFAULT threshold (no override: honoured from 200 000 proofs): 2^18 proofs with a few invalid ones take the RLC kernels
+    (the fallback share is reported), and the status bytes are the exact path's, the generator's and -- on a strided sample -- the oracle's."""
+    pkg.set_rlc_params(min_batch=200000, adaptive=1)
+    n = 1 << 18
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540019, 2, n, invalid_every=1024, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    assert pvk.rlc_state()[0] == -1.0
+    st = pvk.verify_batch(proofs, inputs, flags=pkg.FLAG_RLC)
+    share = pvk.rlc_state()[0]
+    assert 0.0 < share < 0.1, share             # an RLC pass ran: 256 invalid proofs send 256 groups of 32 to the fallback (3 %)
+    assert st == exp == pvk.verify_batch(proofs, inputs)
+    idx = list(range(0, n, 1025))[:200] + list(range(1023, n, 1024 * 37))[:8]
+    sp = b"".join(proofs[256 * j:256 * j + 256] for j in idx); si = b"".join(inputs[64 * j:64 * j + 64] for j in idx)
+    assert O.groth16_verify_many(sp, 256, vk, si, 2, len(idx), O.MODE_REFERENCE) == bytes(st[j] for j in idx)
+    # below the threshold the flag is ignored: no new RLC pass is recorded
+    pvk2 = pkg.PreparedVk(vk)
+    assert pvk2.verify_batch(proofs[:256 * 4096], inputs[:64 * 4096], 4096, flags=pkg.FLAG_RLC) == exp[:4096]
+    assert pvk2.rlc_state()[0] == -1.0
+    pvk.close(); pvk2.close()
 
 
 def test_rlc_more_public_inputs(pkg, O, L):

@@ -83,90 +83,8 @@ def test_final_exp_chain_is_power_of_plain(O):
     assert acc == chain
 
 
-# ---------------------------------------------------------------- independent pairing (py_ecc style)
-FQ12_MOD = [82, 0, 0, 0, 0, 0, -18, 0, 0, 0, 0, 0]  # w^12 = 18 w^6 - 82
-
-
-def p12_mul(a, b):
-    t = [0] * 23
-    for i, x in enumerate(a):
-        if x:
-            for j, y in enumerate(b):
-                t[i + j] += x * y
-    for k in range(22, 11, -1):
-        v = t[k]
-        if v:
-            t[k - 6] += 18 * v
-            t[k - 12] -= 82 * v
-    return [x % P for x in t[:12]]
-
-
-def p12_pow(a, e):
-    r = [1] + [0] * 11
-    while e:
-        if e & 1:
-            r = p12_mul(r, a)
-        a = p12_mul(a, a)
-        e >>= 1
-    return r
-
-
-def p12_inv(a):
-    return p12_pow(a, P ** 12 - 2)
-
-
-def p12_add(a, b): return [(x + y) % P for x, y in zip(a, b)]
-def p12_sub(a, b): return [(x - y) % P for x, y in zip(a, b)]
-def p12_scalar(v): return [v % P] + [0] * 11
-
-
-def untwist(q):  # q = ((x0, x1), (y0, y1)) on the twist; i = w^6 - 9; (x w^2, y w^3)
-    (x0, x1), (y0, y1) = q
-    x = [0] * 12; y = [0] * 12
-    x[2] = (x0 - 9 * x1) % P; x[8] = x1
-    y[3] = (y0 - 9 * y1) % P; y[9] = y1
-    return x, y
-
-
-def ec12_double(p):
-    x, y = p
-    lam = p12_mul(p12_mul(p12_scalar(3), p12_mul(x, x)), p12_inv(p12_mul(p12_scalar(2), y)))
-    nx = p12_sub(p12_mul(lam, lam), p12_mul(p12_scalar(2), x))
-    ny = p12_sub(p12_mul(lam, p12_sub(x, nx)), y)
-    return nx, ny, lam
-
-
-def ec12_add(p, q):
-    lam = p12_mul(p12_sub(q[1], p[1]), p12_inv(p12_sub(q[0], p[0])))
-    nx = p12_sub(p12_sub(p12_mul(lam, lam), p[0]), q[0])
-    ny = p12_sub(p12_mul(lam, p12_sub(p[0], nx)), p[1])
-    return nx, ny, lam
-
-
-def slow_pairing_plain(g1, q):
-    """f_{6u+2,Q}(P) l l over the BITS of 6u+2 (no NAF, no twist tricks), then ^((p^12-1)/r)."""
-    px, py = p12_scalar(g1[0]), p12_scalar(g1[1])
-    Q = untwist(q)
-
-    def line(t, lam):
-        return p12_sub(p12_sub(py, t[1]), p12_mul(lam, p12_sub(px, t[0])))
-
-    f = p12_scalar(1)
-    T = Q
-    n = 6 * U + 2
-    for bit in bin(n)[3:]:
-        nx, ny, lam = ec12_double(T)
-        f = p12_mul(p12_mul(f, f), line(T, lam))
-        T = (nx, ny)
-        if bit == "1":
-            nx, ny, lam = ec12_add(T, Q)
-            f = p12_mul(f, line(T, lam))
-            T = (nx, ny)
-    frob = lambda pt: (p12_pow(pt[0], P), p12_pow(pt[1], P))
-    Q1 = frob(Q); Q2 = frob(Q1); nQ2 = (Q2[0], [(-v) % P for v in Q2[1]])
-    nx, ny, lam = ec12_add(T, Q1); f = p12_mul(f, line(T, lam)); T = (nx, ny)
-    nx, ny, lam = ec12_add(T, nQ2); f = p12_mul(f, line(T, lam))
-    return p12_pow(f, (P ** 12 - 1) // R)
+# ---------------------------------------------------------------- independent pairing (py_ecc style): tests/pyref_groth16.py
+from pyref_groth16 import slow_pairing_plain  # noqa: E402  polynomial-basis Fp12, Miller loop over the bits of 6u+2, plain pow((p^12-1)/r)
 
 
 def tower_bytes_to_poly(b):
