@@ -79,7 +79,10 @@ struct DevState {
   uint8_t* pin[3] = {nullptr, nullptr, nullptr}; size_t pin_cap = 0; hipEvent_t pin_ev[3] = {nullptr, nullptr, nullptr};   // ring of pinned pieces (HOST_RING)
   hipEvent_t busy_ev = nullptr; bool busy_valid = false;
   hipEvent_t ev[5]; bool ev_ready = false; bool ev_recorded = false;
-  hipStream_t aux[4]; hipEvent_t fork_ev, join_ev[4]; bool aux_ready = false;  // concurrent sub-batches (see g16_enqueue)
+  // concurrent sub-batches (see g16_enqueue_exact): part 0 runs on the caller's stream, parts 1..3 on these, created when first needed -- every
+  // stream of a process shares the runtime's few hardware queues (four by default), and a copy stream that lands on the queue of a busy compute
+  // stream waits behind its kernels (measured: 3 GB/s instead of 55), so no stream is created that is not used
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr}; int aux_count = 0; hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // per-launch timing of the first sub-batch (bn254_groth16_kernel_profile)
   std::vector<hipEvent_t> prof_ev; std::vector<uint8_t> prof_kid; G16Prof prof{0, nullptr, nullptr, 0, 0}; size_t prof_n = 0;
   RlcDev rlc;                                                       // BN254_FLAG_RLC buffers (bn254_rlc.hpp)
@@ -153,20 +156,25 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
   }
   return BN254_OK;
 }
-static int ensure_aux(DevState& d) {
-  if (d.aux_ready) return BN254_OK;
-  for (int i = 0; i < 4; i++) { HIPCK(hipStreamCreateWithFlags(&d.aux[i], hipStreamNonBlocking)); HIPCK(hipEventCreateWithFlags(&d.join_ev[i], hipEventDisableTiming)); }
-  HIPCK(hipEventCreateWithFlags(&d.fork_ev, hipEventDisableTiming));
-  d.aux_ready = true;
+static int ensure_aux(DevState& d, int count) {
+  if (count > 3) count = 3;
+  if (!d.fork_ev) {
+    HIPCK(hipEventCreateWithFlags(&d.fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) HIPCK(hipEventCreateWithFlags(&d.join_ev[i], hipEventDisableTiming));
+  }
+  while (d.aux_count < count) { HIPCK(hipStreamCreateWithFlags(&d.aux[d.aux_count], hipStreamNonBlocking)); d.aux_count++; }
   return BN254_OK;
 }
+// part pi of a batch split over concurrent streams: slot pi % 4, slot 0 = the caller's stream, slots 1..3 = the auxiliary streams
+static inline hipStream_t part_stream(DevState& d, hipStream_t user, int pi) { const int k = pi % 4; return k == 0 ? user : d.aux[k - 1]; }
 static void dev_free(DevState& d) {
   int32_t* ptrs[] = {d.k0, d.gtab, d.dtab, d.target, d.msm, d.ws, d.msm_part};
   for (auto q : ptrs) if (q) (void)hipFree(q);
   uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
   for (auto q : bp) if (q) (void)hipFree(q);
   if (d.ev_ready) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(d.ev[i]); for (auto& e : d.prof_ev) (void)hipEventDestroy(e); }
-  if (d.aux_ready) { for (int i = 0; i < 4; i++) { (void)hipStreamDestroy(d.aux[i]); (void)hipEventDestroy(d.join_ev[i]); } (void)hipEventDestroy(d.fork_ev); }
+  for (int i = 0; i < d.aux_count; i++) (void)hipStreamDestroy(d.aux[i]);
+  if (d.fork_ev) { (void)hipEventDestroy(d.fork_ev); for (int i = 0; i < 4; i++) (void)hipEventDestroy(d.join_ev[i]); }
   if (d.busy_ev) (void)hipEventDestroy(d.busy_ev);
   if (d.host_stream) (void)hipStreamDestroy(d.host_stream);
   if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
@@ -465,14 +473,14 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
     while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
     const bool concurrent = !wide && n_streams > 1 && parts > 1;
     const bool split_small = m <= (size_t)G16_SPLIT_MAX_PROOFS;   // latency mode of bn254_launch_g16
-    if (concurrent || split_small) { int rc = ensure_aux(*d); if (rc) return rc; }
+    if (concurrent || split_small) { int rc = ensure_aux(*d, concurrent ? parts - 1 : 2); if (rc) return rc; }
     if (concurrent) HIPCK(hipEventRecord(d->fork_ev, user));
     size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
     for (int pi = 0; pi < parts; pi++) {
       size_t lo = (size_t)pi * per, hi = lo + per < m ? lo + per : m;
       if (lo >= hi) break;
-      hipStream_t st = concurrent ? d->aux[pi % 4] : user;
-      if (concurrent && pi < 4) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
+      hipStream_t st = concurrent ? part_stream(*d, user, pi) : user;
+      if (concurrent && pi < 4 && st != user) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
       G16LaunchArgs a;
       a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
       a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
@@ -485,7 +493,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       a.msm_comb = pvk->host.msm_comb ? 1 : 0;
       a.msm_digits = (wide && pvk->host.msm_comb) ? (uint16_t*)(d->msm_part + d->msm_chunks * 27 * d->msm_part_cap) : nullptr;
       if (split_small && parts == 1) {
-        a.split_streams[0] = d->aux[1]; a.split_streams[1] = d->aux[2];
+        a.split_streams[0] = d->aux[0]; a.split_streams[1] = d->aux[1];
         a.split_ev[0] = d->fork_ev; a.split_ev[1] = d->join_ev[1]; a.split_ev[2] = d->join_ev[2];
       }
       // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
@@ -494,7 +502,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : nullptr);
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));
-      if (concurrent && (pi + 4 >= parts)) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
+      if (concurrent && (pi + 4 >= parts) && st != user) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
     }
   }
   d->ev_recorded = profiling && d->ev_ready;
@@ -548,14 +556,14 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
     int parts = (n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
     while ((m + parts - 1) / parts > (size_t)G16_MAX_LAUNCH) parts++;
     const bool concurrent = parts > 1;
-    if (concurrent) { rc = ensure_aux(*d); if (rc) return rc; HIPCK(hipEventRecord(d->fork_ev, user)); }
+    if (concurrent) { rc = ensure_aux(*d, parts - 1); if (rc) return rc; HIPCK(hipEventRecord(d->fork_ev, user)); }
     const size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
     size_t grp_off = 0;
     for (int pi = 0; pi < parts; pi++) {
       const size_t lo = (size_t)pi * per, hi = lo + per < m ? lo + per : m;
       if (lo >= hi) break;
-      hipStream_t st = concurrent ? d->aux[pi % 4] : user;
-      if (concurrent && pi < 4) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
+      hipStream_t st = concurrent ? part_stream(*d, user, pi) : user;
+      if (concurrent && pi < 4 && st != user) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
       G16LaunchArgs a;
       a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
       a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
@@ -578,7 +586,7 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
       hipError_t e = bn254_launch_g16_rlc(a, ra, st);
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch (rlc): ") + hipGetErrorString(e));
-      if (concurrent && (pi + 4 >= parts)) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
+      if (concurrent && (pi + 4 >= parts) && st != user) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
     }
     // which proofs are still pending (their group's product was not one)?  One stream synchronisation per chunk.
     HIPCK(hipMemcpyAsync(r.h_status, (const uint8_t*)d_status + off, m, hipMemcpyDeviceToHost, user));
@@ -752,7 +760,10 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
       (rc = grow(&d->st_status, &d->st_status_cap, n)))
     return rc;
   if (!d->host_stream) { HIPCK(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking)); }
-  static const size_t hchunk = [] { const char* e = getenv("BN254_HOST_CHUNK_LOG2"); int v = e ? atoi(e) : 18; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
+  // compute chunks: a short first one (its copy is the only exposed one: 2^17 proofs = 42 MB, under a millisecond of DMA), then the rest in chunks
+  // as large as the workspace allows -- every chunk boundary drains both sub-batch streams, so fewer chunks is faster
+  static const size_t first_chunk = [] { const char* e = getenv("BN254_HOST_FIRST_CHUNK_LOG2"); int v = e ? atoi(e) : 17; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
+  const size_t hchunk = (size_t)G16_MAX_BATCH - first_chunk;
   // copy pieces: about 20 MB of the caller's bytes each (65536 proofs at 2 public inputs), a multiple of 256 proofs
   static const size_t piece_bytes_target = [] { const char* e = getenv("BN254_HOST_PIECE_MB"); long v = e ? atol(e) : 20; return (size_t)(v < 1 ? 1 : v) << 20; }();
   size_t piece = piece_bytes_target / row / 256 * 256;
@@ -763,17 +774,26 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
   // (same predicate as g16_enqueue, the adaptive bypass included, decided ONCE here); a flag that will be ignored keeps the chunked
   // copy / compute overlap
   const int use_rlc = (rlc_eligible(pvk, n_public, n, flags) && !rlc_bypass(d->rlc)) ? 1 : 0;
+  static const bool timing = getenv("BN254_HOST_TIMING") != nullptr;   // diagnostics on stderr: where the host thread spends the call
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  double t_copy = 0, t_wait = 0, t_enq = 0;
+  const auto t_begin = now();
   size_t copied = 0, computed = 0, slot_uses = 0;
   // the first chunk is short (its copy is the only exposed one) unless the batch is small anyway
-  size_t c_end = use_rlc ? n : (n > hchunk ? (hchunk / 2 < n ? hchunk / 2 : n) : n);
+  size_t c_end = (use_rlc || n < 2 * first_chunk) ? n : first_chunk;
   while (computed < n) {
     hipEvent_t last = nullptr;
     while (copied < c_end) {
       const size_t m = c_end - copied < piece ? c_end - copied : piece;
       const int slot = (int)(slot_uses % HOST_RING);
+      auto ta = now();
       if (slot_uses >= HOST_RING) HIPCK(hipEventSynchronize(d->pin_ev[slot]));     // the piece that used this slot has left for the device
+      auto tb = now();
       parallel_copy(d->pin[slot], proofs + copied * proof_stride, m * proof_stride);
       if (in_row) parallel_copy(d->pin[slot] + m * proof_stride, public_inputs + copied * in_row, m * in_row);
+      auto tc = now();
+      t_wait += ms(ta, tb); t_copy += ms(tb, tc);
       HIPCK(hipMemcpyAsync(d->st_proofs + copied * proof_stride, d->pin[slot], m * proof_stride, hipMemcpyHostToDevice, d->copy_stream));
       if (in_row) HIPCK(hipMemcpyAsync(d->st_inputs + copied * in_row, d->pin[slot] + m * proof_stride, m * in_row, hipMemcpyHostToDevice, d->copy_stream));
       HIPCK(hipEventRecord(d->pin_ev[slot], d->copy_stream));
@@ -781,14 +801,19 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
       slot_uses++; copied += m;
     }
     if (last) HIPCK(hipStreamWaitEvent(d->host_stream, last, 0));
+    auto td = now();
     rc = g16_enqueue(pvk, d, device, d->st_proofs + computed * proof_stride, proof_stride, d->st_inputs + computed * in_row, n_public, c_end - computed,
                      d->st_status + computed, d->host_stream, flags, use_rlc);
     if (rc) return rc;
+    t_enq += ms(td, now());
     computed = c_end;
     c_end = n - c_end < hchunk ? n : c_end + hchunk;
   }
+  const auto t_enqueued = now();
   HIPCK(hipMemcpyAsync(status, d->st_status, n, hipMemcpyDeviceToHost, d->host_stream));
   HIPCK(hipStreamSynchronize(d->host_stream));
+  if (timing) fprintf(stderr, "host-buffer batch %zu: pieces of %zu proofs; host copies %.2f ms, ring waits %.2f ms, kernel enqueue %.2f ms, all enqueued after %.2f ms, done after %.2f ms\n",
+                      n, piece, t_copy, t_wait, t_enq, ms(t_begin, t_enqueued), ms(t_begin, now()));
   return BN254_OK;
 }
 

@@ -405,6 +405,18 @@ def _oracle_sample(O, vk, proofs, inputs, n_public, idx, mode=None):
     return O.groth16_verify_many(sp, 256, vk, si, n_public, len(idx), O.MODE_REFERENCE if mode is None else mode)
 
 
+def _mixed_sample(n, valid, per_class, lo=0, invalid_every=16):
+    """Indices in [lo, n): `valid` strided ones plus `per_class` proofs of each of the generator's five failure classes (proof i is invalid
+    when i % invalid_every == invalid_every - 1, its class (i // invalid_every) % 5), spread over the range."""
+    idx = set(range(lo, n, max(1, (n - lo) // valid)))
+    q_lo, q_hi = (lo + invalid_every - 1) // invalid_every, n // invalid_every
+    for cls in range(5):
+        qs = [q for q in range(q_lo, q_hi) if q % 5 == cls]
+        step = max(1, len(qs) // per_class)
+        idx.update(invalid_every * q + invalid_every - 1 for q in qs[::step][:per_class])
+    return sorted(i for i in idx if lo <= i < n)
+
+
 def test_batch_65536_expected_statuses(pkg, O, L):
     n = 1 << 16
     vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540003, 2, n, invalid_every=16, agree=True, threads=16)
@@ -412,8 +424,8 @@ def test_batch_65536_expected_statuses(pkg, O, L):
     st = pvk.verify_batch(proofs, inputs)
     assert st == exp
     assert st.count(bytes([1])) == n - n // 16
-    # not only the generator's word for it: the oracle on 256 proofs spread over the batch (stride 255 meets every failure class)
-    idx = list(range(0, n, 255))[:256] + [n - 1]
+    # not only the generator's word for it: the oracle on ~256 proofs spread over the batch, every failure class among them
+    idx = _mixed_sample(n, 200, 11) + [n - 1]
     assert _oracle_sample(O, vk, proofs, inputs, 2, idx) == bytes(st[j] for j in idx)
     assert len(set(st[j] for j in idx)) == 5
     pvk.close()
@@ -429,9 +441,9 @@ def test_full_size_batch_two_chunks(pkg, O, L):
     assert len(st) == n and st == exp
     assert st.count(bytes([pkg.ACCEPT])) == n - n // 16
     # the oracle on a strided 256-proof sample of the full-size batch, the second chunk's 777 proofs included
-    idx = list(range(0, 1 << 20, 4111))[:248] + list(range((1 << 20) + 7, n, 97))[:8]
-    assert len(idx) == 256 and _oracle_sample(O, vk, proofs, inputs, 2, idx) == bytes(st[j] for j in idx)
-    assert len(set(st[j] for j in idx)) == 5
+    idx = _mixed_sample(1 << 20, 190, 10) + _mixed_sample(n, 6, 2, lo=1 << 20)
+    assert 240 <= len(idx) <= 280 and _oracle_sample(O, vk, proofs, inputs, 2, idx) == bytes(st[j] for j in idx)
+    assert len(set(st[j] for j in idx)) == 5 and len(set(st[j] for j in idx if j >= 1 << 20)) == 5
     pvk.close()
 
 
@@ -443,9 +455,9 @@ def test_config5_full_size_4096_x_1024_inputs(pkg, O, L):
     pvk = pkg.PreparedVk(vk)
     st = pvk.verify_batch(proofs, inputs)
     assert st == exp and set(exp) == {0, 1, 2, 3, 4}
-    idx = list(range(3, n, 171))[:24]          # stride 171: indices 15 mod 16 (the invalid ones) come up with every class
-    assert _oracle_sample(O, vk, proofs, inputs, n_public, idx) == bytes(st[j] for j in idx)
-    assert len(set(st[j] for j in idx)) >= 3
+    idx = _mixed_sample(n, 14, 2)
+    assert 20 <= len(idx) <= 28 and _oracle_sample(O, vk, proofs, inputs, n_public, idx) == bytes(st[j] for j in idx)
+    assert len(set(st[j] for j in idx)) == 5
     pvk.close()
 
 
@@ -456,7 +468,7 @@ def test_wide_msm_slicing_70000_x_40_inputs(pkg, O, L):
     pvk = pkg.PreparedVk(vk)
     st = pvk.verify_batch(proofs, inputs)
     assert st == exp
-    idx = list(range(0, n, 2917))[:24] + [65535, 65536, 65551, n - 1]      # both sides of the slice boundary
+    idx = sorted(set(_mixed_sample(n, 14, 2) + [65535, 65536, 65551, n - 1]))      # both sides of the slice boundary
     assert _oracle_sample(O, vk, proofs, inputs, n_public, idx) == bytes(st[j] for j in idx)
     pvk.close()
 
