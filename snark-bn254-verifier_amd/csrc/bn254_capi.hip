@@ -408,7 +408,6 @@ void bn254_set_profiling(int enabled) { g_profiling.store(enabled); }
 void bn254_set_profile_kernels(unsigned mask) { g_prof_mask.store(mask); }
 int bn254_groth16_num_kernel_kinds(void) { return KID_COUNT; }
 const char* bn254_groth16_kernel_kind_name(int i) {
-  if (i == KID_COOP_G16 && bn254_coop_lanes() == 12) return "k_coop12_miller_g16";   // the generation in use (BN254_COOP_LANES)
   if (i == KID_MSM_PARTIAL) { const char* e = getenv("BN254_WIDE_COMB"); if (!(e && atoi(e) == 0)) return "k_g16_msm_partial_comb"; }   // the table form in use
   return (i >= 0 && i < KID_COUNT) ? bn254_kernel_kind_names[i] : "";
 }

@@ -1,7 +1,7 @@
-// bn254_coop12.hip -- the cooperative layout for SMALL batches, second generation: TWELVE lanes per proof.
+// bn254_coop12.hip -- the cooperative layout for SMALL batches: TWELVE lanes per proof.
 //
-// bn254_coop.hip spreads a proof over six lanes (one Fp2 coefficient of every Fp12 value per lane): a batch of 4096 proofs is 410 wavefronts on
-// 1024 SIMDs, and the time of the one launch is one wavefront's serial instruction stream.  Here every Fp2 coefficient
+// A first generation (retired) spread a proof over six lanes, one Fp2 coefficient of every Fp12 value per lane: a batch of
+// 4096 proofs was 410 wavefronts on 1024 SIMDs, and the time of the one launch one wavefront's serial instruction stream.  Here every Fp2 coefficient
 // k_c = re + im i is split once more: lane (c, h) of a proof keeps ONE Fp number, h = 0: re, h = 1: im.  A product of two coefficients is
 //     (a b)_h = a.re * b_h + a.im * (i b)_h          with  i b = (-b.im, b.re)
 // so a sum of n coefficient products is one Fp dot product of 2 n terms per lane (bn254_fp.h::fp_dot: 162 n + 81 multiply-adds against
@@ -10,11 +10,11 @@
 // Five proofs per wavefront (lanes 60..63 idle): 4096 proofs are 820 wavefronts -- still one per SIMD -- with about 0.62 of the multiply-adds.
 //
 // LDS image per wavefront: img[slot][lane][12 dwords] (one Fp = 9 digits + 3 pad: three ds_read_b128; 12 * lane mod 64 puts 16 consecutive lanes
-// on disjoint 4-bank groups), 13 slots = 39 KB, so FOUR wavefronts share a CU's 160 KB (the six-lane image is 66.5 KB: two).  Slots hold Fp12
-// VALUES exactly as in bn254_coop.hip (same slot numbers, same program template for the final exponentiation); "half h of coefficient i of value a"
+// on disjoint 4-bank groups), 13 slots = 39 KB, so FOUR wavefronts share a CU's 160 KB (the six-lane image was 66.5 KB: two).  Slots hold Fp12
+// VALUES (slot numbers = the workspace map's, the final exponentiation is the same program template as everywhere else); "half h of coefficient i of value a"
 // is a read at (a, group base + 2 i + h).
 //
-// Lock-step: as in bn254_coop.hip -- a wavefront executes its LDS instructions in order, every operation reads all of its inputs before it writes
+// Lock-step: a wavefront executes its LDS instructions in order, every operation reads all of its inputs before it writes
 // its output slot.
 #include <hip/hip_runtime.h>
 #include <mutex>
@@ -139,7 +139,7 @@ __device__ __noinline__ void c12_mul(const Coop12 co, int d, int a, int b, bool 
   }
   co.put(d, acc);
 }
-// ---- Granger-Scott squarings, `count` times (pairing of coefficients and roles: bn254_coop.hip::co_cyclo_sqr_n) ------------------------------------------------
+// ---- Granger-Scott squarings, `count` times (pairing of coefficients and roles: bn254_tower.h::fp12_cyclo_sqr) ------------------------------------------------
 __constant__ int8_t C12_CY_A[6] = {0, 2, 1, 0, 2, 1};
 __constant__ int8_t C12_CY_B[6] = {3, 5, 4, 3, 5, 4};
 __device__ __noinline__ void c12_cyclo_sqr_n(const Coop12 co, int d, int s, int count) {
@@ -276,7 +276,7 @@ k_coop12_miller_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ statu
 }
 
 // ---- Groth16: public-input MSM, the shared Miller loop of (A, B) with the running G2 point and the two table-driven pairs, final exponentiation --------------
-// The G2 step's independent Fp2 products are dealt to the six coefficient positions in ROUNDS as in bn254_coop.hip; the two lanes of a position
+// The G2 step's independent Fp2 products are dealt to the six coefficient positions in ROUNDS; the two lanes of a position
 // compute the two halves of its product.  T = (X, Y, Z) is kept whole by every lane.
 __device__ __forceinline__ Fp2 c12_sel6(uint32_t c, const Fp2& v0, const Fp2& v1, const Fp2& v2, const Fp2& v3, const Fp2& v4, const Fp2& v5) {
   return fp2_select(c == 0, v0, fp2_select(c == 1, v1, fp2_select(c == 2, v2, fp2_select(c == 3, v3, fp2_select(c == 4, v4, v5)))));

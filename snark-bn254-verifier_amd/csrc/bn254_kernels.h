@@ -76,7 +76,7 @@ static inline __host__ __device__ uint32_t g16_comb_digit(const uint32_t w[8], i
 // kernel kinds of the Groth16 path (one launch per Fp12-level operation of the verification program)
 enum {
   KID_PREPARE, KID_SUBGROUP, KID_VM_INIT, KID_F12_SQR, KID_MUL_LINE_FIXED, KID_F12_MUL,
-  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_F12_COPY, KID_CYCLO_SQR_N, KID_MILLER_DBL_VAR, KID_MILLER_ADD_VAR, KID_MSM_PARTIAL, KID_MSM_REDUCE, KID_MUL_LINE_FIXED2, KID_MILLER_SQR_DBL_VAR, KID_MILLER_STEP_DBL, KID_MILLER_STEP_ADD, KID_COOP_G16, KID_COUNT
+  KID_CYCLO_SQR, KID_F12_CONJ, KID_F12_FROB, KID_F12_INV, KID_COMPARE, KID_F12_COPY, KID_CYCLO_SQR_N, KID_MILLER_DBL_VAR, KID_MILLER_ADD_VAR, KID_MSM_PARTIAL, KID_MSM_REDUCE, KID_MUL_LINE_FIXED2, KID_MILLER_SQR_DBL_VAR, KID_MILLER_STEP_DBL, KID_MILLER_STEP_ADD, KID_COOP_G16, KID_MILLER_RUN, KID_COUNT
 };
 extern const char* const bn254_kernel_kind_names[KID_COUNT];
 // optional per-launch timing: every launch whose kind is in `mask` is bracketed by two events from the pool
@@ -87,6 +87,12 @@ struct G16Prof {
   int cap, used;
 };
 hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev, G16Prof* prof);
+// bn254_k_miller.hip: one whole step of the shared Miller loop (kind 0: doubling, with the squaring of f when do_sqr; 1..4: additions)
+void bn254_launch_miller_step(bool do_sqr, int kind, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb, int e, int epa,
+                              const int32_t* t0, int ep0, int inf0, const int32_t* t1, int ep1, int inf1);
+// a run of steps in one launch (bn254_vm.h::vm_miller_run): n_dbl doublings from step s0 (tab0 / tab1: the WHOLE line tables), then the addition add_kind (0: none)
+void bn254_launch_miller_run(int s0, int n_dbl, bool first_sqr, int add_kind, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
+                             int e, int epa, const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1);
 // RLC batch mode (bn254_rlc.h): one launch part = n <= G16_MAX_LAUNCH proofs forming plan.groups groups
 #include "bn254_rlc_plan.h"
 struct RlcLaunchArgs {
@@ -110,24 +116,17 @@ hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int la
 bool bn254_g1_msm_split(size_t n, int n_terms);   // the scalar-multiplication launch uses two lanes per term (part needs 2 * n_terms rows)
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
                                        int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
-// cooperative layout for small batches (bn254_coop.hip): six lanes per proof, the whole Miller loop / final exponentiation in one launch
+// cooperative layout for small batches (bn254_coop12.hip): twelve lanes per proof (one Fp number of every Fp12 value per lane), 39 KB of LDS per
+// wavefront, the whole Miller loop / final exponentiation in one launch.  (The first generation, six lanes per proof, was retired in round 3:
+// 2.95 ms against 2.11 ms at 4096 proofs; DESIGN.md section 5.4 keeps its measurements.)
 #define COOP_T_ELEM 46          // = VE_S2: where the cooperative Miller loop leaves the running G2 point for k_g16_subgroup
-#define COOP_MAX_PROOFS 10240   // six-lane generation: above this the one-proof-per-lane kernels fill the GPU better
-#define COOP12_MAX_PROOFS 40960 // twelve-lane generation: passes of 1024 wavefronts x 5 proofs, 1.98 ms each: 8 passes = 15.9 ms against 17.5 ms of the lane kernels at 40960 (tools/bench_mid.py)
-hipError_t bn254_coop_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
-                                 int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
-hipError_t bn254_coop_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
-hipError_t bn254_coop_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
-                                   int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
-// second generation (bn254_coop12.hip): twelve lanes per proof (one Fp number of every Fp12 value per lane), 39 KB of LDS per wavefront
+#define COOP12_MAX_PROOFS 40960 // passes of 1024 wavefronts x 5 proofs, 1.98 ms each: 8 passes = 15.9 ms against 17.5 ms of the lane kernels at 40960 (tools/bench_mid.py)
 hipError_t bn254_coop12_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
                                    int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
 hipError_t bn254_coop12_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
 hipError_t bn254_coop12_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
                                      int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
-// BN254_COOP_LANES = 6 | 12 selects the generation (default 12)
-int bn254_coop_lanes();
-static inline size_t bn254_coop_max_proofs() { return bn254_coop_lanes() == 12 ? COOP12_MAX_PROOFS : COOP_MAX_PROOFS; }
+static inline size_t bn254_coop_max_proofs() { return COOP12_MAX_PROOFS; }
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

@@ -21,81 +21,11 @@
 // registers between operations.  The host walks the program (LaunchOps below) and enqueues ~210 launches per batch.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
-#include "bn254_vm.h"
+#include "bn254_devws.h"
 #include "bn254_rlc.h"
-#include "bn254_kernels.h"
 
 namespace bn254 {
 
-
-// ---- workspace accessor ----------------------------------------------------------------------------------------------------------
-struct DevWs {
-  __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t row_bytes;  // n * 4: one row per (element, limb)
-  uint32_t voff;       // lane * 4
-  int32_t* lds = nullptr;  // parking space of the operations that fuse two Fp12 products (72 dwords per lane, lane-interleaved)
-  __device__ __forceinline__ void park(int slot, const Fp2& a) const {
-#pragma unroll
-    for (int l = 0; l < BN_NL; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x] = a.c1.v[l]; }
-  }
-  __device__ __forceinline__ Fp2 unpark(int slot) const {
-    Fp2 r;
-#pragma unroll
-    for (int l = 0; l < BN_NL; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + BN_NL + l) * 256 + threadIdx.x]; }
-    BN_SETB(r.c0, 3.0, 0.5); BN_SETB(r.c1, 3.0, 0.5);
-    return r;
-  }
-  __device__ __forceinline__ DevWs(int32_t* base, uint32_t n, uint32_t lane) {
-    uint64_t b = (uint64_t)base;
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-    uint32_t nn = __builtin_amdgcn_readfirstlane(n);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nn * (uint32_t)(G16_WS_ELEMS * 36), 0x00020000);
-    row_bytes = nn * 4u;
-    voff = lane * 4u;
-  }
-  __device__ __forceinline__ Fp ld(int e) const {
-    Fp r;
-    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
-#pragma unroll
-    for (int l = 0; l < BN_NL; l++) r.v[l] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
-    return r;
-  }
-  __device__ __forceinline__ void st(int e, const Fp& a) const {
-    uint32_t eu = __builtin_amdgcn_readfirstlane((uint32_t)e);
-#pragma unroll
-    for (int l = 0; l < BN_NL; l++) __builtin_amdgcn_raw_buffer_store_b32(a.v[l], rsrc, voff, (eu * (uint32_t)BN_NL + (uint32_t)l) * row_bytes, 0);
-  }
-};
-
-// Lanes past the end of the batch get this lane index: lane * 4 lies beyond num_records, so the buffer bounds check makes their
-// loads return 0 and drops their stores.  (They must NOT alias a live proof: different waves run the in-place operations at
-// different times.)
-#define DEAD_LANE (0xffffffffu / 4u)
-
-// uniform (batch-constant) data: limbs stored contiguously per element; the pointer is wave-uniform -> scalar loads
-__device__ __forceinline__ const int32_t* uni_ptr(const int32_t* p) {
-  uint64_t b = (uint64_t)p;
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-  return (const int32_t*)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ Fp uni_ld(const int32_t* p) {
-  Fp r;
-#pragma unroll
-  for (int l = 0; l < BN_NL; l++) r.v[l] = p[l];
-  return r;
-}
-__device__ __forceinline__ Fp2 uni_ld2(const int32_t* p) { Fp2 r; r.c0 = uni_ld(p); r.c1 = uni_ld(p + BN_NL); return r; }
-
-// ---- every VM operation (bn254_vm.h) is its own kernel ------------------------------------------------------------------------
-// The VM programs (vm_miller_program, vm_final_exp_program) are host-compilable: the host walks them and enqueues one launch
-// per operation (~210 per batch, all asynchronous on the sub-batch's stream, so launch overhead hides behind the previous kernel
-// for any batch that matters).  No device-side function calls: each kernel gets exactly the registers it needs and no stack.
-// A wave whose 64 proofs have all failed earlier checks exits at once.
-#define VM_KERNEL_PROLOGUE()                                                                     \
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;                                           \
-  const uint8_t st = status[i < n ? i : n - 1];                                                 \
-  if (__builtin_amdgcn_ballot_w64((st & BN254_ST_PENDING) != 0) == 0) return;                   \
-  DevWs w(ws, n, i < n ? i : DEAD_LANE)
 
 __global__ void __launch_bounds__(256, 2) k_vm_init(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status) {  // f = 1, T = B
   VM_KERNEL_PROLOGUE();
@@ -128,32 +58,6 @@ __global__ void __launch_bounds__(256, 2) k_miller_sqr_dbl_var(int32_t* ws, uint
   VM_KERNEL_PROLOGUE();
   w.lds = park_lds;
   vm_miller_sqr_dbl_var(w, e_t, e, e_px);
-}
-// the whole Miller step of the three pairs (bn254_vm.h::vm_miller_step): doubling steps (with the squaring of f, except the first)
-// and addition steps as two kernels so that each carries only its own G2 formulas
-template <bool DO_SQR>
-__global__ void __launch_bounds__(256, 2) k_miller_step_dbl(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e, int e_pa,
-                                                            const int32_t* __restrict__ entry0, int e_p0, int inf_mask0,
-                                                            const int32_t* __restrict__ entry1, int e_p1, int inf_mask1) {
-  __shared__ int32_t park_lds[72 * 256];
-  VM_KERNEL_PROLOGUE();
-  w.lds = park_lds;
-  FixedLine l0, l1;
-  l0.m = uni_ld2(entry0); l0.c = uni_ld2(entry0 + 2 * BN_NL); l0.xc = uni_ld2(entry0 + 4 * BN_NL);
-  l1.m = uni_ld2(entry1); l1.c = uni_ld2(entry1 + 2 * BN_NL); l1.xc = uni_ld2(entry1 + 4 * BN_NL);
-  vm_miller_step<DO_SQR>(w, 0, e_t, 0, e, e_pa, l0, e_p0, (st & inf_mask0) != 0, l1, e_p1, (st & inf_mask1) != 0);
-}
-__global__ void __launch_bounds__(256, 2) k_miller_step_add(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int kind, int e_t, int e_b, int e, int e_pa,
-                                                            const int32_t* __restrict__ entry0, int e_p0, int inf_mask0,
-                                                            const int32_t* __restrict__ entry1, int e_p1, int inf_mask1) {
-  __shared__ int32_t park_lds[72 * 256];
-  VM_KERNEL_PROLOGUE();
-  w.lds = park_lds;
-  FixedLine l0, l1;
-  l0.m = uni_ld2(entry0); l0.c = uni_ld2(entry0 + 2 * BN_NL); l0.xc = uni_ld2(entry0 + 4 * BN_NL);
-  l1.m = uni_ld2(entry1); l1.c = uni_ld2(entry1 + 2 * BN_NL); l1.xc = uni_ld2(entry1 + 4 * BN_NL);
-  int k = __builtin_amdgcn_readfirstlane(kind);
-  vm_miller_step<false>(w, k < 1 ? 1 : k, e_t, e_b, e, e_pa, l0, e_p0, (st & inf_mask0) != 0, l1, e_p1, (st & inf_mask1) != 0);
 }
 __global__ void __launch_bounds__(256, 2) k_miller_add_var(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int e_t, int e_b, int which, int e, int e_px) {
   VM_KERNEL_PROLOGUE(); vm_miller_add_var(w, e_t, e_b, which, e, e_px);
@@ -865,7 +769,7 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); 
 
 const char* const bn254_kernel_kind_names[KID_COUNT] = {
   "k_g16_prepare", "k_g16_subgroup", "k_vm_init", "k_f12_sqr", "k_f12_mul_line_fixed",
-  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var", "k_miller_step_dbl", "k_miller_step_add", "k_coop_miller_g16"};
+  "k_f12_mul", "k_f12_cyclo_sqr", "k_f12_conj", "k_f12_frob", "k_f12_inv", "k_g16_compare", "k_f12_copy", "k_f12_cyclo_sqr_n", "k_miller_dbl_var", "k_miller_add_var", "k_g16_msm_partial", "k_g16_msm_reduce", "k_f12_mul_line_fixed2", "k_miller_sqr_dbl_var", "k_miller_step_dbl", "k_miller_step_add", "k_coop12_miller_g16", "k_miller_run"};
 struct ProfScope {  // records the event pair around one launch (no-op without a profile or for unselected kinds)
   G16Prof* p; hipStream_t s; int slot;
   ProfScope(G16Prof* p_, int kid, hipStream_t s_) : p(p_), s(s_), slot(-1) {
@@ -885,9 +789,12 @@ struct LaunchOps {
   void miller_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_DBL_VAR, k_miller_dbl_var, ws, n, status, et, e, ep); }
   void miller_step(bool do_sqr, int kind, int st_, int et, int eb, int e, int epa, int ep0, int ep1) {
     const int32_t *t0 = tab[0] + (size_t)st_ * FIXED_LINE_DWORDS, *t1 = tab[1] + (size_t)st_ * FIXED_LINE_DWORDS;
-    if (kind == 0 && do_sqr) BN_LAUNCH(KID_MILLER_STEP_DBL, k_miller_step_dbl<true>, ws, n, status, et, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
-    else if (kind == 0) BN_LAUNCH(KID_MILLER_STEP_DBL, k_miller_step_dbl<false>, ws, n, status, et, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
-    else BN_LAUNCH(KID_MILLER_STEP_ADD, k_miller_step_add, ws, n, status, kind, et, eb, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
+    ProfScope ps_(prof, kind == 0 ? KID_MILLER_STEP_DBL : KID_MILLER_STEP_ADD, s);
+    bn254_launch_miller_step(do_sqr, kind, ws, n, status, grid, s, et, eb, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
+  }
+  void miller_run(int s0, int n_dbl, bool first_sqr, int add_kind, int et, int eb, int e, int epa, int ep0, int ep1) {
+    ProfScope ps_(prof, KID_MILLER_RUN, s);
+    bn254_launch_miller_run(s0, n_dbl, first_sqr, add_kind, ws, n, status, grid, s, et, eb, e, epa, tab[0], ep0, inf_mask[0], tab[1], ep1, inf_mask[1]);
   }
   void miller_sqr_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_SQR_DBL_VAR, k_miller_sqr_dbl_var, ws, n, status, et, e, ep); }
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
@@ -913,17 +820,13 @@ static const uint8_t* step_kinds_host() {
   return g_step_kinds;
 }
 
-int bn254_coop_lanes() {
-  static const int lanes = [] { const char* e = getenv("BN254_COOP_LANES"); return (e && atoi(e) == 6) ? 6 : 12; }();
-  return lanes;
-}
 hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* ev /* 5 events or nullptr */, G16Prof* prof) {
   unsigned grid = grid_for(a.n);
   uint32_t n = (uint32_t)a.n;
   if (ev) (void)hipEventRecord(ev[0], s);
   const bool wide = a.msm_part != nullptr && a.inputs_match_key && a.n_public > G16_WIDE_MSM_MIN_INPUTS;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
-  // cooperative path (small batches): the public-input MSM moves into the cooperative kernel (six lanes per proof, L kept projective), so
+  // cooperative path (small batches): the public-input MSM moves into the cooperative kernel (twelve lanes per proof, L kept projective), so
   // k_g16_prepare stops after C; keys with many inputs keep their wide MSM kernels and hand L over through the workspace.  A key with more
   // than G16_WIDE_MSM_MIN_INPUTS inputs but no partial-sum buffer (wrong input count) takes the one-proof-per-lane path.
   const bool coop = coop_on && !a.part_of_larger && a.n <= bn254_coop_max_proofs() && (wide || a.n_public <= G16_WIDE_MSM_MIN_INPUTS);
@@ -952,9 +855,9 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   }
   if (ev) (void)hipEventRecord(ev[1], s);
   if (coop) {
-    // small batch: cooperative layout (bn254_coop.hip): public-input MSM, Miller loop of the three pairs and final exponentiation in ONE launch
+    // small batch: cooperative layout (bn254_coop12.hip): public-input MSM, Miller loop of the three pairs and final exponentiation in ONE launch
     hipError_t e;
-    { ProfScope ps_(prof, KID_COOP_G16, s); e = (bn254_coop_lanes() == 12 ? bn254_coop12_miller_g16 : bn254_coop_miller_g16)(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s); }
+    { ProfScope ps_(prof, KID_COOP_G16, s); e = bn254_coop12_miller_g16(a.ws, a.status, a.n, a.gtab, a.dtab, a.inputs, a.n_public, a.inputs_match_key, a.msm_tab, a.k0, wide ? 1 : 0, 1, s); }
     if (e != hipSuccess) return e;
     if (ev) { (void)hipEventRecord(ev[2], s); }
     BN_LAUNCH(KID_SUBGROUP, k_g16_subgroup, n, a.ws, a.status, a.inputs_match_key, (int)COOP_T_ELEM);
@@ -986,7 +889,10 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     (void)hipStreamWaitEvent(s, a.split_ev[1], 0); (void)hipStreamWaitEvent(s, a.split_ev[2], 0);
     ops.f12_mul(VE_F, VE_F, VE_S1); ops.f12_mul(VE_F, VE_F, VE_S2);
   } else {
-    vm_miller_program(ops, step_kinds_host(), true);
+    // BN254_MILLER_RUNS=0: one launch per step (88) instead of one per run of steps (24)
+    static const bool runs = [] { const char* e = getenv("BN254_MILLER_RUNS"); return !e || atoi(e) != 0; }();
+    if (runs) vm_miller_program_runs(ops, step_kinds_host());
+    else vm_miller_program(ops, step_kinds_host(), true);
   }
   if (ev) (void)hipEventRecord(ev[2], s);
   // r-torsion test of B from the loop's final point; resolves the deferred statuses (C errors, input count)
@@ -1166,8 +1072,8 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
   if (coop_on && n <= bn254_coop_max_proofs()) {
-    // small batch: the cooperative layout (bn254_coop.hip), Miller loop of the two pairs and final exponentiation in ONE launch
-    hipError_t e = (bn254_coop_lanes() == 12 ? bn254_coop12_miller_fixed : bn254_coop_miller_fixed)(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
+    // small batch: the cooperative layout (bn254_coop12.hip), Miller loop of the two pairs and final exponentiation in ONE launch
+    hipError_t e = bn254_coop12_miller_fixed(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
     if (e != hipSuccess) return e;
     BN_LAUNCH(KID_COMPARE, k_g16_compare, ws, nn, status, target_one, reject_code);
     return hipGetLastError();

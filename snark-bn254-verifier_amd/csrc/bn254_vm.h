@@ -243,6 +243,108 @@ BN_HD void vm_miller_step(W& w, int kind, int e_t, int e_b, int e, int e_pa, con
   }
 }
 
+// ---- a RUN of Miller steps in one operation: n_dbl consecutive doubling steps, then optionally one addition step -------------------------------
+// f is loaded once, travels "in flight" through the whole run (k0..k3 parked -- LDS on the GPU -- k4, k5 in registers: the state the stages of
+// vm_miller_step hand each other) and is stored once; the line tables of step s come from `lines.get(t, s)` (scalar loads indexed by the step on
+// the GPU).  The operation sequence per step is that of vm_miller_step; only the round trips of f through the workspace between the steps of a run
+// are gone (864 of a step's 1512 bytes per proof) and with them the launch boundaries.  The running G2 point still goes through the workspace.
+template <class W> BN_HD void mf_load(W& w, int e, Fp2& f4, Fp2& f5) {
+  w.park(0, vld2(w, e)); w.park(1, vld2(w, e + 2)); w.park(2, vld2(w, e + 4)); w.park(3, vld2(w, e + 6));
+  f4 = vld2(w, e + 8); f5 = vld2(w, e + 10);
+}
+template <class W> BN_HD void mf_store(W& w, int e, const Fp2& f4, const Fp2& f5) {
+  vst2(w, e, w.unpark(0)); vst2(w, e + 2, w.unpark(1)); vst2(w, e + 4, w.unpark(2)); vst2(w, e + 6, w.unpark(3));
+  vst2(w, e + 8, f4); vst2(w, e + 10, f5);
+}
+template <class W> BN_HD void mf_sqr(W& w, Fp2& f4, Fp2& f5) {
+  Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3), k4 = f4, k5 = f5;
+  Fp2 x3 = fp2_mul_xi(k3), x4 = fp2_mul_xi(k4), x5 = fp2_mul_xi(k5);
+  w.park(0, fp2_dotp(pp(k0, k0), pp2(k1, x5), pp2(k2, x4), pp(k3, x3)));
+  w.park(1, fp2_dotp(pp2(k0, k1), pp2(k2, x5), pp2(k3, x4)));
+  w.park(2, fp2_dotp(pp2(k0, k2), pp(k1, k1), pp2(k3, x5), pp(k4, x4)));
+  w.park(3, fp2_dotp(pp2(k0, k3), pp2(k1, k2), pp2(k4, x5)));
+  Fp2 n4 = fp2_dotp(pp2(k0, k4), pp2(k1, k3), pp(k2, k2), pp(k5, x5));
+  f5 = fp2_dotp(pp2(k0, k5), pp2(k1, k4), pp2(k2, k3));
+  f4 = n4;
+}
+template <class W> BN_HD G2Line mf_g2(W& w, int kind, int e_t, int e_b) {
+  G2Line l;
+  G2Proj t; t.x = vld2(w, e_t); t.y = vld2(w, e_t + 2); t.z = vld2(w, e_t + 4);
+  if (kind == 0) {
+    l = g2_double_step(t);
+  } else {
+    G2Aff q; q.x = vld2(w, e_b); q.y = vld2(w, e_b + 2);
+    if (kind == 2) q = g2_neg(q);
+    else if (kind == 3) q = g2_psi_affine(q);
+    else if (kind == 4) q = g2_neg(g2_psi2_affine(q));
+    l = g2_add_step(t, q);
+  }
+  vst2(w, e_t, t.x); vst2(w, e_t + 2, t.y); vst2(w, e_t + 4, t.z);
+  return l;
+}
+template <class W> BN_HD void mf_line_var(W& w, const G2Line& l, int e_pa, Fp2& f4, Fp2& f5) {
+  Fp px = w.ld(e_pa), py = w.ld(e_pa + 1);
+  Fp2 d0 = fp2_mul_fp(l.r0, py), d3 = fp2_mul_fp(l.r1, px), d4 = l.r2;
+  Fp2 x3 = fp2_mul_xi(d3), x4 = fp2_mul_xi(d4);
+  Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3), k4 = f4, k5 = f5;
+  w.park(0, fp2_dotp(pp(d0, k0), pp(x3, k5), pp(x4, k3)));
+  w.park(1, fp2_dotp(pp(d0, k1), pp(d3, k0), pp(x4, k4)));
+  w.park(2, fp2_dotp(pp(d0, k2), pp(d3, k1), pp(x4, k5)));
+  w.park(3, fp2_dotp(pp(d0, k3), pp(d3, k2), pp(d4, k0)));
+  Fp2 n4 = fp2_dotp(pp(d0, k4), pp(d3, k3), pp(d4, k1));
+  f5 = fp2_dotp(pp(d0, k5), pp(d3, k4), pp(d4, k2));
+  f4 = n4;
+}
+template <class W> BN_HD void mf_line_fixed(W& w, const FixedLine& l0, int e_p0, bool inf0, Fp2& f4, Fp2& f5) {   // plain dot products
+  Fp px = w.ld(e_p0), d0 = w.ld(e_p0 + 1);
+  Fp2 d3 = fp2_mul_fp(l0.m, px);
+  Fp2 x3 = fp2_mul_xi(d3);
+  const Fp2 &d4 = l0.c, &x4 = l0.xc;
+  Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3), k4 = f4, k5 = f5;
+  w.park(0, fp2_select(inf0, k0, fp2_dot_line(d0, k0, x3, k5, x4, k3)));
+  w.park(1, fp2_select(inf0, k1, fp2_dot_line(d0, k1, d3, k0, x4, k4)));
+  w.park(2, fp2_select(inf0, k2, fp2_dot_line(d0, k2, d3, k1, x4, k5)));
+  w.park(3, fp2_select(inf0, k3, fp2_dot_line(d0, k3, d3, k2, d4, k0)));
+  f4 = fp2_select(inf0, k4, fp2_dot_line(d0, k4, d3, k3, d4, k1));
+  f5 = fp2_select(inf0, k5, fp2_dot_line(d0, k5, d3, k4, d4, k2));
+}
+template <class W> BN_HD void mf_line_fixed_k(W& w, const FixedLine& l1, int e_p1, bool inf1, Fp2& f4, Fp2& f5) {   // Karatsuba dot products
+  Fp px = w.ld(e_p1), d0 = w.ld(e_p1 + 1);
+  Fp2 d3 = fp2_mul_fp(l1.m, px);
+  Fp2 x3 = fp2_mul_xi(d3);
+  const Fp2 &d4 = l1.c, &x4 = l1.xc;
+  Fp2 k0 = w.unpark(0), k1 = w.unpark(1), k2 = w.unpark(2), k3 = w.unpark(3);
+  const Fp2 k4 = f4, k5 = f5;
+  w.park(0, fp2_select(inf1, k0, fp2_dotk(kfp(k0, d0), kp(x3, k5), kp(x4, k3))));
+  w.park(1, fp2_select(inf1, k1, fp2_dotk(kfp(k1, d0), kp(d3, k0), kp(x4, k4))));
+  w.park(2, fp2_select(inf1, k2, fp2_dotk(kfp(k2, d0), kp(d3, k1), kp(x4, k5))));
+  w.park(3, fp2_select(inf1, k3, fp2_dotk(kfp(k3, d0), kp(d3, k2), kp(d4, k0))));
+  f4 = fp2_select(inf1, k4, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1)));
+  f5 = fp2_select(inf1, k5, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2)));
+}
+template <class W, class LINES>
+BN_HD void vm_miller_run(W& w, const LINES& lines, int s0, int n_dbl, bool first_sqr, int add_kind, int e_t, int e_b, int e, int e_pa, int e_p0, bool inf0,
+                         int e_p1, bool inf1) {
+  Fp2 f4, f5;
+  mf_load(w, e, f4, f5);
+  int s = s0;
+  for (int it = 0; it < n_dbl; it++, s++) {
+    if (it != 0 || first_sqr) mf_sqr(w, f4, f5);
+    BN_SCHED_FENCE();
+    { G2Line l = mf_g2(w, 0, e_t, e_b); mf_line_var(w, l, e_pa, f4, f5); }
+    BN_SCHED_FENCE();
+    mf_line_fixed(w, lines.get(0, s), e_p0, inf0, f4, f5);
+    mf_line_fixed_k(w, lines.get(1, s), e_p1, inf1, f4, f5);
+  }
+  if (add_kind != 0) {
+    { G2Line l = mf_g2(w, add_kind, e_t, e_b); mf_line_var(w, l, e_pa, f4, f5); }
+    BN_SCHED_FENCE();
+    mf_line_fixed(w, lines.get(0, s), e_p0, inf0, f4, f5);
+    mf_line_fixed_k(w, lines.get(1, s), e_p1, inf1, f4, f5);
+  }
+  mf_store(w, e, f4, f5);
+}
+
 // ---- r-torsion test of B from the point the Miller loop has already computed ----------------------------------------------------------
 // After vm_miller_program the running point is T = [6u+2]B + psi(B) - psi^2(B).  For B on the twist E'(Fp2):
 //     B in G2  <=>  T == -psi^3(B)          (T finite)
@@ -398,6 +500,20 @@ BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS
     }
     if (kind == 0) { if (s != 0) ops.miller_sqr_dbl_var(VE_T, VE_F, VE_AX); else ops.miller_dbl_var(VE_T, VE_F, VE_AX); }
     else ops.miller_add_var(VE_T, VE_B, kind - 1, VE_F, VE_AX);
+  }
+}
+// the same loop as RUNS: every maximal sequence of doubling steps together with the addition step that follows it is one operation
+// (ops.miller_run(first step, doublings, squaring in the first doubling?, kind of the addition or 0)): 24 operations instead of 88
+template <class OPS>
+BN_HD void vm_miller_program_runs(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS, uniform */) {
+  int s = 0;
+  while (s < BN_ATE_STEPS) {
+    const int s0 = s;
+    int n_dbl = 0;
+    while (s < BN_ATE_STEPS && step_kinds[s] == 0) { n_dbl++; s++; }
+    int add_kind = 0;
+    if (s < BN_ATE_STEPS) { add_kind = step_kinds[s]; s++; }
+    ops.miller_run(s0, n_dbl, s0 != 0, add_kind, VE_T, VE_B, VE_F, VE_AX, VE_LX, VE_CX);
   }
 }
 // x^u on the cyclotomic subgroup: dst <- src^u (dst != src), width-4 signed windows of u (BN_U_W4: digits +-1, +-3, +-5, +-7).

@@ -25,7 +25,6 @@ find $O -name "*kernel_trace.csv" -size +30M -delete
 python tools/bench_rlc.py --batch-log2 20 --steps 3 --invalid-every 0,256,16 > $O/rlc.txt 2> $O/rlc.err || fail rlc $O/rlc.err
 cat $O/rlc.txt
 python tools/bench_small.py > $O/small_coop12.txt 2> $O/small_coop12.err || fail small $O/small_coop12.err
-BN254_COOP_LANES=6 python tools/bench_small.py > $O/small_coop.txt 2> $O/small_coop.err || fail small6 $O/small_coop.err
 BN254_COOP=0 python tools/bench_small.py > $O/small_lane.txt 2> $O/small_lane.err || fail small_lane $O/small_lane.err
 grep 4096 $O/small_coop12.txt $O/small_coop.txt $O/small_lane.txt
 # batch 4096 (BASELINE configs[1]) under the profiler: kernel trace, then SQ counters in their own passes

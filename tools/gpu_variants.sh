@@ -5,7 +5,6 @@ mkdir -p gpurun_out
 run() { tag=$1; shift; env "$@" timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/variants_pytest_$tag.txt 2>&1; rc=$?; echo "$tag rc=$rc $(tail -1 gpurun_out/variants_pytest_$tag.txt)"; grep -q -i "access fault" gpurun_out/variants_pytest_$tag.txt && exit 1; [ $rc -eq 0 ] || exit $rc; }
 if [ -z "$ONLY_RLC" ]; then
 run nocoop BN254_COOP=0
-run coop6 BN254_COOP_LANES=6
 run streams1 BN254_STREAMS=1
 run streams4 BN254_STREAMS=4
 run msm_plain BN254_MSM_SPLIT=0 BN254_MSM_W2=0
