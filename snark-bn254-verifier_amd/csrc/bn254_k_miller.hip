@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(256, 2) k_miller_step_add(int32_t* ws, uint32_
   vm_miller_step<false>(w, k < 1 ? 1 : k, e_t, e_b, e, e_pa, l0, e_p0, (st & inf_mask0) != 0, l1, e_p1, (st & inf_mask1) != 0);
 }
 
-// A RUN of steps in one launch (bn254_vm.h::vm_miller_run): n_dbl doubling steps from step s0 on, then the addition step that follows them
-// (add_kind 1..4, 0: none).  f is loaded and stored once per run; the line-table entries of the step come from scalar loads indexed by the step.
+// A RUN of steps in one launch (bn254_vm.h::vm_miller_run): steps [s_begin, s_end) of the loop -- by default the WHOLE loop.  f is loaded and stored
+// once per run and travels in LDS + registers in between; the kind of a step and its line-table entries come from scalar loads indexed by the step.
 struct DevLines {
   const int32_t* tab0; const int32_t* tab1;
   __device__ __forceinline__ FixedLine get(int t, int s) const {
@@ -43,23 +43,28 @@ struct DevLines {
     return l;
   }
 };
-__global__ void __launch_bounds__(256, 2) k_miller_run(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int s0, int n_dbl, int first_sqr, int add_kind,
+struct DevKinds {   // the step table (88 entries, 0..4), two steps per byte, by value in the kernel arguments
+  MillerKinds k;
+  __device__ __forceinline__ int get(int s) const { return __builtin_amdgcn_readfirstlane((k.nib[s >> 1] >> ((s & 1) * 4)) & 15); }
+};
+__global__ void __launch_bounds__(256, 2) k_miller_run(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, MillerKinds kinds, int s_begin, int s_end,
                                                        int e_t, int e_b, int e, int e_pa, const int32_t* __restrict__ tab0, int e_p0, int inf_mask0,
                                                        const int32_t* __restrict__ tab1, int e_p1, int inf_mask1) {
   __shared__ int32_t park_lds[72 * 256];
   VM_KERNEL_PROLOGUE();
   w.lds = park_lds;
   DevLines lines{uni_ptr(tab0), uni_ptr(tab1)};
-  vm_miller_run(w, lines, __builtin_amdgcn_readfirstlane(s0), __builtin_amdgcn_readfirstlane(n_dbl), __builtin_amdgcn_readfirstlane(first_sqr) != 0,
-                __builtin_amdgcn_readfirstlane(add_kind), e_t, e_b, e, e_pa, e_p0, (st & inf_mask0) != 0, e_p1, (st & inf_mask1) != 0);
+  DevKinds dk{kinds};
+  vm_miller_run(w, lines, dk, __builtin_amdgcn_readfirstlane(s_begin), __builtin_amdgcn_readfirstlane(s_end), e_t, e_b, e, e_pa, e_p0, (st & inf_mask0) != 0,
+                e_p1, (st & inf_mask1) != 0);
 }
 
 }  // namespace bn254
 
 using namespace bn254;
-void bn254_launch_miller_run(int s0, int n_dbl, bool first_sqr, int add_kind, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
+void bn254_launch_miller_run(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
                              int e, int epa, const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1) {
-  hipLaunchKernelGGL(k_miller_run, dim3(grid), dim3(256), 0, s, ws, n, status, s0, n_dbl, first_sqr ? 1 : 0, add_kind, et, eb, e, epa, tab0, ep0, inf0, tab1, ep1, inf1);
+  hipLaunchKernelGGL(k_miller_run, dim3(grid), dim3(256), 0, s, ws, n, status, kinds, s_begin, s_end, et, eb, e, epa, tab0, ep0, inf0, tab1, ep1, inf1);
 }
 void bn254_launch_miller_step(bool do_sqr, int kind, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb, int e, int epa,
                               const int32_t* t0, int ep0, int inf0, const int32_t* t1, int ep1, int inf1) {

@@ -90,8 +90,9 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
 // bn254_k_miller.hip: one whole step of the shared Miller loop (kind 0: doubling, with the squaring of f when do_sqr; 1..4: additions)
 void bn254_launch_miller_step(bool do_sqr, int kind, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb, int e, int epa,
                               const int32_t* t0, int ep0, int inf0, const int32_t* t1, int ep1, int inf1);
-// a run of steps in one launch (bn254_vm.h::vm_miller_run): n_dbl doublings from step s0 (tab0 / tab1: the WHOLE line tables), then the addition add_kind (0: none)
-void bn254_launch_miller_run(int s0, int n_dbl, bool first_sqr, int add_kind, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
+// a run of steps [s_begin, s_end) in one launch (bn254_vm.h::vm_miller_run; tab0 / tab1: the WHOLE line tables); kinds: the step table, a nibble per step
+struct MillerKinds { uint8_t nib[44]; };
+void bn254_launch_miller_run(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
                              int e, int epa, const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1);
 // RLC batch mode (bn254_rlc.h): one launch part = n <= G16_MAX_LAUNCH proofs forming plan.groups groups
 #include "bn254_rlc_plan.h"

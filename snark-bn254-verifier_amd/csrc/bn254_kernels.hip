@@ -21,6 +21,7 @@
 // registers between operations.  The host walks the program (LaunchOps below) and enqueues ~210 launches per batch.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include "bn254_devws.h"
 #include "bn254_rlc.h"
 
@@ -792,9 +793,10 @@ struct LaunchOps {
     ProfScope ps_(prof, kind == 0 ? KID_MILLER_STEP_DBL : KID_MILLER_STEP_ADD, s);
     bn254_launch_miller_step(do_sqr, kind, ws, n, status, grid, s, et, eb, e, epa, t0, ep0, inf_mask[0], t1, ep1, inf_mask[1]);
   }
-  void miller_run(int s0, int n_dbl, bool first_sqr, int add_kind, int et, int eb, int e, int epa, int ep0, int ep1) {
+  void miller_run(int s_begin, int s_end, int et, int eb, int e, int epa, int ep0, int ep1) {
+    static const MillerKinds kinds = [] { MillerKinds k; memset(&k, 0, sizeof k); for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) k.nib[st_ >> 1] |= (uint8_t)(miller_step_kind(st_) << ((st_ & 1) * 4)); return k; }();
     ProfScope ps_(prof, KID_MILLER_RUN, s);
-    bn254_launch_miller_run(s0, n_dbl, first_sqr, add_kind, ws, n, status, grid, s, et, eb, e, epa, tab[0], ep0, inf_mask[0], tab[1], ep1, inf_mask[1]);
+    bn254_launch_miller_run(kinds, s_begin, s_end, ws, n, status, grid, s, et, eb, e, epa, tab[0], ep0, inf_mask[0], tab[1], ep1, inf_mask[1]);
   }
   void miller_sqr_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_SQR_DBL_VAR, k_miller_sqr_dbl_var, ws, n, status, et, e, ep); }
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
@@ -889,9 +891,10 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     (void)hipStreamWaitEvent(s, a.split_ev[1], 0); (void)hipStreamWaitEvent(s, a.split_ev[2], 0);
     ops.f12_mul(VE_F, VE_F, VE_S1); ops.f12_mul(VE_F, VE_F, VE_S2);
   } else {
-    // BN254_MILLER_RUNS=0: one launch per step (88) instead of one per run of steps (24)
-    static const bool runs = [] { const char* e = getenv("BN254_MILLER_RUNS"); return !e || atoi(e) != 0; }();
-    if (runs) vm_miller_program_runs(ops, step_kinds_host());
+    // BN254_MILLER_RUN_STEPS: steps of the Miller loop per launch (default 88: the whole loop is ONE launch, f never leaves LDS + registers);
+    // 0: the one-launch-per-step kernels (k_miller_step_dbl / _add)
+    static const int run_steps = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : BN_ATE_STEPS; return v < 0 ? 0 : v; }();
+    if (run_steps) vm_miller_program_runs(ops, run_steps);
     else vm_miller_program(ops, step_kinds_host(), true);
   }
   if (ev) (void)hipEventRecord(ev[2], s);

@@ -322,22 +322,25 @@ template <class W> BN_HD void mf_line_fixed_k(W& w, const FixedLine& l1, int e_p
   f4 = fp2_select(inf1, k4, fp2_dotk(kfp(k4, d0), kp(d3, k3), kp(d4, k1)));
   f5 = fp2_select(inf1, k5, fp2_dotk(kfp(k5, d0), kp(d3, k4), kp(d4, k2)));
 }
-template <class W, class LINES>
-BN_HD void vm_miller_run(W& w, const LINES& lines, int s0, int n_dbl, bool first_sqr, int add_kind, int e_t, int e_b, int e, int e_pa, int e_p0, bool inf0,
-                         int e_p1, bool inf1) {
+template <class W, class LINES, class KINDS>
+BN_HD void vm_miller_run(W& w, const LINES& lines, const KINDS& kinds, int s_begin, int s_end, int e_t, int e_b, int e, int e_pa, int e_p0, bool inf0, int e_p1, bool inf1) {
+  // steps [s_begin, s_end) of the loop; kinds.get(s): 0 doubling (with the squaring of f except in step 0), 1..4 addition of +B, -B, psi(B), -psi^2(B).
+  // The doubling and the addition side of the (wave-uniform) branch each carry their own G2 formulas AND their own variable-line product, so that
+  // the only state that crosses the join is f in flight; the two key-side line products are shared.  (Joining right after the G2 step instead --
+  // the line and the new point as merged values -- costs 165 spilled registers.)
   Fp2 f4, f5;
   mf_load(w, e, f4, f5);
-  int s = s0;
-  for (int it = 0; it < n_dbl; it++, s++) {
-    if (it != 0 || first_sqr) mf_sqr(w, f4, f5);
-    BN_SCHED_FENCE();
-    { G2Line l = mf_g2(w, 0, e_t, e_b); mf_line_var(w, l, e_pa, f4, f5); }
-    BN_SCHED_FENCE();
-    mf_line_fixed(w, lines.get(0, s), e_p0, inf0, f4, f5);
-    mf_line_fixed_k(w, lines.get(1, s), e_p1, inf1, f4, f5);
-  }
-  if (add_kind != 0) {
-    { G2Line l = mf_g2(w, add_kind, e_t, e_b); mf_line_var(w, l, e_pa, f4, f5); }
+  for (int s = s_begin; s < s_end; s++) {
+    const int kind = kinds.get(s);
+    if (kind == 0) {
+      if (s != 0) mf_sqr(w, f4, f5);
+      BN_SCHED_FENCE();
+      G2Line l = mf_g2(w, 0, e_t, e_b);
+      mf_line_var(w, l, e_pa, f4, f5);
+    } else {
+      G2Line l = mf_g2(w, kind, e_t, e_b);
+      mf_line_var(w, l, e_pa, f4, f5);
+    }
     BN_SCHED_FENCE();
     mf_line_fixed(w, lines.get(0, s), e_p0, inf0, f4, f5);
     mf_line_fixed_k(w, lines.get(1, s), e_p1, inf1, f4, f5);
@@ -502,19 +505,13 @@ BN_HD void vm_miller_program(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS
     else ops.miller_add_var(VE_T, VE_B, kind - 1, VE_F, VE_AX);
   }
 }
-// the same loop as RUNS: every maximal sequence of doubling steps together with the addition step that follows it is one operation
-// (ops.miller_run(first step, doublings, squaring in the first doubling?, kind of the addition or 0)): 24 operations instead of 88
+// the same loop as RUNS of consecutive steps, one operation each (ops.miller_run(first step, one past the last step)): `per_run` steps per
+// operation (BN_ATE_STEPS: the whole loop is ONE operation)
 template <class OPS>
-BN_HD void vm_miller_program_runs(OPS& ops, const uint8_t* step_kinds /* BN_ATE_STEPS, uniform */) {
-  int s = 0;
-  while (s < BN_ATE_STEPS) {
-    const int s0 = s;
-    int n_dbl = 0;
-    while (s < BN_ATE_STEPS && step_kinds[s] == 0) { n_dbl++; s++; }
-    int add_kind = 0;
-    if (s < BN_ATE_STEPS) { add_kind = step_kinds[s]; s++; }
-    ops.miller_run(s0, n_dbl, s0 != 0, add_kind, VE_T, VE_B, VE_F, VE_AX, VE_LX, VE_CX);
-  }
+BN_HD void vm_miller_program_runs(OPS& ops, int per_run) {
+  if (per_run < 1) per_run = 1;
+  for (int s = 0; s < BN_ATE_STEPS; s += per_run)
+    ops.miller_run(s, s + per_run < BN_ATE_STEPS ? s + per_run : BN_ATE_STEPS, VE_T, VE_B, VE_F, VE_AX, VE_LX, VE_CX);
 }
 // x^u on the cyclotomic subgroup: dst <- src^u (dst != src), width-4 signed windows of u (BN_U_W4: digits +-1, +-3, +-5, +-7).
 // x^3, x^5, x^7 go to VE_P3/P5/P7; a negative digit multiplies by the conjugate (= inverse) of the table entry.

@@ -244,6 +244,7 @@ def test_latency_mode_program_matches(hostsim, O):
         exp = O.pairing(pa + pc, qb + qd) if l_inf else O.pairing(pa + pl + pc, qb + qg + qd)
         assert bytes(o2) == exp
         # the run form of the Miller loop (k_miller_run: runs of doubling steps + the following addition step as one operation)
-        o3 = (C.c_uint8 * 384)()
-        assert hs.hs_vm_pairing3(o3, pa, qb, pl, qg, pc, qd, l_inf | 2) == 1
-        assert bytes(o3) == exp
+        for per_run in (0, 1, 7, 22):            # the whole loop as one operation; one, seven, twenty-two steps per operation
+            o3 = (C.c_uint8 * 384)()
+            assert hs.hs_vm_pairing3(o3, pa, qb, pl, qg, pc, qd, l_inf | 2 | (per_run << 2)) == 1
+            assert bytes(o3) == exp, per_run

@@ -397,6 +397,28 @@ def main():
         else:
             for i, e in enumerate(es):
                 kernels["%s#%d" % (name, i)] = e
+    if "k_miller_run" in kernels and "k_miller_step_dbl" in kernels and "k_miller_step_add" in kernels:
+        # the whole Miller loop in one launch (bn254_vm.h::vm_miller_run): the same field operations as the one-launch-per-step kernels -- 64 doubling
+        # steps with the squaring of f, the first one without, 23 additions (2 of them with a psi map) -- inside one loop with a wave-uniform branch per
+        # step kind; the loads / stores of f between the steps are what is gone, and they carry no multiply-adds.  The sum is CHECKED against the
+        # counter: profiles/miller_run_pmc_counts.json holds SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU per wavefront from a rocprofv3 --pmc pass.
+        run = kernels["k_miller_run"]
+        a, b = sorted(inst["k_miller_step_dbl"], key=lambda e: -e["static_mads"])
+        add = kernels["k_miller_step_add"]
+        total = 64 * a["mads_per_proof_launch"] + b["mads_per_proof_launch"] + 23 * add["mads_per_proof_launch"]
+        run["mads_per_proof_launch"] = total
+        run["mads_per_proof_batch"] = total
+        run["unmodelled"] = []
+        run["model"] = ("whole Miller loop in one launch = 64 doubling steps with the squaring of f (%d multiply-adds, k_miller_step_dbl<true>) + the first without (%d) + "
+                        "23 addition steps (%.1f on average, k_miller_step_add); static multiply-adds of the loop body with both branches: %d"
+                        % (a["static_mads"], b["static_mads"], add["mads_per_proof_launch"], run["static_mads"]))
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "miller_run_pmc_counts.json")))
+            # per wavefront (64 proofs = one lane each): the multiply-adds are a known share of the 64-bit integer instructions of the step kernels
+            run["pmc_check"] = {"SQ_INSTS_VALU_per_wavefront": pmc["SQ_INSTS_VALU"], "SQ_INSTS_VALU_INT64_per_wavefront": pmc["SQ_INSTS_VALU_INT64"],
+                                "model_mads_per_lane": total, "note": pmc.get("note", "")}
+        except Exception:
+            pass
     if "k_f12_cyclo_sqr_n" in kernels:
         e = kernels["k_f12_cyclo_sqr_n"]
         e["mads_per_proof_batch"] = e["mads_per_proof_launch"] * 39     # all 39 launches of a batch together (exact: 186 squarings)
