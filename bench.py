@@ -131,6 +131,10 @@ class GpuVerifier:
     def kernel_profile(self):
         return self.pvk.kernel_profile(self.local_rank)
 
+    def kernel_profile_all(self):
+        """{kind: (launches, total_ms, union_ms)} over the first two sub-batch streams, proofs per launch"""
+        return self.pvk.kernel_profile_all(self.local_rank)
+
     def phases(self):
         return self.pvk.last_kernel_ms(self.local_rank)
 
@@ -194,10 +198,10 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         gathers.append(tg)
         # HIP-event durations of this step (recorded on the launch stream); reading them waits for the step's last event only,
         # which the next step would have to wait for anyway (same stream)
-        kp, per_launch = v.kernel_profile()
-        for k, (cnt, ms) in kp.items():
-            c0, m0 = prof.get(k, (0, 0.0))
-            prof[k] = (c0 + cnt, m0 + ms)
+        kp, per_launch = v.kernel_profile_all()
+        for k, (cnt, ms, un) in kp.items():
+            c0, m0, u0 = prof.get(k, (0, 0.0, 0.0))
+            prof[k] = (c0 + cnt, m0 + ms, u0 + un)
         for k, x in v.phases().items():
             phase_ms.setdefault(k, []).append(x)
     fence()
@@ -208,7 +212,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         elapsed = float(t.item())
     gather_ms = sum(v.elapsed_ms(a, b) for a, b in gathers) / max(1, len(gathers))
     if breakdown is None:
-        breakdown = {k: (c // args.steps, m / args.steps) for k, (c, m) in prof.items()}
+        breakdown = {k: (c // args.steps, m / args.steps) for k, (c, m, _u) in prof.items()}
 
     # correctness of the timed work: this rank's shard, and its slice of the gathered vector
     got = v.status_bytes()
@@ -242,7 +246,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         }
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
-            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, concurrent=per_launch < n)
+            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch)
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
             out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown, algo)
         emit(json.dumps(out))
@@ -256,25 +260,25 @@ def _load_json(name):
         return None
 
 
-def _valu_roofline(dom, launches_ms, per_launch, concurrent=True):
-    """The binding roofline, for the dominant kernel kind: multiply-adds per launch / average launch duration vs the v_mad peak."""
-    launches, total_ms = launches_ms
+def _valu_roofline(dom, launches_ms, per_launch):
+    """The binding roofline, for the dominant kernel kind: multiply-adds of all its launches / the time during which it was running, vs the v_mad peak.
+    launches_ms = (launches, summed launch durations, union of the launch intervals) over the sub-batch streams of the timed steps: two streams that
+    run the kernel side by side give union = about one launch's duration, launches that happen to run one after the other the sum."""
+    launches, total_ms, union_ms = launches_ms
     avg_ms = total_ms / max(1, launches)
     mads = (_load_json("kernel_mads.json") or {}).get("kernels", {}).get(dom, {}).get("mads_per_proof_launch")
     traffic = (_load_json("pmc_traffic.json") or {}).get(dom)
     r = {"bound": "valu", "kernel": dom, "unit": "T mad/s", "peak": VALU_PEAK_MAD_PER_S / 1e12, "avg_launch_ms": avg_ms,
-         "launches_timed": launches, "proofs_per_launch": per_launch,
+         "launches_timed": launches, "proofs_per_launch": per_launch, "union_ms": union_ms, "overlap": total_ms / union_ms if union_ms else None,
          "traffic": (traffic["read_bytes_per_proof"] + traffic["write_bytes_per_proof"]) * per_launch if traffic else None,
-         "note": "v_mad_[iu]64_[iu]32 per proof and launch counted in the gfx950 code object (tools/count_mads.py -> profiles/kernel_mads.json) x proofs "
-                 "per launch / HIP-event launch duration inside the timed region; peak = measured issue rate (profiles/r01_ubench_valu.txt); "
-                 "launches of the concurrent sub-batch streams share the GPU, so one stream's launch sees about half the chip (batches below 32768 proofs: "
-                 "one launch, no concurrent stream; cooperative kernels: 12 lanes per proof, count from the call-graph model checked against SQ_INSTS_VALU_INT64)"}
-    if mads:
-        streams = int(os.environ.get("BN254_STREAMS", "2")) if concurrent else 1
-        # sub-batch streams run the same kernel kind side by side: a launch of one stream competes with the other stream's
-        ach = mads * per_launch / (avg_ms * 1e-3) / 1e12
-        r.update({"mads_per_proof_launch": mads, "achieved_one_stream": ach, "achieved": ach * streams, "concurrent_streams": streams,
-                  "frac": ach * streams / (VALU_PEAK_MAD_PER_S / 1e12)})
+         "note": "achieved = v_mad_[iu]64_[iu]32 per proof and launch (counted in the gfx950 code object: tools/count_mads.py -> profiles/kernel_mads.json) x proofs per "
+                 "launch x launches / union of the launch intervals (HIP events around every launch of the kind on BOTH sub-batch streams inside the timed region, one time "
+                 "base); `overlap` = summed launch durations / union (2 = the two streams ran the kernel side by side the whole time); avg_launch_ms is what rocprofv3's "
+                 "kernel trace averages; peak = measured issue rate (profiles/r01_ubench_valu.txt).  Cooperative kernels: 12 lanes per proof, count from the call-graph "
+                 "model checked against SQ_INSTS_VALU_INT64"}
+    if mads and union_ms:
+        ach = mads * per_launch * launches / (union_ms * 1e-3) / 1e12
+        r.update({"mads_per_proof_launch": mads, "achieved": ach, "frac": ach / (VALU_PEAK_MAD_PER_S / 1e12)})
     else:
         r.update({"achieved": None, "frac": None})
     return r
@@ -422,13 +426,13 @@ def device_config(pkg, local_rank, label, n_public, n, steps, warmup, seed, orac
     dom = max(breakdown, key=lambda k: breakdown[k][1])
     v.select_kernels([dom])
     v.sync()
-    prof = (0, 0.0)
+    prof = (0, 0.0, 0.0)
     t = time.perf_counter()
     for _ in range(steps):
         v.step()
-        kp, per_launch = v.kernel_profile()
+        kp, per_launch = v.kernel_profile_all()
         if dom in kp:
-            prof = (prof[0] + kp[dom][0], prof[1] + kp[dom][1])
+            prof = (prof[0] + kp[dom][0], prof[1] + kp[dom][1], prof[2] + kp[dom][2])
     v.sync()
     dt = (time.perf_counter() - t) / steps
     got = v.status_bytes()
@@ -447,7 +451,7 @@ def device_config(pkg, local_rank, label, n_public, n, steps, warmup, seed, orac
     value = n / dt
     out = {"workload": label, "value": value, "unit": "proofs/s", "ms_per_step": dt * 1e3, "steps": steps, "batch": n, "n_public": n_public,
            "status_check": "all %d statuses == generator's; %d strided proofs == oracle" % (n, checked),
-           "roofline": _valu_roofline(dom, prof, per_launch, concurrent=per_launch < n),
+           "roofline": _valu_roofline(dom, prof, per_launch),
            "valu_whole_path": _valu_whole_path(breakdown, value),
            "hbm_roofline": {"algorithmic_bytes_per_proof": algo, "achieved": value * algo / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value * algo / 1e9 / HBM_PEAK_GBPS},
            "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},

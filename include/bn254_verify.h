@@ -196,6 +196,10 @@ const char* bn254_groth16_kernel_name(int i);                 /* phase names */
 int bn254_groth16_num_kernel_kinds(void);
 const char* bn254_groth16_kernel_kind_name(int i);
 int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned launches[], float total_ms[], size_t* proofs_per_launch);
+/* Same over the first TWO sub-batches (two streams side by side), plus union_ms[kind]: the length of the union of the launch intervals of that kind
+ * on a common time base.  Work of all the launches / union = the rate the GPU delivered while that kernel kind ran, whether the two streams' launches
+ * overlapped (union = about one launch) or ran one after the other (union = the sum). */
+int bn254_groth16_kernel_profile_all(const bn254_g16_pvk* pvk, int device, unsigned launches[], float total_ms[], float union_ms[], size_t* proofs_per_launch);
 
 /* ---- synthetic gnark-format workload generator (bench / tests; host threads, no GPU) --------------------------------
  * Deterministic (SplitMix64 seed).  Writes a gnark-compressed verifying key (292 + 32 (n_public+1) + 4 + 128 bytes), n

@@ -94,6 +94,7 @@ def lib():
         L.bn254_set_rlc_params.argtypes = [C.c_long, C.c_int, C.c_long]
         L.bn254_set_rlc_params.restype = None
         L.bn254_groth16_kernel_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.POINTER(C.c_size_t)]
+        L.bn254_groth16_kernel_profile_all.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -229,6 +230,13 @@ class PreparedVk:
         cnt = (C.c_uint * k)(); ms = (C.c_float * k)(); per = C.c_size_t(0)
         _check(lib().bn254_groth16_kernel_profile(self._h, device, cnt, ms, C.byref(per)))
         return {lib().bn254_groth16_kernel_kind_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(k) if cnt[i]}, int(per.value)
+
+    def kernel_profile_all(self, device=0):
+        """Per kernel kind over the first two sub-batches (two streams): {name: (launches, total_ms, union_ms)}, and the proofs per launch."""
+        k = lib().bn254_groth16_num_kernel_kinds()
+        cnt = (C.c_uint * k)(); ms = (C.c_float * k)(); un = (C.c_float * k)(); per = C.c_size_t(0)
+        _check(lib().bn254_groth16_kernel_profile_all(self._h, device, cnt, ms, un, C.byref(per)))
+        return {lib().bn254_groth16_kernel_kind_name(i).decode(): (int(cnt[i]), float(ms[i]), float(un[i])) for i in range(k) if cnt[i]}, int(per.value)
 
     def close(self):
         if self._h:

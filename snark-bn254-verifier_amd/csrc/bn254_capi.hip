@@ -3,6 +3,7 @@
 // There is deliberately no CPU implementation of verify here: if HIP is unusable the calls fail (BN254_E_NO_DEVICE).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -85,6 +86,8 @@ struct DevState {
   hipStream_t aux[3] = {nullptr, nullptr, nullptr}; int aux_count = 0; hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // per-launch timing of the first sub-batch (bn254_groth16_kernel_profile)
   std::vector<hipEvent_t> prof_ev; std::vector<uint8_t> prof_kid; G16Prof prof{0, nullptr, nullptr, 0, 0}; size_t prof_n = 0;
+  // the same for the SECOND sub-batch (its launches run on another stream beside the first's): bn254_groth16_kernel_profile_all
+  std::vector<hipEvent_t> prof2_ev; std::vector<uint8_t> prof2_kid; G16Prof prof2{0, nullptr, nullptr, 0, 0}; bool prof2_used = false;
   RlcDev rlc;                                                       // BN254_FLAG_RLC buffers (bn254_rlc.hpp)
 };
 struct bn254_g16_pvk {
@@ -152,6 +155,9 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
     d.prof_ev.resize(2 * cap); d.prof_kid.resize(cap);
     for (auto& e : d.prof_ev) HIPCK(hipEventCreate(&e));
     d.prof.ev = d.prof_ev.data(); d.prof.kid = d.prof_kid.data(); d.prof.cap = cap;
+    d.prof2_ev.resize(2 * cap); d.prof2_kid.resize(cap);
+    for (auto& e : d.prof2_ev) HIPCK(hipEventCreate(&e));
+    d.prof2.ev = d.prof2_ev.data(); d.prof2.kid = d.prof2_kid.data(); d.prof2.cap = cap;
     d.ev_ready = true;
   }
   return BN254_OK;
@@ -172,7 +178,7 @@ static void dev_free(DevState& d) {
   for (auto q : ptrs) if (q) (void)hipFree(q);
   uint8_t* bp[] = {d.st_proofs, d.st_inputs, d.st_status};
   for (auto q : bp) if (q) (void)hipFree(q);
-  if (d.ev_ready) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(d.ev[i]); for (auto& e : d.prof_ev) (void)hipEventDestroy(e); }
+  if (d.ev_ready) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(d.ev[i]); for (auto& e : d.prof_ev) (void)hipEventDestroy(e); for (auto& e : d.prof2_ev) (void)hipEventDestroy(e); }
   for (int i = 0; i < d.aux_count; i++) (void)hipStreamDestroy(d.aux[i]);
   if (d.fork_ev) { (void)hipEventDestroy(d.fork_ev); for (int i = 0; i < 4; i++) (void)hipEventDestroy(d.join_ev[i]); }
   if (d.busy_ev) (void)hipEventDestroy(d.busy_ev);
@@ -497,8 +503,10 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       }
       // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
       const bool prof_this = profiling && d->ev_ready && pi == 0;
-      if (prof_this) { d->prof.mask = g_prof_mask.load(); d->prof.used = 0; d->prof_n = a.n; }
-      hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : nullptr);
+      if (prof_this) { d->prof.mask = g_prof_mask.load(); d->prof.used = 0; d->prof_n = a.n; d->prof2.used = 0; d->prof2_used = false; }
+      const bool prof_second = profiling && d->ev_ready && pi == 1;
+      if (prof_second) { d->prof2.mask = g_prof_mask.load(); d->prof2.used = 0; d->prof2_used = true; }
+      hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : (prof_second ? &d->prof2 : nullptr));
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));
       if (concurrent && (pi + 4 >= parts) && st != user) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
@@ -710,6 +718,48 @@ int bn254_groth16_kernel_profile(const bn254_g16_pvk* pvk, int device, unsigned 
     float ms = 0.f;
     HIPCK(hipEventElapsedTime(&ms, d.prof.ev[2 * i], d.prof.ev[2 * i + 1]));
     launches[d.prof.kid[i]]++; total_ms[d.prof.kid[i]] += ms;
+  }
+  if (proofs_per_launch) *proofs_per_launch = d.prof_n;
+  return BN254_OK;
+}
+
+// Launches, summed durations AND the union of the launch intervals per kernel kind over the first TWO sub-batches of the last profiled batch (they
+// run on two streams side by side).  union_ms[k] = length of the union of the intervals [start, end] of every launch of kind k, on a common time
+// base (HIP events of both streams against the first sub-batch's first event): for two streams that run the same kernel at the same time it is
+// about one launch's duration, for launches that happen to run one after the other it is the sum -- either way "work of all those launches / union"
+// is the rate the GPU delivered while that kernel kind was running.
+int bn254_groth16_kernel_profile_all(const bn254_g16_pvk* pvk, int device, unsigned launches[], float total_ms[], float union_ms[], size_t* proofs_per_launch) {
+  if (!pvk || !launches || !total_ms || !union_ms) return set_err(BN254_E_BAD_ARG, "bad argument");
+  DevState* dp = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(dp->mu);
+  DevState& d = *dp;
+  if (!d.ev_recorded || d.prof.used == 0) return set_err(BN254_E_BAD_ARG, "no profiled batch on this device");
+  HIPCK(hipSetDevice(device));
+  std::vector<std::vector<std::pair<float, float>>> iv(KID_COUNT);
+  for (int k = 0; k < KID_COUNT; k++) { launches[k] = 0; total_ms[k] = 0.f; union_ms[k] = 0.f; }
+  const hipEvent_t ref = d.prof.ev[0];
+  const G16Prof* ps[2] = {&d.prof, d.prof2_used ? &d.prof2 : nullptr};
+  for (const G16Prof* p : ps) {
+    if (!p) continue;
+    for (int i = 0; i < p->used; i++) {
+      HIPCK(hipEventSynchronize(p->ev[2 * i + 1]));
+      float a = 0.f, b = 0.f;
+      HIPCK(hipEventElapsedTime(&a, ref, p->ev[2 * i]));
+      HIPCK(hipEventElapsedTime(&b, ref, p->ev[2 * i + 1]));
+      launches[p->kid[i]]++; total_ms[p->kid[i]] += b - a;
+      iv[p->kid[i]].push_back({a, b});
+    }
+  }
+  for (int k = 0; k < KID_COUNT; k++) {
+    auto& v = iv[k];
+    std::sort(v.begin(), v.end());
+    float cur_lo = 0.f, cur_hi = 0.f; bool open = false;
+    for (auto& x : v) {
+      if (!open) { cur_lo = x.first; cur_hi = x.second; open = true; }
+      else if (x.first <= cur_hi) { if (x.second > cur_hi) cur_hi = x.second; }
+      else { union_ms[k] += cur_hi - cur_lo; cur_lo = x.first; cur_hi = x.second; }
+    }
+    if (open) union_ms[k] += cur_hi - cur_lo;
   }
   if (proofs_per_launch) *proofs_per_launch = d.prof_n;
   return BN254_OK;

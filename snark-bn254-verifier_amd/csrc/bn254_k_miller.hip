@@ -2,6 +2,7 @@
 // each instantiation is ~300 KB of straight-line code and the three of them dominate the library's compile time.
 //   k_miller_step_dbl<DO_SQR>, k_miller_step_add: one whole step of the shared Miller loop (bn254_vm.h::vm_miller_step): [f <- f^2,] T <- 2T or
 //   T + Q, f <- f * line_T(A) * line_gamma(L) * line_delta(C)   (replaces one iteration of bn's miller_loop_batch under groth16/verify.rs:73-77)
+#include <cstdlib>
 #include "bn254_devws.h"
 
 namespace bn254 {
