@@ -40,6 +40,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes every stream of a process onto a few hardware queues (four by default), and streams that share a queue run one
+# after the other.  A rank of this bench has the library's two sub-batch streams, its copy stream and -- under torch.distributed -- RCCL's own
+# streams; with eight queues none of them shares (measured with RCCL initialised: the two sub-batch streams overlap 1.75 x instead of not at all,
+# 185 against 192 ms per step).  Read by the runtime when it initialises, i.e. before torch is imported; a deployment sets the same variable.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 def algo_bytes_per_proof(n_public):
     """256 B proof + 32 B per public input in, 1 B status out (321 B at 2 inputs, 33 025 B at 1024)."""
