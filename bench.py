@@ -251,7 +251,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         }
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
-            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch)
+            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, passes=args.steps * (2 if per_launch < n else 1))
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
             out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown, algo)
         emit(json.dumps(out))
@@ -265,7 +265,7 @@ def _load_json(name):
         return None
 
 
-def _valu_roofline(dom, launches_ms, per_launch):
+def _valu_roofline(dom, launches_ms, per_launch, passes=None):
     """The binding roofline, for the dominant kernel kind: multiply-adds of all its launches / the time during which it was running, vs the v_mad peak.
     launches_ms = (launches, summed launch durations, union of the launch intervals) over the sub-batch streams of the timed steps: two streams that
     run the kernel side by side give union = about one launch's duration, launches that happen to run one after the other the sum."""
@@ -281,8 +281,16 @@ def _valu_roofline(dom, launches_ms, per_launch):
                  "base); `overlap` = summed launch durations / union (2 = the two streams ran the kernel side by side the whole time); avg_launch_ms is what rocprofv3's "
                  "kernel trace averages; peak = measured issue rate (profiles/r01_ubench_valu.txt).  Cooperative kernels: 12 lanes per proof, count from the call-graph "
                  "model checked against SQ_INSTS_VALU_INT64"}
+    entry = (_load_json("kernel_mads.json") or {}).get("kernels", {}).get(dom, {})
     if mads and union_ms:
-        ach = mads * per_launch * launches / (union_ms * 1e-3) / 1e12
+        if entry.get("per_pass") and passes:
+            # a kernel whose launches split one fixed piece of work (k_miller_run: the 88 steps of the Miller loop in 1, 2, 4 or 8 launches by sub-batch size):
+            # the count is per pass over a sub-batch, whatever the number of launches
+            total = entry["mads_per_proof_batch"] * per_launch * passes
+            r["passes_timed"] = passes
+        else:
+            total = mads * per_launch * launches
+        ach = total / (union_ms * 1e-3) / 1e12
         r.update({"mads_per_proof_launch": mads, "achieved": ach, "frac": ach / (VALU_PEAK_MAD_PER_S / 1e12)})
     else:
         r.update({"achieved": None, "frac": None})
@@ -456,7 +464,7 @@ def device_config(pkg, local_rank, label, n_public, n, steps, warmup, seed, orac
     value = n / dt
     out = {"workload": label, "value": value, "unit": "proofs/s", "ms_per_step": dt * 1e3, "steps": steps, "batch": n, "n_public": n_public,
            "status_check": "all %d statuses == generator's; %d strided proofs == oracle" % (n, checked),
-           "roofline": _valu_roofline(dom, prof, per_launch),
+           "roofline": _valu_roofline(dom, prof, per_launch, passes=steps * (2 if per_launch < n else 1)),
            "valu_whole_path": _valu_whole_path(breakdown, value),
            "hbm_roofline": {"algorithmic_bytes_per_proof": algo, "achieved": value * algo / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value * algo / 1e9 / HBM_PEAK_GBPS},
            "kernels_ms": {k: {"launches": c, "total_ms": round(m, 3)} for k, (c, m) in sorted(breakdown.items(), key=lambda kv: -kv[1][1])},

@@ -891,9 +891,12 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     (void)hipStreamWaitEvent(s, a.split_ev[1], 0); (void)hipStreamWaitEvent(s, a.split_ev[2], 0);
     ops.f12_mul(VE_F, VE_F, VE_S1); ops.f12_mul(VE_F, VE_F, VE_S2);
   } else {
-    // BN254_MILLER_RUN_STEPS: steps of the Miller loop per launch (default 88: the whole loop is ONE launch, f never leaves LDS + registers);
-    // 0: the one-launch-per-step kernels (k_miller_step_dbl / _add)
-    static const int run_steps = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : BN_ATE_STEPS; return v < 0 ? 0 : v; }();
+    // Steps of the Miller loop per launch (k_miller_run: f never leaves LDS + registers inside a launch).  Large sub-batches take the whole loop in ONE
+    // launch; sub-batches that are a single generation of workgroups run measurably better in a few shorter launches (batch 2^17 = two sub-batches of
+    // 2^16: 11 steps per launch 5.75 M proofs/s, 22: 5.71, 44: 5.60, 88: 5.49; batch 2^19: 44 best; 2^20: 88 best by 0.7 %; profiles/r03_run_steps_sweep.txt).
+    // BN254_MILLER_RUN_STEPS overrides (0: the one-launch-per-step kernels k_miller_step_dbl / _add).
+    static const int run_steps_env = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : -1; return v < -1 ? -1 : v; }();
+    const int run_steps = run_steps_env >= 0 ? run_steps_env : (a.n <= 65536 ? 11 : a.n <= 131072 ? 22 : a.n <= 262144 ? 44 : BN_ATE_STEPS);
     if (run_steps) vm_miller_program_runs(ops, run_steps);
     else vm_miller_program(ops, step_kinds_host(), true);
   }

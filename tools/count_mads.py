@@ -408,6 +408,7 @@ def main():
         total = 64 * a["mads_per_proof_launch"] + b["mads_per_proof_launch"] + 23 * add["mads_per_proof_launch"]
         run["mads_per_proof_launch"] = total
         run["mads_per_proof_batch"] = total
+        run["per_pass"] = True      # the 88 steps run in 1, 2, 4 or 8 launches depending on the sub-batch size: the count is per pass over a sub-batch
         run["unmodelled"] = []
         run["model"] = ("whole Miller loop in one launch = 64 doubling steps with the squaring of f (%d multiply-adds, k_miller_step_dbl<true>) + the first without (%d) + "
                         "23 addition steps (%.1f on average, k_miller_step_add); static multiply-adds of the loop body with both branches: %d"
