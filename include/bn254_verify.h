@@ -113,6 +113,13 @@ int bn254_groth16_verify_batch_multi(const bn254_g16_pvk* pvk, const uint8_t* pr
  * above it is BN254_E_BAD_ARG). */
 int bn254_shard_plan(size_t n, uint64_t device_mask, int device_count, int devices[64], size_t first[64], size_t count[64], int* n_shards);
 
+/* The gather of a multi-PROCESS job (one process per GPU, rank r verifying shard r of bn254_shard_plan(n, ranks 0..world-1)): ONE ncclAllGather of the
+ * status bytes on hip_stream, every rank ends with the full n-byte vector in d_full (device memory).  nccl_comm: the caller's ncclComm_t (RCCL; the
+ * library does not link RCCL: ncclAllGather is looked up in the process, then in librccl.so).  d_local: this rank's shard statuses (device memory).
+ * d_scratch: world * ceil(n / world) bytes of device memory, needed only when n is not a multiple of world (ragged shards travel as padded blocks).
+ * bench.py's ranks do the same through torch.distributed (snark-bn254-verifier_amd/sharding.py); this entry is for a Rust / C host. */
+int bn254_status_all_gather(void* nccl_comm, int world, int rank, const void* d_local, size_t n, void* d_full, void* d_scratch, void* hip_stream);
+
 /* Same, with proofs / public_inputs / status already resident in the memory of `device` (the bench path: inputs in
  * HBM when the timed region starts).  hip_stream is a hipStream_t (NULL = default stream); the call only enqueues
  * work and returns, so the caller synchronises the stream before reading status.  Use bn254_groth16_reserve() first to

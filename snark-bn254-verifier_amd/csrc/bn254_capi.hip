@@ -3,6 +3,7 @@
 // There is deliberately no CPU implementation of verify here: if HIP is unusable the calls fail (BN254_E_NO_DEVICE).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -880,6 +881,46 @@ int bn254_shard_plan(size_t n, uint64_t device_mask, int device_count, int devic
   const size_t base = n / (size_t)w, rem = n % (size_t)w;
   for (int r = 0; r < w; r++) { first[r] = (size_t)r * base + ((size_t)r < rem ? (size_t)r : rem); count[r] = base + ((size_t)r < rem ? 1 : 0); }
   *n_shards = w;
+  return BN254_OK;
+}
+
+// ---- the gather of a multi-PROCESS job (one process per GPU): one ncclAllGather of the ranks' status bytes -----------------
+// RCCL is not linked: a host that runs such a job already has it in its process (it created the communicator), so the symbol is looked up at the
+// first call -- among the objects already loaded, then in librccl.so.
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static nccl_all_gather_fn rccl_all_gather() {
+  static nccl_all_gather_fn fn = [] {
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+    if (!sym) { void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (h) sym = dlsym(h, "ncclAllGather"); }
+    return (nccl_all_gather_fn)sym;
+  }();
+  return fn;
+}
+int bn254_status_all_gather(void* nccl_comm, int world, int rank, const void* d_local, size_t n, void* d_full, void* d_scratch, void* hip_stream) {
+  if (!nccl_comm || world <= 0 || world > 64 || rank < 0 || rank >= world || (n && (!d_local || !d_full))) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (n == 0) return BN254_OK;
+  int devs[64], nsh = 0; size_t first[64], cnt[64];
+  int rc = bn254_shard_plan(n, world == 64 ? ~0ull : ((1ull << world) - 1), world, devs, first, cnt, &nsh);   // the ranks' contiguous ranges
+  if (rc) return rc;
+  nccl_all_gather_fn ag = rccl_all_gather();
+  if (!ag) return set_err(BN254_E_HIP, "ncclAllGather not found: RCCL is neither loaded in this process nor loadable as librccl.so");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const size_t cap = (n + (size_t)world - 1) / (size_t)world;
+  const int nccl_uint8 = 1;
+  if (n % (size_t)world == 0) {
+    // equal shards: the gathered blocks ARE the status vector
+    int e = ag(d_local, d_full, cap, nccl_uint8, nccl_comm, s);
+    return e ? set_err(BN254_E_HIP, "ncclAllGather failed (" + std::to_string(e) + ")") : BN254_OK;
+  }
+  // ragged: every rank sends a block of `cap` bytes (its shard, padded), in place in the scratch; the blocks are then packed into the vector
+  if (!d_scratch) return set_err(BN254_E_BAD_ARG, "n is not a multiple of the world size: the gather needs world * ceil(n / world) bytes of scratch");
+  uint8_t* sc = (uint8_t*)d_scratch;
+  HIPCK(hipMemsetAsync(sc + (size_t)rank * cap, 0, cap, s));
+  HIPCK(hipMemcpyAsync(sc + (size_t)rank * cap, d_local, cnt[rank], hipMemcpyDeviceToDevice, s));
+  int e = ag(sc + (size_t)rank * cap, sc, cap, nccl_uint8, nccl_comm, s);
+  if (e) return set_err(BN254_E_HIP, "ncclAllGather failed (" + std::to_string(e) + ")");
+  for (int r = 0; r < world; r++)
+    if (cnt[r]) HIPCK(hipMemcpyAsync((uint8_t*)d_full + first[r], sc + (size_t)r * cap, cnt[r], hipMemcpyDeviceToDevice, s));
   return BN254_OK;
 }
 

@@ -54,3 +54,31 @@ def test_cpp_mirror_on_device(mirror_check, O, fixtures, tmp_path):
     want = [O.plonk_verify(p, vk, q) for p, q in cases]
     assert got == want
     assert want[:4] == [O.ACCEPT] * 4 and len(set(want)) >= 3
+
+
+def _build_gather_check(tmp_path_factory, mock):
+    out = str(tmp_path_factory.mktemp("cppg") / ("gather_check_mock" if mock else "gather_check_rccl"))
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "gather_check.cpp"), "-o", out,
+           "-L", PKG, "-l:libbn254_verify_amd.so", "-Wl,-rpath," + PKG]
+    cmd += ["-DGATHER_MOCK", "-rdynamic"] if mock else ["-lrccl"]
+    subprocess.check_call(cmd)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mock", [True, False])
+def test_status_all_gather_cpp_host(pkg, tmp_path_factory, mock):
+    """bn254_status_all_gather, the gather of a multi-process job for a C / Rust host: with an in-process stand-in for ncclAllGather that plays 2 ... 8
+    ranks (equal and ragged shards, first and last rank), and with a real one-rank RCCL communicator."""
+    exe = _build_gather_check(tmp_path_factory, mock)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "gather_check ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_status_all_gather_rejects_bad_arguments(pkg):
+    import ctypes as C
+    L = pkg.lib()
+    L.bn254_status_all_gather.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.bn254_status_all_gather(None, 2, 0, None, 10, None, None, None) == -1          # no communicator
+    assert L.bn254_status_all_gather(C.c_void_p(1), 2, 5, C.c_void_p(1), 10, C.c_void_p(1), None, None) == -1   # rank outside the world
+    assert L.bn254_status_all_gather(C.c_void_p(1), 2, 0, None, 0, None, None, None) == 0   # nothing to gather
