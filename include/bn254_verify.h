@@ -235,6 +235,9 @@ int bn254_dbg_g2_subgroup_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* out
 /* host-only probe of the GLV scalar decomposition the PlonK MSMs use: k = (-1)^neg1 k1 + (-1)^neg2 k2 lambda (mod r), k1, k2 < 2^127 */
 int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2);
 
+/* host-only probe of the modular inversion of the PlonK stages (binary extended GCD; which = 1: the Fermat form; field 0: Fr, 1: Fp); 32-byte big-endian in / out */
+int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field);
+
 /* host-only probe of the comb tables used for keys with many public inputs (csrc/bn254_host.hpp::build_comb_table): x * P computed from P's table
  * and the column digits of the 256-bit big-endian x, as the kernels do; out64 = uncompressed point, all zero for the identity */
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]);

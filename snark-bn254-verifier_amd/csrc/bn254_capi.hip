@@ -30,6 +30,15 @@ static_assert(BN254_REJECT == BN254_ST_REJECT && BN254_ACCEPT == BN254_ST_ACCEPT
 
 using namespace bn254host;
 
+// bn254_k_plonk.hip: the PlonK host stages as device kernels (the same bn254_plonk.hpp source, one proof per lane)
+size_t bn254_plonk_work_bytes();
+size_t bn254_plonk_key_bytes();
+hipError_t bn254_plonk_dev_init(int device);
+hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs, size_t stride, const uint8_t* d_inputs, size_t n_public, size_t n, const uint32_t lam_key[11],
+                                     void* d_work, void* d_terms, uint8_t* d_flags, int T1, hipStream_t s);
+hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
+                                     void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s);
+
 static thread_local std::string g_err;
 static std::atomic<int> g_profiling{0};
 static std::atomic<unsigned> g_prof_mask{0xffffffffu};
@@ -213,10 +222,13 @@ struct PlonkCtx {
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
   MsmTerm* h_terms = nullptr; uint8_t *h_flags = nullptr, *h_status = nullptr, *h_inf = nullptr; uint32_t* h_words = nullptr;
+  // device-side stages (bn254_k_plonk.hip): the batch's proofs and inputs in device memory (through a pinned copy), per-proof state between the stages
+  uint8_t *d_in = nullptr, *h_in = nullptr; size_t in_cap = 0; void* d_work = nullptr;
 };
 struct PlonkDev {
   bool ready = false;
   int32_t *tab0 = nullptr, *tab1 = nullptr, *one = nullptr;
+  void* d_key = nullptr;               // the parsed key (PlonkKey) for the device-side stages
   PlonkCtx ctx[PLONK_WORKERS];
 };
 struct bn254_plonk_pvk {
@@ -226,9 +238,9 @@ struct bn254_plonk_pvk {
   mutable std::map<int, PlonkDev> dev;
 };
 static void plonk_ctx_free(PlonkCtx& c) {
-  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status};
+  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status, c.d_in, c.d_work};
   for (auto q : ptrs) if (q) (void)hipFree(q);
-  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words};
+  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words, c.h_in};
   for (auto q : hp) if (q) (void)hipHostFree(q);
   if (c.stream) (void)hipStreamDestroy(c.stream);
   if (c.aux) (void)hipStreamDestroy(c.aux);
@@ -238,10 +250,10 @@ static void plonk_ctx_free(PlonkCtx& c) {
   c = PlonkCtx();
 }
 static void plonk_dev_free(PlonkDev& d) {
-  void* ptrs[] = {d.tab0, d.tab1, d.one};
+  void* ptrs[] = {d.tab0, d.tab1, d.one, d.d_key};
   for (auto q : ptrs) if (q) (void)hipFree(q);
   for (auto& c : d.ctx) plonk_ctx_free(c);
-  d.ready = false; d.tab0 = d.tab1 = d.one = nullptr;
+  d.ready = false; d.tab0 = d.tab1 = d.one = nullptr; d.d_key = nullptr;
 }
 static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** out) {
   int rc = check_device(device);
@@ -249,6 +261,11 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
   PlonkDev& d = pvk->dev[device];
   if (!d.ready) {
     if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
+    // the key and the field constants for the device-side stages
+    if (sizeof(PlonkKey) != bn254_plonk_key_bytes()) return set_err(BN254_E_HIP, "PlonK key layout differs between the translation units");
+    HIPCK(bn254_plonk_dev_init(device));
+    HIPCK(hipMalloc(&d.d_key, sizeof(PlonkKey)));
+    HIPCK(hipMemcpy(d.d_key, &pvk->key, sizeof(PlonkKey), hipMemcpyHostToDevice));
     d.ready = true;
   }
   *out = &d;
@@ -265,7 +282,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   // drop the old buffers and forget them BEFORE anything is allocated: if an allocation below fails the context is left empty (cap = 0, every
   // pointer null), never with a stale pointer that a later call or plonk_ctx_free would free a second time
   auto drop = [&c] {
-    void** dp[] = {(void**)&c.ws, (void**)&c.part, (void**)&c.glv_tab, (void**)&c.terms, (void**)&c.flags, (void**)&c.words, (void**)&c.inf, (void**)&c.status};
+    void** dp[] = {(void**)&c.ws, (void**)&c.part, (void**)&c.glv_tab, (void**)&c.terms, (void**)&c.flags, (void**)&c.words, (void**)&c.inf, (void**)&c.status, (void**)&c.d_work};
     for (auto q : dp) { if (*q) (void)hipFree(*q); *q = nullptr; }
     void** hp[] = {(void**)&c.h_terms, (void**)&c.h_flags, (void**)&c.h_status, (void**)&c.h_inf, (void**)&c.h_words};
     for (auto q : hp) { if (*q) (void)hipHostFree(*q); *q = nullptr; }
@@ -290,6 +307,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   dm((void**)&c.words, need * 16 * sizeof(uint32_t));
   dm((void**)&c.inf, need);
   dm((void**)&c.status, need);
+  dm((void**)&c.d_work, need * bn254_plonk_work_bytes());
   hm((void**)&c.h_terms, need * tmax * sizeof(MsmTerm));
   hm((void**)&c.h_flags, need * tmax);
   hm((void**)&c.h_status, need);
@@ -1125,6 +1143,68 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   return BN254_OK;
 }
 
+// The same sub-batch with BOTH host stages on the device (bn254_k_plonk.hip): one H2D copy of the proofs and inputs, stage 1 -> digest MSM -> stage 2 ->
+// folding MSMs -> pairing check on the context's stream without a host wait in between, one D2H copy of the status bytes.
+static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c, int device, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                            size_t n_public, size_t m, uint8_t* status) {
+  HIPCK(hipSetDevice(device));
+  const PlonkKey& key = pvk->key;
+  const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key), TT = T2 + 2;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto t0 = now();
+  const size_t pb = m * proof_stride, ib = m * n_public * 32, need = pb + ib;
+  if (need > c.in_cap) {
+    if (c.d_in) HIPCK(hipFree(c.d_in));
+    if (c.h_in) HIPCK(hipHostFree(c.h_in));
+    c.d_in = nullptr; c.h_in = nullptr; c.in_cap = 0;
+    const size_t cap = (need + 65535) / 65536 * 65536;
+    HIPCK(hipMalloc((void**)&c.d_in, cap));
+    HIPCK(hipHostMalloc((void**)&c.h_in, cap, hipHostMallocDefault));
+    c.in_cap = cap;
+  }
+  uint32_t lam_key[11];
+  for (size_t got = 0; got < sizeof lam_key;) {   // fresh per call, secret until the proofs are fixed (plonk_run has the reasoning)
+    ssize_t k = getrandom((uint8_t*)lam_key + got, sizeof lam_key - got, 0);
+    if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
+    got += (size_t)k;
+  }
+  parallel_copy(c.h_in, proofs, pb);
+  if (ib) parallel_copy(c.h_in + pb, public_inputs, ib);
+  auto t1_ = now();
+  HIPCK(hipMemcpyAsync(c.d_in, c.h_in, need, hipMemcpyHostToDevice, c.stream));
+  const uint8_t* d_proofs = c.d_in; const uint8_t* d_inputs = c.d_in + pb;
+  HIPCK(hipEventRecord(c.tk[0], c.stream));
+  hipError_t e = bn254_launch_plonk_stage1(d->d_key, d_proofs, proof_stride, d_inputs, n_public, m, lam_key, c.d_work, c.terms, c.flags, T1, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_tab, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 1 launch: ") + hipGetErrorString(e));
+  HIPCK(hipEventRecord(c.tk[1], c.stream));
+  e = bn254_launch_plonk_stage2(d->d_key, d_proofs, proof_stride, m, c.d_work, c.words, c.inf, c.terms, c.flags, c.status, TT, T2, c.stream);
+  HIPCK(hipEventRecord(c.tk[2], c.stream));
+  if (e == hipSuccess) e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_tab, c.stream);
+  HIPCK(hipEventRecord(c.tk[3], c.stream));
+  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, TT, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 2 launch: ") + hipGetErrorString(e));
+  HIPCK(hipEventRecord(c.tk[4], c.stream));
+  e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
+  HIPCK(hipEventRecord(c.tk[5], c.stream));
+  HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  memcpy(status, c.h_status, m);
+  {
+    auto t4_ = now();
+    // slots as bn254_plonk_last_timing names them; the host stages are the staging copy and nothing: [0] host copy into pinned memory, [2] 0
+    c.last_ms[0] = (float)ms(t0, t1_); c.last_ms[2] = 0.f; c.last_ms[3] = (float)ms(t1_, t4_);
+    HIPCK(hipEventElapsedTime(&c.last_ms[4], c.tk[0], c.tk[1])); HIPCK(hipEventElapsedTime(&c.last_ms[5], c.tk[2], c.tk[3]));
+    HIPCK(hipEventElapsedTime(&c.last_ms[6], c.tk[4], c.tk[5])); HIPCK(hipEventElapsedTime(&c.last_ms[7], c.tk[1], c.tk[2]));
+    c.last_ms[1] = c.last_ms[4];
+    c.last_lanes[0] = m * (size_t)T1; c.last_lanes[1] = m * (size_t)TT; c.last_valid = true;
+  }
+  return BN254_OK;
+}
+
 int bn254_plonk_last_timing(const bn254_plonk_pvk* pvk, int device, float ms[BN254_PLONK_NUM_TIMINGS], size_t lanes[2]) {
   if (!pvk || !ms) return set_err(BN254_E_BAD_ARG, "bad argument");
   std::lock_guard<std::mutex> lk(pvk->mu);
@@ -1147,6 +1227,8 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   // sub-batches: at least 512 proofs each, at most PLONK_WORKERS in flight, each at most PLONK_MAX_LAUNCH proofs per pass
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
   static const int max_workers = [] { const char* e = getenv("BN254_PLONK_WORKERS"); int v = e ? atoi(e) : PLONK_WORKERS; return v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v); }();
+  // BN254_PLONK_HOST=1: the transcripts and the Fr arithmetic on host threads (rounds 1-2) instead of the device kernels of bn254_k_plonk.hip
+  static const bool dev_stages = [] { const char* e = getenv("BN254_PLONK_HOST"); return !(e && atoi(e) != 0); }();
   // below ~16 k proofs every GPU stage is latency-bound (one wave generation): sub-batches would only repeat those latencies side by side
   int workers = (int)(n / 8192); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
   const size_t per = (n + workers - 1) / workers;
@@ -1156,8 +1238,9 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     const size_t lo = (size_t)w * per, hi = lo + per < n ? lo + per : n;
     for (size_t off = lo; off < hi; off += PLONK_MAX_LAUNCH) {
       const size_t m = hi - off < (size_t)PLONK_MAX_LAUNCH ? hi - off : (size_t)PLONK_MAX_LAUNCH;
-      int r = plonk_run(pvk, d, d->ctx[w], device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
-                        (hw + workers - 1) / workers);
+      int r = dev_stages ? plonk_run_device(pvk, d, d->ctx[w], device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off)
+                         : plonk_run(pvk, d, d->ctx[w], device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
+                                     (hw + workers - 1) / workers);
       if (r) { rcs[w] = r; errs[w] = g_err; return; }
     }
   };
@@ -1339,6 +1422,16 @@ int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2
   Glv g = glv_decompose(F.to_canon(F.from_be32(k32)));
   for (int i = 0; i < 8; i++) { k1_16[i] = (uint8_t)(g.k1[1] >> (56 - 8 * i)); k1_16[8 + i] = (uint8_t)(g.k1[0] >> (56 - 8 * i)); k2_16[i] = (uint8_t)(g.k2[1] >> (56 - 8 * i)); k2_16[8 + i] = (uint8_t)(g.k2[0] >> (56 - 8 * i)); }
   *neg1 = g.neg1 ? 1 : 0; *neg2 = g.neg2 ? 1 : 0;
+  return BN254_OK;
+}
+
+// host-only probe of the Fr inversion the PlonK stages use (bn254_plonk.hpp::FrCtx::inverse, binary extended GCD; which = 1: the Fermat form it replaced;
+// field = 1: the same code instantiated for Fp, as the curve checks of the proof points use it).  in / out: 32-byte big-endian canonical values.
+int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field) {
+  if (!in32 || !out32) return set_err(BN254_E_BAD_ARG, "bad argument");
+  const FrCtx& F = field ? fp64_ctx().F : fr_ctx();
+  const FrM a = F.from_be_reduce(in32, 32);
+  F.to_be(out32, which ? F.inverse_fermat(a) : F.inverse(a));
   return BN254_OK;
 }
 

@@ -1,0 +1,100 @@
+// bn254_k_plonk.hip -- the per-proof HOST stages of the PlonK verifier as device kernels, one proof per lane (round 3).
+//
+// plonk/verify.rs:46-284 and kzg.rs:46-190 up to the group operations -- proof parsing and curve checks (plonk/converter.rs:121-178), the four
+// Fiat-Shamir challenges and the folding challenge (transcript.rs:15-108: SHA-256), the BSB22 hash-to-field (hash_to_field.rs:45-97), the scalar-field
+// arithmetic of the linearisation, the GLV split of every MSM scalar -- are the SAME source as the host path: bn254_plonk.hpp compiled with
+// BN254_PLONK_DEVICE_TU, which makes its functions __host__ __device__.  A batch then stays on the GPU between its one H2D copy (proofs, inputs) and
+// its one D2H copy (status bytes): no device -> host -> device round trip between the two MSM stages, no host threads.
+//   k_plonk_stage1: transcripts gamma / beta / alpha / zeta, opening check, the T1 terms of the linearised-polynomial digest, lambda (ChaCha20)
+//   k_plonk_stage2: folding transcript over the digest (the first MSM's result, read from device memory), the T2 + 2 terms of the KZG check
+// A lane runs ~250 k instructions on its own; 4096 proofs are 64 wavefronts, so the launches are latency-bound (one wavefront per SIMD, 64-thread
+// workgroups so that they spread over the chip).
+#define BN254_PLONK_DEVICE_TU 1
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include "bn254_plonk.hpp"
+#include "bn254_rlc.h"
+
+using namespace bn254host;
+
+namespace bn254 {
+
+__global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs,
+                                                     size_t n_public, uint32_t n, ChaChaKey lam_key, PlonkWork* __restrict__ work, MsmTerm* __restrict__ terms,
+                                                     uint8_t* __restrict__ flags, int T1) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  const FrCtx& F = fr_ctx();
+  PlonkWork& wk = work[i];
+  {
+    // the KZG batching scalar: 384 bits of the call's ChaCha20 stream (blocks 3i .. 3i+2) reduced mod r, as the host path draws it
+    uint32_t lw[12];
+    for (int j = 0; j < 3; j++) chacha20_block4(lw + 4 * j, lam_key, 3u * i + (uint32_t)j);
+    uint8_t lb[48];
+    for (int j = 0; j < 12; j++) { lb[4 * j] = (uint8_t)lw[j]; lb[4 * j + 1] = (uint8_t)(lw[j] >> 8); lb[4 * j + 2] = (uint8_t)(lw[j] >> 16); lb[4 * j + 3] = (uint8_t)(lw[j] >> 24); }
+    wk.lambda = F.from_be_reduce(lb, 48);
+  }
+  MsmTerm* t = terms + (size_t)i * T1;
+  uint8_t* fl = flags + (size_t)i * T1;
+  for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
+  PlonkStage1 s;
+  int st = s.a(*key, proofs + (size_t)i * stride, stride, inputs + (size_t)i * n_public * 32, n_public, wk);
+  if (st == PL_OK) st = s.b(F.inverse(s.acc), t, fl);
+  if (st != PL_OK) for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
+  wk.status = st;
+}
+
+__global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, uint32_t n,
+                                                     PlonkWork* __restrict__ work, const uint32_t* __restrict__ lin_words, const uint8_t* __restrict__ lin_inf,
+                                                     MsmTerm* __restrict__ terms, uint8_t* __restrict__ flags, uint8_t* __restrict__ status, int TT, int T2) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  MsmTerm* t = terms + (size_t)i * TT;
+  uint8_t* fl = flags + (size_t)i * TT;
+  for (int k = 0; k < TT; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
+  PlonkWork& wk = work[i];
+  if (wk.status == PL_OK) {
+    wk.pr.raw = proofs + (size_t)i * stride;
+    uint32_t lw[16];
+    for (int q = 0; q < 16; q++) lw[q] = lin_words[(size_t)i * 16 + q];
+    plonk_stage2(*key, proofs + (size_t)i * stride, wk, lw, lin_inf[i] != 0, t, fl, t + T2);
+    status[i] = BN254_ST_PENDING;
+  } else {
+    status[i] = (uint8_t)wk.status;
+  }
+}
+
+}  // namespace bn254
+
+using namespace bn254;
+size_t bn254_plonk_work_bytes() { return sizeof(PlonkWork); }
+size_t bn254_plonk_key_bytes() { return sizeof(PlonkKey); }
+// the field constants of bn254_plonk.hpp (FrCtx, Fp64Ctx: built by host constructors) -> this device's copies; once per device
+hipError_t bn254_plonk_dev_init(int device) {
+  static std::mutex mu;
+  static bool done[64] = {false};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  if (done[device]) return hipSuccess;
+  const FrCtx& F = fr_ctx();
+  const Fp64Ctx& C = fp64_ctx();
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_plonk_fr_raw), &F, sizeof(FrCtx));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_plonk_fp64_raw), &C, sizeof(Fp64Ctx));
+  if (e == hipSuccess) done[device] = true;
+  return e;
+}
+hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs, size_t stride, const uint8_t* d_inputs, size_t n_public, size_t n, const uint32_t lam_key[11],
+                                     void* d_work, void* d_terms, uint8_t* d_flags, int T1, hipStream_t s) {
+  ChaChaKey key;
+  for (int i = 0; i < 8; i++) key.k[i] = lam_key[i];
+  for (int i = 0; i < 3; i++) key.nonce[i] = lam_key[8 + i];
+  hipLaunchKernelGGL(k_plonk_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkKey*)d_key, d_proofs, stride, d_inputs, n_public, (uint32_t)n, key, (PlonkWork*)d_work,
+                     (MsmTerm*)d_terms, d_flags, T1);
+  return hipGetLastError();
+}
+hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
+                                     void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s) {
+  hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words, d_lin_inf,
+                     (MsmTerm*)d_terms, d_flags, d_status, TT, T2);
+  return hipGetLastError();
+}

@@ -17,17 +17,27 @@
 #endif
 #include "bn254_host.hpp"
 
+// The per-proof stages (parsing, transcripts, Fr arithmetic, GLV decomposition) also run ON THE DEVICE, one proof per lane (csrc/bn254_k_plonk.hip,
+// round 3): that translation unit defines BN254_PLONK_DEVICE_TU before it includes this header, which turns PL_HD into __host__ __device__ and routes
+// fr_ctx() / fp64_ctx() to copies of the constants in device memory.  Every other includer sees plain host code, as before.
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIPCC__)
+#define PL_HD __host__ __device__ inline
+#define PL_DEVICE_PASS defined(__HIP_DEVICE_COMPILE__)
+#else
+#define PL_HD inline
+#endif
+
 namespace bn254host {
 
 // ---------------------------------------------------------------- SHA-256 (FIPS 180-4), transcript.rs / hash_to_field.rs use sha2
 struct Sha256 {
   uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill;
-  Sha256() { reset(); }
-  void reset() {
-    static const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+  PL_HD Sha256() { reset(); }
+  PL_HD void reset() {
+    const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
     memcpy(h, iv, sizeof h); len = 0; fill = 0;
   }
-  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  PL_HD static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 #if defined(__x86_64__)
   // the same compression function on the SHA extensions (every x86 host an MI355X box has carries them; checked at run time): the five
   // transcripts of a proof are ~30 blocks, a quarter of the host time of stage 1 with the portable code below
@@ -74,8 +84,8 @@ struct Sha256 {
     _mm_storeu_si128((__m128i*)&h[4], st1);
   }
 #endif
-  void block(const uint8_t* p) {
-#if defined(__x86_64__)
+  PL_HD void block(const uint8_t* p) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
     if (have_shani()) { block_shani(p); return; }
 #endif
     static const uint32_t K[64] = {
@@ -99,15 +109,16 @@ struct Sha256 {
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
   }
-  void update(const void* data, size_t n) {
+  PL_HD void update(const void* data, size_t n) {
     const uint8_t* p = (const uint8_t*)data; len += n;
     while (n) {
       size_t k = 64 - fill < n ? 64 - fill : n;
-      memcpy(buf + fill, p, k); fill += k; p += k; n -= k;
+      for (size_t q = 0; q < k; q++) buf[fill + q] = p[q];
+      fill += k; p += k; n -= k;
       if (fill == 64) { block(buf); fill = 0; }
     }
   }
-  void finish(uint8_t out[32]) {
+  PL_HD void finish(uint8_t out[32]) {
     uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1); uint8_t z = 0;
     while (fill != 56) update(&z, 1);
     uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
@@ -131,26 +142,26 @@ struct FrCtx {
     r2 = t;                                                          // 2^512 mod r
     shift256 = mul(one, r2);                                         // Montgomery form of 2^256: (2^256 mod r) * R
   }
-  bool geq_m(const FrM& a) const { for (int i = 3; i >= 0; i--) { if (a.l[i] > m[i]) return true; if (a.l[i] < m[i]) return false; } return true; }
-  FrM sub_m(const FrM& a) const { FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)a.l[i] - m[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r; }
-  FrM dbl_mod(const FrM& a) const {
+  PL_HD bool geq_m(const FrM& a) const { for (int i = 3; i >= 0; i--) { if (a.l[i] > m[i]) return true; if (a.l[i] < m[i]) return false; } return true; }
+  PL_HD FrM sub_m(const FrM& a) const { FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)a.l[i] - m[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r; }
+  PL_HD FrM dbl_mod(const FrM& a) const {
     FrM r; uint64_t c = 0;
     for (int i = 0; i < 4; i++) { uint64_t v = a.l[i]; r.l[i] = (v << 1) | c; c = v >> 63; }
     if (c || geq_m(r)) r = sub_m(r);
     return r;
   }
-  FrM add(const FrM& a, const FrM& b) const {
+  PL_HD FrM add(const FrM& a, const FrM& b) const {
     FrM r; unsigned __int128 c = 0;
     for (int i = 0; i < 4; i++) { c += (unsigned __int128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
     if (c || geq_m(r)) r = sub_m(r);
     return r;
   }
-  FrM neg(const FrM& a) const {
+  PL_HD FrM neg(const FrM& a) const {
     if (!(a.l[0] | a.l[1] | a.l[2] | a.l[3])) return a;
     FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)m[i] - a.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r;
   }
-  FrM sub(const FrM& a, const FrM& b) const { return add(a, neg(b)); }
-  FrM mul(const FrM& a, const FrM& b) const {  // CIOS Montgomery product
+  PL_HD FrM sub(const FrM& a, const FrM& b) const { return add(a, neg(b)); }
+  PL_HD FrM mul(const FrM& a, const FrM& b) const {  // CIOS Montgomery product
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
       unsigned __int128 c = 0;
@@ -165,30 +176,57 @@ struct FrCtx {
     if (t[4] || geq_m(r)) r = sub_m(r);
     return r;
   }
-  FrM from_u64(uint64_t v) const { FrM t = {{v, 0, 0, 0}}; return mul(t, r2); }
-  FrM from_canon(const FrM& a) const { return mul(a, r2); }          // a < r
-  FrM to_canon(const FrM& a) const { FrM o = {{1, 0, 0, 0}}; return mul(a, o); }
-  bool is_zero(const FrM& a) const { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
-  bool eq(const FrM& a, const FrM& b) const { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
-  FrM pow_u64(const FrM& a, uint64_t e) const {
+  PL_HD FrM from_u64(uint64_t v) const { FrM t = {{v, 0, 0, 0}}; return mul(t, r2); }
+  PL_HD FrM from_canon(const FrM& a) const { return mul(a, r2); }          // a < r
+  PL_HD FrM to_canon(const FrM& a) const { FrM o = {{1, 0, 0, 0}}; return mul(a, o); }
+  PL_HD bool is_zero(const FrM& a) const { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
+  PL_HD bool eq(const FrM& a, const FrM& b) const { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+  PL_HD FrM pow_u64(const FrM& a, uint64_t e) const {
     FrM r = one, b = a;
     while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; }
     return r;
   }
-  FrM inverse(const FrM& a) const {  // a^(r-2); 0 -> 0
+  PL_HD FrM inverse_fermat(const FrM& a) const {  // a^(r-2); 0 -> 0
     uint64_t e[4] = {m[0] - 2, m[1], m[2], m[3]};
     FrM r = one;
     for (int i = 255; i >= 0; i--) { r = mul(r, r); if ((e[i / 64] >> (i % 64)) & 1) r = mul(r, a); }
     return r;
   }
+  // Inverse by the binary extended Euclidean algorithm on the canonical value (HAC 14.61 for an odd modulus): invariants x1 a = u, x2 a = v (mod m);
+  // at most 2 x 256 halvings, each a few 256-bit additions / shifts -- a tenth of the 384 Montgomery products of the Fermat form, which matters on
+  // the device where a lane computes it alone.  Montgomery in, Montgomery out; 0 -> 0.
+  PL_HD FrM inverse(const FrM& a) const {
+    FrM u = to_canon(a), v = {{m[0], m[1], m[2], m[3]}}, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+    if (is_zero(u)) return u;
+    auto is_one = [](const FrM& t) { return t.l[0] == 1 && !(t.l[1] | t.l[2] | t.l[3]); };
+    auto shr1 = [](FrM& t, uint64_t top) { for (int i = 0; i < 3; i++) t.l[i] = (t.l[i] >> 1) | (t.l[i + 1] << 63); t.l[3] = (t.l[3] >> 1) | (top << 63); };
+    auto half_mod = [&](FrM& x) {            // x / 2 mod m
+      if (x.l[0] & 1) { unsigned __int128 c = 0; for (int i = 0; i < 4; i++) { c += (unsigned __int128)x.l[i] + m[i]; x.l[i] = (uint64_t)c; c >>= 64; } shr1(x, (uint64_t)c); }
+      else shr1(x, 0);
+    };
+    auto ge = [](const FrM& p, const FrM& q) { for (int i = 3; i >= 0; i--) { if (p.l[i] > q.l[i]) return true; if (p.l[i] < q.l[i]) return false; } return true; };
+    auto sub_into = [](FrM& p, const FrM& q) { uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)p.l[i] - q.l[i] - br; p.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } };
+    for (int guard = 0; guard < 1024 && !is_one(u) && !is_one(v); guard++) {
+      while (!(u.l[0] & 1)) { shr1(u, 0); half_mod(x1); }
+      while (!(v.l[0] & 1)) { shr1(v, 0); half_mod(x2); }
+      if (ge(u, v)) { sub_into(u, v); x1 = sub_canon(x1, x2); } else { sub_into(v, u); x2 = sub_canon(x2, x1); }
+    }
+    return from_canon(is_one(u) ? x1 : x2);
+  }
+  PL_HD FrM sub_canon(const FrM& a, const FrM& b) const {   // a - b mod m on canonical values
+    FrM r; uint64_t br = 0;
+    for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)a.l[i] - b.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    if (br) { unsigned __int128 c = 0; for (int i = 0; i < 4; i++) { c += (unsigned __int128)r.l[i] + m[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+    return r;
+  }
   // big-endian bytes, reduced mod r (Fr::from_slice stores the raw value and every later operation is mod r; the challenges and
   // hash_to_field reduce explicitly).  One Montgomery product per 32-byte block: mul(raw, r2) is exact for any raw < 2^256.
-  FrM from_be32(const uint8_t* b) const {
+  PL_HD FrM from_be32(const uint8_t* b) const {
     FrM raw;
     for (int i = 0; i < 4; i++) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = v << 8 | b[(3 - i) * 8 + j]; raw.l[i] = v; }
     return mul(raw, r2);
   }
-  FrM from_be_reduce(const uint8_t* b, size_t n) const {
+  PL_HD FrM from_be_reduce(const uint8_t* b, size_t n) const {
     if (n == 32) return from_be32(b);
     uint8_t pad[32];
     FrM acc = {{0, 0, 0, 0}};
@@ -199,13 +237,23 @@ struct FrCtx {
     for (size_t off = first; off < n; off += 32) acc = add(mul(acc, shift256), from_be32(b + off));
     return acc;
   }
-  void to_be(uint8_t out[32], const FrM& a) const {
+  PL_HD void to_be(uint8_t out[32], const FrM& a) const {
     FrM c = to_canon(a);
     for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[(3 - i) * 8 + j] = (uint8_t)(c.l[i] >> (56 - 8 * j));
   }
-  void to_words(uint32_t w[8], const FrM& a) const { FrM c = to_canon(a); for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)c.l[i]; w[2 * i + 1] = (uint32_t)(c.l[i] >> 32); } }
+  PL_HD void to_words(uint32_t w[8], const FrM& a) const { FrM c = to_canon(a); for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)c.l[i]; w[2 * i + 1] = (uint32_t)(c.l[i] >> 32); } }
 };
-inline const FrCtx& fr_ctx() { static const FrCtx c; return c; }
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIPCC__)
+// device copies of the field constants (raw storage: the constructors run on the host; bn254_k_plonk.hip uploads them once per device)
+__device__ uint64_t g_plonk_fr_raw[(sizeof(FrCtx) + 7) / 8];
+#endif
+PL_HD const FrCtx& fr_ctx() {
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const FrCtx*>(g_plonk_fr_raw);
+#else
+  static const FrCtx c; return c;
+#endif
+}
 // Fp on 4 x 64-bit limbs for the host-side checks of proof points: a CIOS product costs a third of the 9 x 29-bit digit product the kernels'
 // representation needs on a CPU.  k261: 2^(261 + 256) mod p, so that mul(x, k261) = x 2^261 mod p -- the digit form's Montgomery factor.
 struct Fp64Ctx {
@@ -217,7 +265,16 @@ struct Fp64Ctx {
     k261 = t;
   }
 };
-inline const Fp64Ctx& fp64_ctx() { static const Fp64Ctx c; return c; }
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIPCC__)
+__device__ uint64_t g_plonk_fp64_raw[(sizeof(Fp64Ctx) + 7) / 8];
+#endif
+PL_HD const Fp64Ctx& fp64_ctx() {
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const Fp64Ctx*>(g_plonk_fp64_raw);
+#else
+  static const Fp64Ctx c; return c;
+#endif
+}
 
 // ---------------------------------------------------------------- key and proof (plonk/converter.rs:18-178, proof.rs)
 enum { PLONK_MAX_QCP = 8, PLONK_MAX_CLAIMED = 16 };
@@ -230,7 +287,8 @@ struct PlonkKey {
   uint8_t enc[8 + PLONK_MAX_QCP][64];  // uncompressed encodings of s1..3, ql, qr, qm, qo, qk, qcp[]: what the transcript binds
   Sha256 gamma_mid;                    // SHA-256 state after "gamma" and those encodings: the key-side prefix of every proof's first challenge
 };
-inline uint64_t be64(const uint8_t* b) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = v << 8 | b[i]; return v; }
+PL_HD uint32_t pl_be32(const uint8_t* b) { return (uint32_t)b[0] << 24 | (uint32_t)b[1] << 16 | (uint32_t)b[2] << 8 | b[3]; }
+PL_HD uint64_t be64(const uint8_t* b) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = v << 8 | b[i]; return v; }
 // plonk/converter.rs:18-119.  G1 points: unchecked decompression (converter.rs:62-76); G2: converter.rs:113-133 in the reference's
 // reading of the root order; 33 788 bytes of precomputed lines are skipped (converter.rs:58).
 inline int parse_plonk_vk(PlonkKey& vk, const uint8_t* b, size_t n) {
@@ -269,7 +327,7 @@ struct PlonkProof {
 // status codes as in include/bn254_verify.h
 enum { PL_OK = 1, PL_NOT_MEMBER = 2, PL_NOT_ON_CURVE = 3, PL_INPUT_LEN = 5, PL_MALFORMED = 6, PL_OPENING = 7, PL_PAIRING = 8, PL_BSB22 = 9, PL_INVERSE = 10 };
 // converter.rs:78-88: two field members (>= p rejected), then the curve equation
-inline int dec_g1_uncompressed_checked(G1Aff& o, const uint8_t* b) {
+PL_HD int dec_g1_uncompressed_checked(G1Aff& o, const uint8_t* b) {
   const Fp64Ctx& C = fp64_ctx();
   const FrCtx& F = C.F;
   FrM x, y;
@@ -286,14 +344,14 @@ inline int dec_g1_uncompressed_checked(G1Aff& o, const uint8_t* b) {
   return on ? PL_OK : PL_NOT_ON_CURVE;
 }
 // plonk/converter.rs:121-178
-inline int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
+PL_HD int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
   const FrCtx& F = fr_ctx();
   int st;
   if (n < 516) return PL_MALFORMED;
   p.raw = b;
   G1Aff* pts[8] = {&p.lro[0], &p.lro[1], &p.lro[2], &p.z, &p.h[0], &p.h[1], &p.h[2], &p.batch_h};
   for (int i = 0; i < 8; i++) if ((st = dec_g1_uncompressed_checked(*pts[i], b + 64 * i)) != PL_OK) return st;
-  p.n_claimed = be32(b + 512);
+  p.n_claimed = pl_be32(b + 512);
   if (p.n_claimed > PLONK_MAX_CLAIMED) return PL_MALFORMED;
   size_t off = 516;
   if (n < off + 32 * (size_t)p.n_claimed + 100) return PL_MALFORMED;
@@ -302,7 +360,7 @@ inline int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
   p.off_zs_h = off;
   if ((st = dec_g1_uncompressed_checked(p.zs_h, b + off)) != PL_OK) return st;
   p.zs_value = F.from_be_reduce(b + off + 64, 32);
-  p.n_bsb = be32(b + off + 96);
+  p.n_bsb = pl_be32(b + off + 96);
   if (p.n_bsb > PLONK_MAX_QCP) return PL_MALFORMED;
   off += 100;
   if (n < off + 64 * (size_t)p.n_bsb) return PL_MALFORMED;
@@ -314,14 +372,14 @@ inline int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
 // transcript.rs:15-108: challenge = SHA-256(name | digest of the previous challenge (position > 0) | bindings in order)
 struct Challenge {
   Sha256 h;
-  Challenge(const char* name, const uint8_t* prev) { h.update(name, strlen(name)); if (prev) h.update(prev, 32); }
-  explicit Challenge(const Sha256& mid) : h(mid) {}     // continue from a saved state (name and key-side bindings already absorbed)
-  void bind(const void* d, size_t n) { h.update(d, n); }
-  FrM finish(uint8_t digest[32]) { h.finish(digest); return fr_ctx().from_be_reduce(digest, 32); }
+  PL_HD Challenge(const char* name, size_t name_len, const uint8_t* prev) { h.update(name, name_len); if (prev) h.update(prev, 32); }
+  PL_HD explicit Challenge(const Sha256& mid) : h(mid) {}     // continue from a saved state (name and key-side bindings already absorbed)
+  PL_HD void bind(const void* d, size_t n) { h.update(d, n); }
+  PL_HD FrM finish(uint8_t digest[32]) { h.finish(digest); return fr_ctx().from_be_reduce(digest, 32); }
 };
 // hash_to_field.rs:45-97: RFC 9380 expand_message_xmd(SHA-256), 48 bytes, DST "BSB22-Plonk", reduced mod r
-inline FrM bsb22_hash_to_field(const uint8_t g1_uncompressed[64]) {
-  static const char dst[] = "BSB22-Plonk";
+PL_HD FrM bsb22_hash_to_field(const uint8_t g1_uncompressed[64]) {
+  const char dst[] = "BSB22-Plonk";
   const uint8_t dl = 11;
   uint8_t b0[32], b1[32], b2[32], z[64] = {0}, lib[3] = {0, 48, 0}, idx = 1, out[48], sx[32];
   Sha256 h; h.update(z, 64); h.update(g1_uncompressed, 64); h.update(lib, 3); h.update(dst, dl); h.update(&dl, 1); h.finish(b0);
@@ -329,7 +387,8 @@ inline FrM bsb22_hash_to_field(const uint8_t g1_uncompressed[64]) {
   for (int j = 0; j < 32; j++) sx[j] = b0[j] ^ b1[j];
   idx = 2;
   h.reset(); h.update(sx, 32); h.update(&idx, 1); h.update(dst, dl); h.update(&dl, 1); h.finish(b2);
-  memcpy(out, b1, 32); memcpy(out + 32, b2, 16);
+  for (int j = 0; j < 32; j++) out[j] = b1[j];
+  for (int j = 0; j < 16; j++) out[32 + j] = b2[j];
   return fr_ctx().from_be_reduce(out, 48);
 }
 
@@ -342,7 +401,7 @@ static_assert(sizeof(MsmTerm) == 104, "term layout");
 // c1 = floor(k g1 / 2^256), c2 = floor(k g2 / 2^256) with g1 = floor(2^256 b2 / r), g2 = floor(-2^256 b1 / r);  k1 = k - c1 a1 - c2 a2,
 // k2 = -c1 b1 - c2 b2.  (tests/test_capi_cpu.py::test_glv_decomposition checks the identity and the bounds through bn254_dbg_glv_decompose.)
 struct Glv { uint64_t k1[2], k2[2]; bool neg1, neg2; };
-inline Glv glv_decompose(const FrM& kc /* canonical, < r */) {
+PL_HD Glv glv_decompose(const FrM& kc /* canonical, < r */) {
   typedef unsigned __int128 u128;
   const uint64_t A1 = 0x89d3256894d213e3ull;
   const uint64_t B1[2] = {0x8211bbeb7d4f1128ull, 0x6f4d8248eeb859fcull};        // |b1|
@@ -385,8 +444,8 @@ inline Glv glv_decompose(const FrM& kc /* canonical, < r */) {
   return g;
 }
 // flag: bit 1 / bit 2 = sign of k1 / k2 (bit 0, set by the caller, marks an identity point)
-inline void put_term(MsmTerm& t, const G1Aff& p, const FrM& k, uint8_t* flag) {
-  fp_to_limbs(t.pt, p.x); fp_to_limbs(t.pt + BN_NL, p.y);
+PL_HD void put_term(MsmTerm& t, const G1Aff& p, const FrM& k, uint8_t* flag) {
+  { const Fp cx = fp_reduce(fp_norm(p.x)), cy = fp_reduce(fp_norm(p.y)); for (int i = 0; i < BN_NL; i++) { t.pt[i] = cx.v[i]; t.pt[BN_NL + i] = cy.v[i]; } }
   const Glv g = glv_decompose(fr_ctx().to_canon(k));
   t.k[0] = (uint32_t)g.k1[0]; t.k[1] = (uint32_t)(g.k1[0] >> 32); t.k[2] = (uint32_t)g.k1[1]; t.k[3] = (uint32_t)(g.k1[1] >> 32);
   t.k[4] = (uint32_t)g.k2[0]; t.k[5] = (uint32_t)(g.k2[0] >> 32); t.k[6] = (uint32_t)g.k2[1]; t.k[7] = (uint32_t)(g.k2[1] >> 32);
@@ -399,8 +458,8 @@ struct PlonkWork {
   FrM lambda;
 };
 enum { PLONK_STAGE1_TERMS_BASE = 10 };  // + n_bsb
-inline int plonk_stage1_terms(const PlonkKey& vk) { return PLONK_STAGE1_TERMS_BASE + (int)vk.n_qcp; }
-inline int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }   // lin_digest, lro x3, s1, s2, qcp.., z, kzg_g1, batch_h, zs_h
+PL_HD int plonk_stage1_terms(const PlonkKey& vk) { return PLONK_STAGE1_TERMS_BASE + (int)vk.n_qcp; }
+PL_HD int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }   // lin_digest, lro x3, s1, s2, qcp.., z, kzg_g1, batch_h, zs_h
 
 // Stage 1 (plonk/verify.rs:46-284): everything up to the scalars of the linearised polynomial digest.  On a failed check the
 // proof's final status is returned and its terms are left zeroed.
@@ -408,14 +467,19 @@ inline int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }
 // therefore written in two halves around it -- a() up to the product `acc`, b(1 / acc) from there -- so that a batch can invert the
 // products of many proofs with a single inversion (bn254_capi.hip::plonk_run); plonk_stage1() below runs both halves for one proof.
 struct PlonkStage1 {
-  enum { MAXDEN = 2 + 64 + PLONK_MAX_QCP };
+#if defined(__HIP_DEVICE_COMPILE__)
+  enum { MAXIN = 8 };    // a lane keeps the stage's arrays in its private memory: the batched inversion covers 8 public inputs, further ones invert singly
+#else
+  enum { MAXIN = 64 };
+#endif
+  enum { MAXDEN = 2 + MAXIN + PLONK_MAX_QCP };
   const PlonkKey* vkp; const uint8_t* proof; const uint8_t* inputs; size_t n_inputs; PlonkWork* wkp;
   FrM alpha, beta, gamma, zeta, zeta_n, zh_zeta, acc;
   FrM den[MAXDEN], pre[MAXDEN]; bool zero[MAXDEN]; int nden; size_t n_in;
-  int a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk);
-  int b(const FrM& acc_inv, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */);
+  PL_HD int a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk);
+  PL_HD int b(const FrM& acc_inv, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */);
 };
-inline int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk) {
+PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk) {
   const FrCtx& F = fr_ctx();
   vkp = &vk; proof = proof_; inputs = inputs_; n_inputs = n_inputs_; wkp = &wk;
   PlonkProof& pr = wk.pr;
@@ -431,12 +495,12 @@ inline int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proo
   cg.bind(inputs, 32 * n_inputs);                                         // the public inputs as stored (raw big-endian)
   cg.bind(proof, 192);                                                    // l, r, o
   gamma = cg.finish(dg);
-  Challenge cb("beta", dg); beta = cb.finish(db);
-  Challenge ca("alpha", db);
+  Challenge cb("beta", 4, dg); beta = cb.finish(db);
+  Challenge ca("alpha", 5, db);
   ca.bind(proof + pr.off_bsb, 64 * (size_t)pr.n_bsb);
   ca.bind(proof + 192, 64);                                               // z
   alpha = ca.finish(da);
-  Challenge cz("zeta", da);
+  Challenge cz("zeta", 4, da);
   cz.bind(proof + 256, 192);                                              // h0, h1, h2
   zeta = cz.finish(dz);
   wk.zeta = zeta;
@@ -450,7 +514,7 @@ inline int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proo
   // BSB22 division by zero gives zero.
   nden = 0;
   den[nden++] = zm1;
-  n_in = n_inputs <= 64 ? n_inputs : 64;   // larger public-input counts fall back to per-term inversions below
+  n_in = n_inputs <= (size_t)MAXIN ? n_inputs : (size_t)MAXIN;   // larger public-input counts fall back to per-term inversions below
   {
     FrM accw = one;
     for (size_t i = 0; i < n_in; i++) { den[nden++] = F.sub(zeta, accw); accw = F.mul(accw, vk.generator); }
@@ -460,7 +524,7 @@ inline int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proo
   for (int i = 0; i < nden; i++) { zero[i] = F.is_zero(den[i]); pre[i] = acc; if (!zero[i]) acc = F.mul(acc, den[i]); }
   return PL_OK;
 }
-inline int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
+PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   const FrCtx& F = fr_ctx();
   const PlonkKey& vk = *vkp; PlonkWork& wk = *wkp; PlonkProof& pr = wk.pr;
   const FrM one = F.one;
@@ -530,7 +594,7 @@ inline int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   put(pr.h[0], zh); put(pr.h[1], zn2); put(pr.h[2], zn2sq);
   return PL_OK;
 }
-inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
+PL_HD int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
                         PlonkWork& wk, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */) {
   PlonkStage1 s;
   int st = s.a(vk, proof, proof_len, inputs, n_inputs, wk);
@@ -543,7 +607,7 @@ inline int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_l
 //   P0 = sum_i gamma^i D_i + lambda Z - fe G_kzg + zeta H_batch + lambda zeta omega H_zs      (plonk_stage2_terms(vk) terms)
 //   P1 = -(H_batch + lambda H_zs)                                                              (2 terms)
 // for the check e(P0, g2[0]) e(P1, g2[1]) == 1 (kzg.rs:175-187).  t1 must be t0 + plonk_stage2_terms(vk): one flag array (t0_inf) covers both.
-inline void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWork& wk, const uint32_t lin_words[16], bool lin_inf,
+PL_HD void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWork& wk, const uint32_t lin_words[16], bool lin_inf,
                          MsmTerm* t0, uint8_t* t0_inf, MsmTerm* t1) {
   const FrCtx& F = fr_ctx();
   const PlonkProof& pr = wk.pr;
@@ -551,11 +615,15 @@ inline void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWo
   // the digests in folding order: linearised polynomial, l, r, o, s1, s2, qcp...
   uint8_t lin_enc[64];
   G1Aff lin;
-  if (lin_inf) { memset(lin_enc, 0, 64); lin.x = fp_zero(); lin.y = fp_zero(); }
-  else { lin.x = fp_from_words(lin_words); lin.y = fp_from_words(lin_words + 8); enc_g1_uncompressed(lin_enc, lin); }
+  if (lin_inf) { for (int j = 0; j < 64; j++) lin_enc[j] = 0; lin.x = fp_zero(); lin.y = fp_zero(); }
+  else {
+    // the MSM result arrives as canonical little-endian words: its big-endian encoding is a byte shuffle, its digit form one product each
+    lin.x = fp_from_words(lin_words); lin.y = fp_from_words(lin_words + 8);
+    words_to_be(lin_enc, lin_words); words_to_be(lin_enc + 32, lin_words + 8);
+  }
   // kzg.rs:46-72: a fresh transcript for the folding challenge
   uint8_t b32[32], dgam[32];
-  Challenge cg("gamma", nullptr);
+  Challenge cg("gamma", 5, nullptr);
   F.to_be(b32, wk.zeta); cg.bind(b32, 32);
   cg.bind(lin_enc, 64);
   cg.bind(proof, 192);                                      // l, r, o
@@ -574,7 +642,7 @@ inline void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWo
   FrM fe = F.add(folded_eval, F.mul(pr.zs_value, lam));
   FrM shifted = F.mul(wk.zeta, vk.generator);
   int np = 0;
-  memset(t0_inf, 0, (size_t)plonk_stage2_terms(vk) + 2);
+  for (int j = 0; j < plonk_stage2_terms(vk) + 2; j++) t0_inf[j] = 0;
   auto put = [&](const G1Aff& p, const FrM& k) { put_term(t0[np], p, k, &t0_inf[np]); np++; };
   t0_inf[np] = lin_inf ? 1 : 0; put(lin, gi[0]);
   put(pr.lro[0], gi[1]); put(pr.lro[1], gi[2]); put(pr.lro[2], gi[3]);

@@ -245,3 +245,20 @@ def test_glv_decomposition(pkg):
         a, b = int.from_bytes(bytes(k1), "big"), int.from_bytes(bytes(k2), "big")
         assert a < (1 << 127) and b < (1 << 127), hex(k)
         assert ((-a if n1.value else a) + (-b if n2.value else b) * LAM - k) % R == 0, hex(k)
+
+
+def test_fr_inverse_binary_gcd(pkg):
+    """The inversion of the PlonK stages (binary extended GCD on 4 x 64-bit limbs, shared by the host path and the device kernels) against Python's
+    pow and against the Fermat form it replaced, in Fr and in Fp; 0 -> 0."""
+    import random
+    L = pkg.lib()
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    rng = random.Random(12)
+    for field, mod in ((0, R), (1, P)):
+        vals = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 255, (1 << 256) - 1] + [rng.randrange(1 << 256) for _ in range(60)] + [rng.randrange(1, 1 << k) for k in (3, 17, 64, 65, 128, 200)]
+        for v in vals:
+            o1 = (C.c_uint8 * 32)(); o2 = (C.c_uint8 * 32)()
+            assert L.bn254_dbg_fr_inverse(v.to_bytes(32, "big"), o1, 0, field) == 0 and L.bn254_dbg_fr_inverse(v.to_bytes(32, "big"), o2, 1, field) == 0
+            want = pow(v % mod, -1, mod) if v % mod else 0
+            assert int.from_bytes(bytes(o1), "big") == want == int.from_bytes(bytes(o2), "big"), (field, hex(v))
