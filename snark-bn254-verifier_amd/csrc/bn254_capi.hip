@@ -1122,8 +1122,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipEventRecord(c.tk[2], c.stream));
   e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_tab, c.stream);
   HIPCK(hipEventRecord(c.tk[3], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
-  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, TT, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum2((const int32_t*)c.part, 0, T2, T2, 2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[4], c.stream));
   e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
@@ -1183,8 +1182,7 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
   HIPCK(hipEventRecord(c.tk[2], c.stream));
   if (e == hipSuccess) e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_tab, c.stream);
   HIPCK(hipEventRecord(c.tk[3], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, 0, T2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, c.stream);
-  if (e == hipSuccess) e = bn254_launch_g1_sum((const int32_t*)c.part, T2, 2, TT, m, c.ws, c.status, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_sum2((const int32_t*)c.part, 0, T2, T2, 2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 2 launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[4], c.stream));
   e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);

@@ -19,9 +19,52 @@ using namespace bn254host;
 
 namespace bn254 {
 
+// Dynamic LDS of both kernels (bn254_plonk.hpp::pl_lane_lds): [0] u32 lane stride | per lane: 64-byte SHA block, the proof's bytes, its public inputs.
+// The 64 proofs of a workgroup are copied in cooperatively -- one proof at a time, the lanes on consecutive dwords -- so that the byte-wise reads of
+// the parser and of the transcripts hit LDS instead of each lane walking its own 900 bytes of global memory.  Returns the lane's proof pointer.
+#define PL_STAGE_MAX_PROOF 1664      // 516 + 32 x 16 claimed values + 100 + 64 x 8 commitments: the most the parser reads
+#define PL_STAGE_MAX_INPUT 256       // public inputs staged up to 8; beyond that they are read from global memory
+__device__ __forceinline__ const uint8_t* pl_stage_lds(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs, size_t n_public, uint32_t n,
+                                                     uint32_t lane_stride, const uint8_t** lane_inputs) {
+  extern __shared__ uint8_t pl_dyn_lds[];
+  if (threadIdx.x == 0) *(uint32_t*)pl_dyn_lds = lane_stride;
+  const size_t pbytes = stride < PL_STAGE_MAX_PROOF ? stride : PL_STAGE_MAX_PROOF;
+  const size_t ibytes = n_public * 32 <= PL_STAGE_MAX_INPUT ? n_public * 32 : 0;
+  const uint32_t first = blockIdx.x * 64u;
+  const bool aligned = (((uintptr_t)proofs | stride | (uintptr_t)inputs) & 3) == 0;
+  for (uint32_t j = 0; j < 64; j++) {
+    const uint32_t rec = first + j;
+    if (rec >= n) break;
+    uint8_t* dst = pl_dyn_lds + 16 + (size_t)j * lane_stride + 64;
+    const uint8_t* src = proofs + (size_t)rec * stride;
+    const uint8_t* isrc = inputs + (size_t)rec * n_public * 32;
+    if (aligned) {
+      for (size_t off = 4 * (size_t)threadIdx.x; off < pbytes; off += 256) *(uint32_t*)(dst + off) = *(const uint32_t*)(src + off);
+      for (size_t off = 4 * (size_t)threadIdx.x; off < ibytes; off += 256) *(uint32_t*)(dst + ((pbytes + 3) & ~(size_t)3) + off) = *(const uint32_t*)(isrc + off);
+    } else {
+      for (size_t off = threadIdx.x; off < pbytes; off += 64) dst[off] = src[off];
+      for (size_t off = threadIdx.x; off < ibytes; off += 64) dst[((pbytes + 3) & ~(size_t)3) + off] = isrc[off];
+    }
+  }
+  __syncthreads();
+  const uint32_t i = first + threadIdx.x;
+  const uint8_t* mine = pl_dyn_lds + 16 + (size_t)threadIdx.x * lane_stride + 64;
+  *lane_inputs = ibytes ? mine + ((pbytes + 3) & ~(size_t)3) : inputs + (size_t)(i < n ? i : 0) * n_public * 32;
+  return mine;
+}
+static uint32_t pl_lane_stride(size_t stride, size_t n_public) {
+  const size_t pbytes = stride < PL_STAGE_MAX_PROOF ? stride : PL_STAGE_MAX_PROOF;
+  const size_t ibytes = n_public * 32 <= PL_STAGE_MAX_INPUT ? n_public * 32 : 0;
+  size_t dw = (64 + ((pbytes + 3) & ~(size_t)3) + ibytes) / 4;
+  if (!(dw & 1)) dw++;                 // an odd number of dwords per lane: the lanes' same-offset accesses fall on different banks
+  return (uint32_t)(dw * 4);
+}
+
 __global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs,
                                                      size_t n_public, uint32_t n, ChaChaKey lam_key, PlonkWork* __restrict__ work, MsmTerm* __restrict__ terms,
-                                                     uint8_t* __restrict__ flags, int T1) {
+                                                     uint8_t* __restrict__ flags, int T1, uint32_t lane_stride) {
+  const uint8_t* my_inputs;
+  const uint8_t* my_proof = pl_stage_lds(proofs, stride, inputs, n_public, n, lane_stride, &my_inputs);
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   if (i >= n) return;
   const FrCtx& F = fr_ctx();
@@ -38,7 +81,7 @@ __global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict_
   uint8_t* fl = flags + (size_t)i * T1;
   for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
   PlonkStage1 s;
-  int st = s.a(*key, proofs + (size_t)i * stride, stride, inputs + (size_t)i * n_public * 32, n_public, wk);
+  int st = s.a(*key, my_proof, stride, my_inputs, n_public, wk);
   if (st == PL_OK) st = s.b(F.inverse(s.acc), t, fl);
   if (st != PL_OK) for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
   wk.status = st;
@@ -46,7 +89,9 @@ __global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict_
 
 __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, uint32_t n,
                                                      PlonkWork* __restrict__ work, const uint32_t* __restrict__ lin_words, const uint8_t* __restrict__ lin_inf,
-                                                     MsmTerm* __restrict__ terms, uint8_t* __restrict__ flags, uint8_t* __restrict__ status, int TT, int T2) {
+                                                     MsmTerm* __restrict__ terms, uint8_t* __restrict__ flags, uint8_t* __restrict__ status, int TT, int T2, uint32_t lane_stride) {
+  const uint8_t* unused_inputs;
+  const uint8_t* my_proof = pl_stage_lds(proofs, stride, proofs, 0, n, lane_stride, &unused_inputs);
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   if (i >= n) return;
   MsmTerm* t = terms + (size_t)i * TT;
@@ -54,10 +99,10 @@ __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict_
   for (int k = 0; k < TT; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
   PlonkWork& wk = work[i];
   if (wk.status == PL_OK) {
-    wk.pr.raw = proofs + (size_t)i * stride;
+    wk.pr.raw = my_proof;
     uint32_t lw[16];
     for (int q = 0; q < 16; q++) lw[q] = lin_words[(size_t)i * 16 + q];
-    plonk_stage2(*key, proofs + (size_t)i * stride, wk, lw, lin_inf[i] != 0, t, fl, t + T2);
+    plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2);
     status[i] = BN254_ST_PENDING;
   } else {
     status[i] = (uint8_t)wk.status;
@@ -88,13 +133,15 @@ hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs,
   ChaChaKey key;
   for (int i = 0; i < 8; i++) key.k[i] = lam_key[i];
   for (int i = 0; i < 3; i++) key.nonce[i] = lam_key[8 + i];
-  hipLaunchKernelGGL(k_plonk_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkKey*)d_key, d_proofs, stride, d_inputs, n_public, (uint32_t)n, key, (PlonkWork*)d_work,
-                     (MsmTerm*)d_terms, d_flags, T1);
+  const uint32_t ls = pl_lane_stride(stride, n_public);
+  hipLaunchKernelGGL(k_plonk_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, d_inputs, n_public, (uint32_t)n, key,
+                     (PlonkWork*)d_work, (MsmTerm*)d_terms, d_flags, T1, ls);
   return hipGetLastError();
 }
 hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
                                      void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s) {
-  hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words, d_lin_inf,
-                     (MsmTerm*)d_terms, d_flags, d_status, TT, T2);
+  const uint32_t ls = pl_lane_stride(stride, 0);
+  hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words,
+                     d_lin_inf, (MsmTerm*)d_terms, d_flags, d_status, TT, T2, ls);
   return hipGetLastError();
 }

@@ -114,6 +114,8 @@ hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
 hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, hipStream_t s);
 hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
+hipError_t bn254_launch_g1_sum2(const int32_t* part, int first, int count, int first_b, int count_b, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit,
+                                int e_x_b, int inf_bit_b, hipStream_t s);
 bool bn254_g1_msm_split(size_t n, int n_terms);   // the scalar-multiplication launch uses two lanes per term (part needs 2 * n_terms rows)
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
                                        int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);

@@ -475,8 +475,16 @@ k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ f
 // (0, 1) for the identity, whose flag bit `inf_bit` is OR-ed into the (pending) status byte.
 __global__ void __launch_bounds__(256, 2)
 k_g1_sum_affine(const int32_t* __restrict__ part, int first, int n_terms, int second /* 0, or the row distance of the split launch's high halves */, uint32_t n,
-                uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf, int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+                uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf, int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit,
+                int first_b, int n_terms_b, int e_x_b, int inf_bit_b) {
+  // n_terms_b > 0: TWO sums per item in one launch (PlonK: P0 and P1 of the KZG check): the lanes from round_up(n, 64) on form the second one (a
+  // wavefront never mixes the two: the workspace accessor takes its element numbers from the first lane) -- the launch lasts as long as one lane's
+  // chain (an inversion), whatever the number of sums
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t n_pad = (n + 63u) & ~63u;
+  const bool second_sum = n_terms_b > 0 && g >= n_pad;
+  const uint32_t i = second_sum ? g - n_pad : (g < n ? g : 0xffffffffu);
+  if (second_sum) { first = first_b; n_terms = n_terms_b; e_x = e_x_b; inf_bit = inf_bit_b; }
   const uint32_t ii = i < n ? i : n - 1;
   G1Proj L = g1_identity();
   const int total = second ? 2 * n_terms : n_terms;
@@ -503,7 +511,8 @@ k_g1_sum_affine(const int32_t* __restrict__ part, int first, int n_terms, int se
     DevWs w(ws, n, i < n ? i : DEAD_LANE);
     La.y = fp_select(l_inf, fp_one(), La.y);
     w.st(e_x, La.x); w.st(e_x + 1, La.y);
-    if (i < n && l_inf) { uint8_t st = status[i]; if (st & BN254_ST_PENDING) status[i] = st | (uint8_t)inf_bit; }
+    // the two sums of an item may both flag their point: different bits of the same status byte -> an atomic OR
+    if (i < n && l_inf) { if (status[i] & BN254_ST_PENDING) atomicOr((unsigned int*)(status + (i & ~3u)), (unsigned int)inf_bit << (8 * (i & 3u))); }
   }
 }
 
@@ -1053,7 +1062,7 @@ hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_
                                uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
   const bool split = bn254_g1_msm_split(n, n_terms);
   launch_scalar_mul(terms, flags, n, n_terms, part, glv_tab, split, s);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, split ? n_terms : 0, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, split ? n_terms : 0, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit, 0, 0, 0, 0);
   return hipGetLastError();
 }
 // the two halves of the above separately: ONE scalar-multiplication launch can feed several sums (PlonK: P0 and P1 of the KZG check); the sums
@@ -1064,7 +1073,15 @@ hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flag
 }
 hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
   const bool split = bn254_g1_msm_split(n, launch_terms);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, part, first, count, split ? launch_terms : 0, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status, e_x, inf_bit);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, part, first, count, split ? launch_terms : 0, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status, e_x, inf_bit, 0, 0, 0, 0);
+  return hipGetLastError();
+}
+// two sums per item in ONE launch (rows [first, first + count) -> e_x / inf_bit, rows [first_b, first_b + count_b) -> e_x_b / inf_bit_b)
+hipError_t bn254_launch_g1_sum2(const int32_t* part, int first, int count, int first_b, int count_b, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit,
+                                int e_x_b, int inf_bit_b, hipStream_t s) {
+  const bool split = bn254_g1_msm_split(n, launch_terms);
+  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(((n + 63) & ~(size_t)63) + n)), dim3(256), 0, s, part, first, count, split ? launch_terms : 0, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status,
+                     e_x, inf_bit, first_b, count_b, e_x_b, inf_bit_b);
   return hipGetLastError();
 }
 // prod_t e(P_t, Q_t) == 1 for two key-side G2 points (line tables tab0, tab1) and per-item G1 points already in the workspace

@@ -29,9 +29,32 @@
 
 namespace bn254host {
 
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+// Device side: a lane's pending SHA-256 block lives in LDS, not in its private memory (a byte buffer indexed by a run-time fill level would be
+// scratch: a vector-memory round trip per byte, with one wavefront per SIMD to hide it).  The kernels of bn254_k_plonk.hip lay their dynamic LDS out as
+//   [0] u32 lane stride in bytes | 16 + lane * stride: [0, 64) this lane's SHA block, [64, ...) its proof bytes, then its public inputs
+// and a lane hashes with ONE Sha256 object at a time (the transcripts are sequential), so the slot needs no owner.
+__device__ __forceinline__ uint8_t* pl_lane_lds() {
+  extern __shared__ uint8_t pl_dyn_lds[];
+  return pl_dyn_lds + 16 + (size_t)threadIdx.x * *(const uint32_t*)pl_dyn_lds;
+}
+#define PL_SHA_BUF() pl_lane_lds()
+#else
+#define PL_SHA_BUF() buf
+#endif
+
 // ---------------------------------------------------------------- SHA-256 (FIPS 180-4), transcript.rs / hash_to_field.rs use sha2
 struct Sha256 {
   uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill;
+  // continue from a saved state (the key-side prefix of a transcript): on the device the pending bytes move into this lane's LDS slot
+  PL_HD void adopt(const Sha256& src) {
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+    uint8_t* b = PL_SHA_BUF();
+    for (size_t q = 0; q < src.fill; q++) b[q] = src.buf[q];
+#else
+    (void)src;
+#endif
+  }
   PL_HD Sha256() { reset(); }
   PL_HD void reset() {
     const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
@@ -95,15 +118,22 @@ struct Sha256 {
       0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
       0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
       0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
-    uint32_t w[64];
+    // a rolling 16-word schedule, fully unrolled: every index is static, so the words stay in registers on the device
+    uint32_t w[16];
+#pragma unroll
     for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
-    for (int i = 16; i < 64; i++) {
-      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
-      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
     for (int i = 0; i < 64; i++) {
-      uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      uint32_t wi;
+      if (i < 16) wi = w[i];
+      else {
+        const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+        const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3), s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+        wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        w[i & 15] = wi;
+      }
+      uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + wi;
       uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
@@ -113,9 +143,10 @@ struct Sha256 {
     const uint8_t* p = (const uint8_t*)data; len += n;
     while (n) {
       size_t k = 64 - fill < n ? 64 - fill : n;
-      for (size_t q = 0; q < k; q++) buf[fill + q] = p[q];
+      uint8_t* bb = PL_SHA_BUF();
+      for (size_t q = 0; q < k; q++) bb[fill + q] = p[q];
       fill += k; p += k; n -= k;
-      if (fill == 64) { block(buf); fill = 0; }
+      if (fill == 64) { block(bb); fill = 0; }
     }
   }
   PL_HD void finish(uint8_t out[32]) {
@@ -373,7 +404,7 @@ PL_HD int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
 struct Challenge {
   Sha256 h;
   PL_HD Challenge(const char* name, size_t name_len, const uint8_t* prev) { h.update(name, name_len); if (prev) h.update(prev, 32); }
-  PL_HD explicit Challenge(const Sha256& mid) : h(mid) {}     // continue from a saved state (name and key-side bindings already absorbed)
+  PL_HD explicit Challenge(const Sha256& mid) : h(mid) { h.adopt(mid); }     // continue from a saved state (name and key-side bindings already absorbed)
   PL_HD void bind(const void* d, size_t n) { h.update(d, n); }
   PL_HD FrM finish(uint8_t digest[32]) { h.finish(digest); return fr_ctx().from_be_reduce(digest, 32); }
 };
