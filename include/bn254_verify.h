@@ -232,6 +232,11 @@ int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, siz
 int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int device);                       /* 1 = in G2 (gnark's psi relation, one kernel) */
 int bn254_dbg_g2_subgroup_ate(const uint8_t* g1, const uint8_t* g2, uint8_t* out_flags, size_t n, int device); /* 1 = in G2: the product's test, from the Miller loop's final point (g1: any G1 points) */
 
+/* stage 1 of the PlonK path as the DEVICE runs it (csrc/bn254_k_plonk.hip), for n proofs: zeta -- the last of the four chained Fiat-Shamir challenges
+ * (plonk/verify.rs:62-95), 32-byte big-endian, canonical -- and the stage's status per proof (BN254_ACCEPT: alive; else the error it decided) */
+int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n,
+                           uint8_t* zeta_out, uint8_t* status_out, int device);
+
 /* host-only probe of the GLV scalar decomposition the PlonK MSMs use: k = (-1)^neg1 k1 + (-1)^neg2 k2 lambda (mod r), k1, k2 < 2^127 */
 int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2);
 

@@ -39,6 +39,8 @@ hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs,
 hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
                                      void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s);
 
+hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_zeta, uint8_t* d_status, hipStream_t s);
+
 static thread_local std::string g_err;
 static std::atomic<int> g_profiling{0};
 static std::atomic<unsigned> g_prof_mask{0xffffffffu};
@@ -1372,6 +1374,32 @@ static int run_probe(size_t in_a, size_t in_b, size_t out_sz, const uint8_t* a, 
   HIPCK(hipMemcpy(o, dout.p, out_sz * n, hipMemcpyDeviceToHost));
   return BN254_OK;
 }
+// probe (tests): stage 1 of the device path alone -- zeta (32-byte big-endian, canonical; zero where the proof failed before the challenges) and the
+// stage-1 status of each proof (BN254_ACCEPT = alive, or the error code the stage decided)
+int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n,
+                           uint8_t* zeta_out, uint8_t* status_out, int device) {
+  if (!pvk || !proofs || !zeta_out || !status_out || n == 0 || n > PLONK_MAX_LAUNCH) return set_err(BN254_E_BAD_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  PlonkDev* d;
+  int rc = plonk_ensure_dev(pvk, device, &d);
+  if (rc) return rc;
+  PlonkCtx& c = d->ctx[0];
+  if ((rc = plonk_ensure_ctx(pvk, c, n))) return rc;
+  const size_t pb = n * proof_stride, ib = n * n_public * 32;
+  DevBuf in, zo, so;
+  HIPCK(hipMalloc((void**)&in.p, pb + ib + 4)); HIPCK(hipMalloc((void**)&zo.p, 32 * n)); HIPCK(hipMalloc((void**)&so.p, n));
+  HIPCK(hipMemcpy(in.p, proofs, pb, hipMemcpyHostToDevice));
+  if (ib) HIPCK(hipMemcpy(in.p + pb, public_inputs, ib, hipMemcpyHostToDevice));
+  uint32_t lam_key[11] = {0};
+  hipError_t e = bn254_launch_plonk_stage1(d->d_key, in.p, proof_stride, in.p + pb, n_public, n, lam_key, c.d_work, c.terms, c.flags, plonk_stage1_terms(pvk->key), c.stream);
+  if (e == hipSuccess) e = bn254_launch_plonk_dbg_zeta(c.d_work, n, zo.p, so.p, c.stream);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("probe launch: ") + hipGetErrorString(e));
+  HIPCK(hipStreamSynchronize(c.stream));
+  HIPCK(hipMemcpy(zeta_out, zo.p, 32 * n, hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(status_out, so.p, n, hipMemcpyDeviceToHost));
+  return BN254_OK;
+}
+
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {
   return run_probe(32, 32, 32, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp_mul(x, y, o, m, nullptr); });
 }

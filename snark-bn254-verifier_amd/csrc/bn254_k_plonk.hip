@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict_
 }  // namespace bn254
 
 using namespace bn254;
+namespace bn254 { __global__ void k_plonk_dbg_zeta(const PlonkWork* __restrict__ work, uint32_t n, uint8_t* __restrict__ zeta_out, uint8_t* __restrict__ status_out); }
 size_t bn254_plonk_work_bytes() { return sizeof(PlonkWork); }
 size_t bn254_plonk_key_bytes() { return sizeof(PlonkKey); }
 // the field constants of bn254_plonk.hpp (FrCtx, Fp64Ctx: built by host constructors) -> this device's copies; once per device
@@ -143,5 +144,22 @@ hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs,
   const uint32_t ls = pl_lane_stride(stride, 0);
   hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words,
                      d_lin_inf, (MsmTerm*)d_terms, d_flags, d_status, TT, T2, ls);
+  return hipGetLastError();
+}
+
+namespace bn254 {
+// probe for the parity tests: zeta (the last of the four chained Fiat-Shamir challenges: it depends on gamma, beta and alpha) and the stage-1 status
+// of every proof as the DEVICE computed them -- canonical 32-byte big-endian values
+__global__ void k_plonk_dbg_zeta(const PlonkWork* __restrict__ work, uint32_t n, uint8_t* __restrict__ zeta_out, uint8_t* __restrict__ status_out) {
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  uint8_t z[32];
+  fr_ctx().to_be(z, work[i].zeta);
+  for (int j = 0; j < 32; j++) zeta_out[(size_t)i * 32 + j] = work[i].status == PL_OK || work[i].status == PL_OPENING ? z[j] : 0;
+  status_out[i] = (uint8_t)work[i].status;
+}
+}  // namespace bn254
+hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_zeta, uint8_t* d_status, hipStream_t s) {
+  hipLaunchKernelGGL(k_plonk_dbg_zeta, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkWork*)d_work, (uint32_t)n, d_zeta, d_status);
   return hipGetLastError();
 }

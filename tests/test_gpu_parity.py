@@ -481,3 +481,32 @@ def test_more_public_inputs(pkg, O, L):
     st = pvk.verify_batch(proofs, inputs)
     assert st == exp == O.groth16_verify_many(proofs, 256, vk, inputs, 5, n, O.MODE_REFERENCE)
     pvk.close()
+
+
+def test_plonk_device_transcripts_vs_oracle_stage_goldens(pkg, O, fixtures, L):
+    """The Fiat-Shamir chain as the DEVICE computes it (bn254_k_plonk.hip: SHA-256, the key-side prefix, gamma -> beta -> alpha -> zeta) against the oracle's
+    stage digests -- for the reference's four fixtures these are the goldens of SURVEY.md Appendix B.3 -- and the stage-1 verdicts (opening check,
+    loader errors) of mutated proofs."""
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = random.Random(33)
+    cases, vk = _plonk_cases(O, fixtures, rng, 12)
+    n = len(cases)
+    pvk = pkg.PreparedPlonkVk(vk)
+    L.bn254_dbg_plonk_stage1.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    zeta = (C.c_uint8 * (32 * n))(); st = (C.c_uint8 * n)()
+    assert L.bn254_dbg_plonk_stage1(pvk._h, b"".join(c[0] for c in cases), 904, b"".join(c[1] for c in cases), 2, n, zeta, st, 0) == 0
+    zeta = bytes(zeta); st = bytes(st)
+    alive = 0
+    for i, (p, q) in enumerate(cases):
+        ins = [int.from_bytes(q[:32], "big"), int.from_bytes(q[32:], "big")]
+        ost, dig = O.plonk_stage_digests(p, vk, ins)
+        final = O.plonk_verify(p, vk, ins)
+        if st[i] == pkg.ACCEPT:                      # alive after stage 1: the oracle must not have failed it before the KZG stage
+            assert final in (pkg.ACCEPT, 8), (i, final)
+            alive += 1
+        else:
+            assert st[i] == final, (i, st[i], final)
+        if st[i] in (pkg.ACCEPT, 7) and ost == O.ACCEPT:      # the challenges exist: zeta = digest mod r
+            assert int.from_bytes(zeta[32 * i:32 * i + 32], "big") == int.from_bytes(dig["zeta"], "big") % R, i
+    assert alive >= 4
+    pvk.close()
