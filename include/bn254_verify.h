@@ -146,8 +146,9 @@ int bn254_groth16_proof_write_raw(const uint8_t a[64], const uint8_t b[128], con
  * Replaces PlonkVerifier::verify (verifier/src/lib.rs:69-73) = load_plonk_proof_from_bytes (plonk/converter.rs:121-178) +
  * load_plonk_verifying_key_from_bytes (plonk/converter.rs:18-119, hoisted into vk_prepare) + verify_plonk
  * (plonk/verify.rs:46-317: Fiat-Shamir transcripts transcript.rs:15-108, BSB22 hash_to_field.rs:9-122, kzg::fold_proof and
- * kzg::batch_verify_multi_points plonk/kzg.rs:87-190).  The transcripts and the scalar-field arithmetic run on host threads;
- * every group operation (24 G1 scalar multiplications and the two-pair pairing check per proof) runs on the GPU.
+ * kzg::batch_verify_multi_points plonk/kzg.rs:87-190).  Everything per proof runs on the GPU: the transcripts, the hash-to-field and the scalar-field
+ * arithmetic as one-proof-per-lane kernels (csrc/bn254_k_plonk.hip, compiled from the same source as the host-thread stages that BN254_PLONK_HOST=1 still
+ * selects), every group operation (24 G1 scalar multiplications and the two-pair pairing check per proof) as before.
  * Status bytes: BN254_ACCEPT or an error code; PlonK never returns BN254_REJECT (plonk/verify.rs:316).  Each proof occupies
  * proof_stride bytes (>= its length: 904 for the SP1 circuits); public inputs are n_public x 32 big-endian bytes per proof. */
 typedef struct bn254_plonk_pvk bn254_plonk_pvk;
