@@ -34,9 +34,14 @@ namespace bn254host {
 // scratch: a vector-memory round trip per byte, with one wavefront per SIMD to hide it).  The kernels of bn254_k_plonk.hip lay their dynamic LDS out as
 //   [0] u32 lane stride in bytes | 16 + lane * stride: [0, 64) this lane's SHA block, [64, ...) its proof bytes, then its public inputs
 // and a lane hashes with ONE Sha256 object at a time (the transcripts are sequential), so the slot needs no owner.
+// The slot is addressed by its LDS offset, not through an `extern __shared__` declaration: the functions below may be compiled out of line, and
+// dynamic LDS is only nameable from the kernel itself.  The two kernels declare no static LDS, so their dynamic LDS starts at offset 0.
 __device__ __forceinline__ uint8_t* pl_lane_lds() {
-  extern __shared__ uint8_t pl_dyn_lds[];
-  return pl_dyn_lds + 16 + (size_t)threadIdx.x * *(const uint32_t*)pl_dyn_lds;
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+  const uint32_t stride = *(lds_cu32*)(uintptr_t)0;
+  lds_u8* p = (lds_u8*)(uintptr_t)(16u + threadIdx.x * stride);
+  return (uint8_t*)p;
 }
 #define PL_SHA_BUF() pl_lane_lds()
 #else
@@ -193,6 +198,36 @@ struct FrCtx {
   }
   PL_HD FrM sub(const FrM& a, const FrM& b) const { return add(a, neg(b)); }
   PL_HD FrM mul(const FrM& a, const FrM& b) const {  // CIOS Montgomery product
+#if defined(BN254_FR_MUL32)
+    // EXPERIMENT (not compiled by default): the same product on 8 x 32-bit words, the shape of gfx950's widest multiply (v_mad_u64_u32).  690 instructions
+    // on the device against 890 for the 64-bit-limb form below through __int128; bit-exact on the host and in isolation on the device
+    // (tools/exp/tmul.hip), no measurable change of the stage-1 kernel (0.97 ms either way) -- and with the inlining left to the compiler that kernel
+    // computed a wrong opening check (fine with the function pinned out of line), so the 64-bit form, which every test has run through, stays.
+    uint32_t aw[8], bw[8], mw[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { aw[2 * i] = (uint32_t)a.l[i]; aw[2 * i + 1] = (uint32_t)(a.l[i] >> 32); bw[2 * i] = (uint32_t)b.l[i]; bw[2 * i + 1] = (uint32_t)(b.l[i] >> 32);
+                                  mw[2 * i] = (uint32_t)m[i]; mw[2 * i + 1] = (uint32_t)(m[i] >> 32); }
+    const uint32_t inv32 = (uint32_t)inv;
+    uint32_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t top = 0;                                        // t[9]: at most one bit
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint64_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { c = (uint64_t)aw[j] * bw[i] + ((uint64_t)t[j] + c); t[j] = (uint32_t)c; c >>= 32; }
+      c += t[8]; t[8] = (uint32_t)c; top = (uint32_t)(c >> 32);
+      const uint32_t q = t[0] * inv32;
+      c = ((uint64_t)q * mw[0] + t[0]) >> 32;
+#pragma unroll
+      for (int j = 1; j < 8; j++) { c = (uint64_t)q * mw[j] + ((uint64_t)t[j] + c); t[j - 1] = (uint32_t)c; c >>= 32; }
+      c += t[8]; t[7] = (uint32_t)c; t[8] = top + (uint32_t)(c >> 32);
+    }
+    FrM r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)t[2 * i] | ((uint64_t)t[2 * i + 1] << 32);
+    if (t[8] || geq_m(r)) r = sub_m(r);
+    return r;
+#else
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
       unsigned __int128 c = 0;
@@ -206,6 +241,7 @@ struct FrCtx {
     FrM r = {{t[0], t[1], t[2], t[3]}};
     if (t[4] || geq_m(r)) r = sub_m(r);
     return r;
+#endif
   }
   PL_HD FrM from_u64(uint64_t v) const { FrM t = {{v, 0, 0, 0}}; return mul(t, r2); }
   PL_HD FrM from_canon(const FrM& a) const { return mul(a, r2); }          // a < r
