@@ -239,6 +239,31 @@ def test_plonk_batch_4096(pkg, O, fixtures):
     pvk.close()
 
 
+def test_plonk_calls_in_flight_on_one_key(pkg, O, fixtures):
+    """Several host threads on ONE prepared PlonK key (the library hands each call a context of the key's pool): batches of different
+    sizes -- one of them cut into two sub-batches, so that it needs two contexts at once -- must give the statuses of the calls made one after the
+    other, and those are the oracle's on the distinct cases."""
+    import threading
+    rng = random.Random(33)
+    cases, vk = _plonk_cases(O, fixtures, rng, 5)
+    exp = bytes(O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) for c in cases)
+    pb, ib = b"".join(c[0] for c in cases), b"".join(c[1] for c in cases)
+    pvk = pkg.PreparedPlonkVk(vk)
+    sizes = [4096 // len(cases), 1, 17000 // len(cases), 37, 200, 3]          # repetitions of the case list per call
+    serial = [pvk.verify_batch(pb * r, ib * r) for r in sizes]
+    assert all(s == exp * r for s, r in zip(serial, sizes))
+    out = [[None] * 3 for _ in sizes]
+    def work(j):
+        for it in range(3):
+            out[j][it] = pvk.verify_batch(pb * sizes[j], ib * sizes[j])
+    th = [threading.Thread(target=work, args=(j,)) for j in range(len(sizes))]
+    for t in th: t.start()
+    for t in th: t.join()
+    for j in range(len(sizes)):
+        assert all(o == serial[j] for o in out[j]), j
+    pvk.close()
+
+
 @pytest.mark.parametrize("n_public", [17, 40, 300, 1024])
 def test_many_public_inputs_vs_oracle(pkg, O, n_public):
     """Keys with many public inputs (BASELINE configs[4]: 1024) take the wide MSM path: the inputs of one proof are summed by
