@@ -519,8 +519,9 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       const size_t need = m < max_launch ? (m + 255) / 256 * 256 : max_launch;
       if (need > d->msm_part_cap) return set_err(BN254_E_BAD_ARG, "workspace of a key with many public inputs is smaller than the batch: bn254_groth16_reserve first");
     }
-    int parts = (!wide && n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
-    if (m <= bn254_coop_max_proofs()) parts = 1;              // one launch: the cooperative kernels take batches of this size whole
+    // Up to 65 536 proofs are one wavefront per SIMD at most: one sub-batch (13.4 against 16.9 ms at 49 152, 14.2 against 16.2 ms at 65 536 for two side by side;
+    // profiles/r03_mid_batch_sweep.txt), and up to COOP12_MAX_PROOFS the cooperative kernels take the batch whole.  Above that, n_streams sub-batches.
+    int parts = (!wide && n_streams > 1 && m > 65536) ? n_streams : 1;
     while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
     const bool concurrent = !wide && n_streams > 1 && parts > 1;
     const bool split_small = m <= (size_t)G16_SPLIT_MAX_PROOFS;   // latency mode of bn254_launch_g16

@@ -123,13 +123,18 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
 // wavefront, the whole Miller loop / final exponentiation in one launch.  (The first generation, six lanes per proof, was retired in round 3:
 // 2.95 ms against 2.11 ms at 4096 proofs; DESIGN.md section 5.4 keeps its measurements.)
 #define COOP_T_ELEM 46          // = VE_S2: where the cooperative Miller loop leaves the running G2 point for k_g16_subgroup
-#define COOP12_MAX_PROOFS 40960 // passes of 1024 wavefronts x 5 proofs, 1.98 ms each: 8 passes = 15.9 ms against 17.5 ms of the lane kernels at 40960 (tools/bench_mid.py)
+// Groth16: passes of 1024 wavefronts x 5 proofs, 1.98 ms each.  6 passes = 11.8 ms against 12.9 ms of the lane kernels (one sub-batch, k_miller_run) at 30 720 proofs;
+// 7 passes = 13.7 ms against 13.0 ms at 32 768 (profiles/r03_mid_batch_sweep.txt; until k_miller_run the hand-over was at 40 960)
+#define COOP12_MAX_PROOFS 30720
+// two-pair check of the PlonK path: its lane form is still one launch per operation, the cooperative kernel keeps the range it had
+#define COOP12_MAX_PROOFS_FIXED 40960
 hipError_t bn254_coop12_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
                                    int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
 hipError_t bn254_coop12_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
 hipError_t bn254_coop12_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
                                      int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
 static inline size_t bn254_coop_max_proofs() { return COOP12_MAX_PROOFS; }
+static inline size_t bn254_coop_max_proofs_fixed() { return COOP12_MAX_PROOFS_FIXED; }
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

@@ -905,7 +905,8 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
     // 2^16: 11 steps per launch 5.75 M proofs/s, 22: 5.71, 44: 5.60, 88: 5.49; batch 2^19: 44 best; 2^20: 88 best by 0.7 %; profiles/r03_run_steps_sweep.txt).
     // BN254_MILLER_RUN_STEPS overrides (0: the one-launch-per-step kernels k_miller_step_dbl / _add).
     static const int run_steps_env = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : -1; return v < -1 ? -1 : v; }();
-    const int run_steps = run_steps_env >= 0 ? run_steps_env : (a.n <= 65536 ? 11 : a.n <= 131072 ? 22 : a.n <= 262144 ? 44 : BN_ATE_STEPS);
+    // A batch that is ONE sub-batch (up to 65 536 proofs, see g16_enqueue) takes the whole loop in one launch: 14.23 ms against 14.29 ms with 11 steps at 65 536.
+    const int run_steps = run_steps_env >= 0 ? run_steps_env : !a.part_of_larger ? BN_ATE_STEPS : (a.n <= 65536 ? 11 : a.n <= 131072 ? 22 : a.n <= 262144 ? 44 : BN_ATE_STEPS);
     if (run_steps) vm_miller_program_runs(ops, run_steps);
     else vm_miller_program(ops, step_kinds_host(), true);
   }
@@ -1094,7 +1095,7 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1, nullptr}, nullptr};
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
-  if (coop_on && n <= bn254_coop_max_proofs()) {
+  if (coop_on && n <= bn254_coop_max_proofs_fixed()) {
     // small batch: the cooperative layout (bn254_coop12.hip), Miller loop of the two pairs and final exponentiation in ONE launch
     hipError_t e = bn254_coop12_miller_fixed(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
     if (e != hipSuccess) return e;

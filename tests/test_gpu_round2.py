@@ -225,6 +225,20 @@ def test_batch_just_above_65536(pkg, L):
     pvk.close()
 
 
+@pytest.mark.parametrize("n", [30720, 30721, 65537])
+def test_sizes_around_the_path_boundaries(pkg, O, L, n):
+    """The hand-over sizes of the exact path (round 3: cooperative kernels up to 30 720 proofs, one sub-batch of lane kernels up to 65 536, two above):
+    the generator's statuses on both sides of each boundary, the oracle on a sample that includes the last proofs."""
+    from test_gpu_parity import _mixed_sample, _oracle_sample
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540100 + n, 2, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    st = pvk.verify_batch(proofs, inputs)
+    assert st == exp
+    idx = _mixed_sample(n, 40, 3) + [n - 2, n - 1]
+    assert _oracle_sample(O, vk, proofs, inputs, 2, idx) == bytes(st[j] for j in idx)
+    pvk.close()
+
+
 def test_plonk_rejects_the_known_lambda_forgery(pkg, O, fixtures, L):
     """The (H + lambda D, H' - D) forgery against round 1's published batching constant (tests/kzg_forgery.py): the oracle run with that
     constant accepts it; the product, which now draws a fresh scalar per proof like the reference (plonk/kzg.rs:149-154), answers

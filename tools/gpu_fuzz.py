@@ -24,7 +24,7 @@ def main():
     checked = oracle_checked = 0
     for case in range(args.cases):
         n_public = rng.choice([0, 1, 2, 2, 2, 3, 5, 8, 12, 20])
-        n = rng.choice([1, 7, 63, 64, 65, 100, 333, 1000, 2049, 4096, 5000, 10240, 10241, 20000, 40960, 40961, 70001, 70001, 131073, 150000, 300000])   # the last sizes: 11 / 22 / 44 steps per k_miller_run launch
+        n = rng.choice([1, 7, 63, 64, 65, 100, 333, 1000, 2049, 4096, 5000, 10240, 10241, 20000, 30720, 30721, 40961, 65536, 65537, 70001, 131073, 150000, 300000])   # the last sizes: 11 / 22 / 44 steps per k_miller_run launch
         inv = rng.choice([0, 2, 3, 5, 16, 50])
         mode = rng.choice([pkg.VK_REFERENCE, pkg.VK_GNARK])
         seed = 0xF0220000 + rng.randrange(1 << 16)
