@@ -85,7 +85,7 @@ def plonk_batches(seed):
 
 
 th = [threading.Thread(target=g16_batches, args=(1,)), threading.Thread(target=g16_batches, args=(2,)), threading.Thread(target=g16_single, args=(3,)), threading.Thread(target=g16_wide, args=(6,)),
-      threading.Thread(target=plonk_batches, args=(4,)), threading.Thread(target=plonk_batches, args=(5,))]
+      threading.Thread(target=plonk_batches, args=(4,)), threading.Thread(target=plonk_batches, args=(5,)), threading.Thread(target=plonk_batches, args=(7,))]   # three callers on ONE PlonK key: its context pool
 for t in th: t.start()
 for t in th: t.join()
 print(json.dumps({"seconds": secs, "calls": counts, "errors": errors[:5], "all_ok": not errors}))
