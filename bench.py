@@ -109,15 +109,38 @@ class GpuVerifier:
         self.pvk.reserve(self.n, local_rank)
         self.d_proofs = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(self.dev)
         self.d_inputs = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(self.dev)
-        self.d_status = torch.zeros(self.n, dtype=torch.uint8, device=self.dev)
+        # two status buffers, used in turn: the gather of batch k reads one while batch k + 1 already writes the other
+        self.d_st = [torch.zeros(self.n, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.d_status, self.k = self.d_st[0], 0
         self.stream = torch.cuda.current_stream(self.dev)
+        self.side = torch.cuda.Stream(self.dev)     # the status gather runs here, beside the next batch
         self.flags = pkg.FLAG_RLC if args.rlc else 0
         pkg.lib().bn254_set_profiling(1)
 
     def step(self):
+        self.d_status = self.d_st[self.k & 1]
+        self.k += 1
         self.pvk.verify_batch_device(self.d_proofs.data_ptr(), self.d_inputs.data_ptr(), self.d_status.data_ptr(), self.n, 256,
                                      self.args.n_public, self.local_rank, self.stream.cuda_stream, flags=self.flags)
         return self.d_status
+
+    def gather(self, st, n_total, world):
+        """The path's one collective, enqueued on a side stream behind this batch's last kernel: the next batch starts at once (it writes the other
+        status buffer).  Returns the gathered vector and the two events that bracket the collective on the side stream."""
+        torch = self.torch
+        sharding = importlib.import_module("snark-bn254-verifier_amd.sharding")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(done)
+            a = torch.cuda.Event(enable_timing=True); a.record(self.side)
+            full = sharding.gather_status(st, n_total, world)
+            b = torch.cuda.Event(enable_timing=True); b.record(self.side)
+        return full, (a, b)
+
+    def accumulate_profile(self, on):
+        """on: the per-launch events of the selected kernels accumulate over the batches that follow (read once, after the final synchronisation)"""
+        self.pkg.lib().bn254_set_profiling(2 if on else 1)
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -170,8 +193,10 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
 
     def step():
         st = v.step()
+        if hasattr(v, "gather"):
+            return v.gather(st, n_total, world)              # the only collective of the path, beside the next batch
         t_a = v.timer()
-        full = sharding.gather_status(st, n_total, world)   # the only collective of the path
+        full = sharding.gather_status(st, n_total, world)
         t_b = v.timer()
         return full, (t_a, t_b)
 
@@ -195,22 +220,27 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
             v.select_kernels([dom])               # timed region: events around the dominant kernel's launches only
     prof, phase_ms, gathers = {}, {}, []
     per_launch = n
+    if hasattr(v, "accumulate_profile"):
+        v.accumulate_profile(True)                # the events of the dominant kernel's launches accumulate over the K steps
     fence()
     t_start = time.perf_counter()
     full = None
     for _ in range(args.steps):
+        # nothing in here waits for the GPU: K batches and their gathers are enqueued back to back (a verifier with requests pending)
         full, tg = step()
         gathers.append(tg)
-        # HIP-event durations of this step (recorded on the launch stream); reading them waits for the step's last event only,
-        # which the next step would have to wait for anyway (same stream)
-        kp, per_launch = v.kernel_profile_all()
-        for k, (cnt, ms, un) in kp.items():
-            c0, m0, u0 = prof.get(k, (0, 0.0, 0.0))
-            prof[k] = (c0 + cnt, m0 + ms, u0 + un)
-        for k, x in v.phases().items():
-            phase_ms.setdefault(k, []).append(x)
+        if os.environ.get("BENCH_SYNC_EACH_STEP") == "1":
+            v.sync()                              # experiment: the host waits for every batch (what rounds 1-3a did through the per-step profile read)
     fence()
     elapsed = time.perf_counter() - t_start
+    # HIP-event durations of the dominant kernel's launches over ALL timed steps (both sub-batch streams), phase durations of the last step
+    kp, per_launch = v.kernel_profile_all()
+    for k, (cnt, ms, un) in kp.items():
+        prof[k] = (cnt, ms, un)
+    for k, x in v.phases().items():
+        phase_ms.setdefault(k, []).append(x)
+    if hasattr(v, "accumulate_profile"):
+        v.accumulate_profile(False)
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=full.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -193,7 +193,10 @@ int bn254_sp1_fixture_parse(const uint8_t* buf, size_t len, int* variant, uint8_
  * (b) around every launch whose kernel kind is selected by bn254_set_profile_kernels (bit i = kind i, default all).
  * After the stream has been synchronised bn254_groth16_last_kernel_ms returns the phase durations and
  * bn254_groth16_kernel_profile the number of launches and the summed duration per kernel kind, together with the number of
- * proofs each launch covered (the first sub-batch when the batch is split over concurrent streams, BN254_STREAMS). */
+ * proofs each launch covered (the first sub-batch when the batch is split over concurrent streams, BN254_STREAMS).
+ * bn254_set_profiling: 0 off; 1 the event pairs of (b) are those of the LAST batch; 2 they accumulate over every batch enqueued since the last call of one of the
+ * two setters (up to 1024 launches per sub-batch stream, further ones are not recorded), so that a caller timing back-to-back batches reads them once, after its
+ * final synchronisation, instead of waiting for each batch. */
 #define BN254_G16_NUM_KERNELS 4   /* phases */
 void bn254_set_profiling(int enabled);
 void bn254_set_profile_kernels(unsigned mask);

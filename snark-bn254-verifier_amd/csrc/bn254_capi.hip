@@ -44,6 +44,7 @@ hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_
 static thread_local std::string g_err;
 static std::atomic<int> g_profiling{0};
 static std::atomic<unsigned> g_prof_mask{0xffffffffu};
+static std::atomic<unsigned> g_prof_epoch{0};   // bumped by the two profiling setters: an accumulating profile (mode 2) starts over at the next batch
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
 // Knobs of the RLC batch mode.  Initial values come from the environment, read ONCE when the library is loaded (getenv racing a host's
 // setenv is undefined behaviour); afterwards only bn254_set_rlc_params changes them.
@@ -97,7 +98,7 @@ struct DevState {
   // stream waits behind its kernels (measured: 3 GB/s instead of 55), so no stream is created that is not used
   hipStream_t aux[3] = {nullptr, nullptr, nullptr}; int aux_count = 0; hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // per-launch timing of the first sub-batch (bn254_groth16_kernel_profile)
-  std::vector<hipEvent_t> prof_ev; std::vector<uint8_t> prof_kid; G16Prof prof{0, nullptr, nullptr, 0, 0}; size_t prof_n = 0;
+  std::vector<hipEvent_t> prof_ev; std::vector<uint8_t> prof_kid; G16Prof prof{0, nullptr, nullptr, 0, 0}; size_t prof_n = 0; unsigned prof_epoch = 0;
   // the same for the SECOND sub-batch (its launches run on another stream beside the first's): bn254_groth16_kernel_profile_all
   std::vector<hipEvent_t> prof2_ev; std::vector<uint8_t> prof2_kid; G16Prof prof2{0, nullptr, nullptr, 0, 0}; bool prof2_used = false;
   RlcDev rlc;                                                       // BN254_FLAG_RLC buffers (bn254_rlc.hpp)
@@ -456,8 +457,8 @@ const char* bn254_status_string(int s) {
     default: return "unknown";
   }
 }
-void bn254_set_profiling(int enabled) { g_profiling.store(enabled); }
-void bn254_set_profile_kernels(unsigned mask) { g_prof_mask.store(mask); }
+void bn254_set_profiling(int enabled) { g_profiling.store(enabled); g_prof_epoch++; }
+void bn254_set_profile_kernels(unsigned mask) { g_prof_mask.store(mask); g_prof_epoch++; }
 int bn254_groth16_num_kernel_kinds(void) { return KID_COUNT; }
 const char* bn254_groth16_kernel_kind_name(int i) {
   if (i == KID_MSM_PARTIAL) { const char* e = getenv("BN254_WIDE_COMB"); if (!(e && atoi(e) == 0)) return "k_g16_msm_partial_comb"; }   // the table form in use
@@ -550,9 +551,16 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       }
       // the events bracket the kernels of the LAST chunk only (one chunk for n <= 2^20)
       const bool prof_this = profiling && d->ev_ready && pi == 0;
-      if (prof_this) { d->prof.mask = g_prof_mask.load(); d->prof.used = 0; d->prof_n = a.n; d->prof2.used = 0; d->prof2_used = false; }
+      // mode 1: the event pairs of THIS batch; mode 2: the pairs accumulate over the batches enqueued since the last call of a profiling setter (a caller that
+      // times many back-to-back batches reads them once at the end instead of synchronising with every batch; a full pool simply stops recording)
+      const unsigned epoch = g_prof_epoch.load();
+      const bool keep = profiling == 2 && d->prof_epoch == epoch && d->prof.used > 0;
+      if (prof_this) {
+        d->prof.mask = g_prof_mask.load(); d->prof_n = a.n; d->prof_epoch = epoch;
+        if (!keep) { d->prof.used = 0; d->prof2.used = 0; d->prof2_used = false; }
+      }
       const bool prof_second = profiling && d->ev_ready && pi == 1;
-      if (prof_second) { d->prof2.mask = g_prof_mask.load(); d->prof2.used = 0; d->prof2_used = true; }
+      if (prof_second) { d->prof2.mask = g_prof_mask.load(); if (!keep) d->prof2.used = 0; d->prof2_used = true; }
       hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : (prof_second ? &d->prof2 : nullptr));
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));

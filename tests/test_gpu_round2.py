@@ -239,6 +239,40 @@ def test_sizes_around_the_path_boundaries(pkg, O, L, n):
     pvk.close()
 
 
+def test_profile_accumulates_over_batches(pkg, L):
+    """bn254_set_profiling(2): the per-launch events of the selected kernel accumulate over back-to-back batches (bench.py reads them once after its
+    timed steps); mode 1 keeps the last batch's only; a setter call starts the accumulation over."""
+    import torch
+    n = 1 << 17
+    vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540201, 2, n, invalid_every=16, agree=True, threads=16)
+    pvk = pkg.PreparedVk(vk)
+    dev = torch.device("cuda", 0)
+    dp = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).to(dev); di = torch.frombuffer(bytearray(inputs), dtype=torch.uint8).to(dev)
+    ds = torch.zeros(n, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    run = lambda: pvk.verify_batch_device(dp.data_ptr(), di.data_ptr(), ds.data_ptr(), n, 256, 2, 0, st.cuda_stream)
+    try:
+        L.bn254_set_profiling(1)
+        pkg.set_profile_kernels(["k_miller_run"])
+        run(); run(); torch.cuda.synchronize(dev)
+        one, per = pvk.kernel_profile_all(0)
+        assert per == n // 2 and set(one) == {"k_miller_run"}
+        L.bn254_set_profiling(2)
+        run(); run(); run(); torch.cuda.synchronize(dev)
+        three, _ = pvk.kernel_profile_all(0)
+        assert three["k_miller_run"][0] == 3 * one["k_miller_run"][0]
+        assert 2.0 * one["k_miller_run"][2] < three["k_miller_run"][2] < 4.5 * one["k_miller_run"][2]       # union of the launch intervals: three batches' worth
+        pkg.set_profile_kernels(["k_miller_run"])                                                          # a setter call: start over
+        run(); torch.cuda.synchronize(dev)
+        again, _ = pvk.kernel_profile_all(0)
+        assert again["k_miller_run"][0] == one["k_miller_run"][0]
+        assert bytes(ds.cpu().numpy().tobytes()) == exp
+    finally:
+        pkg.set_profile_kernels(None)
+        L.bn254_set_profiling(0)
+        pvk.close()
+
+
 def test_plonk_rejects_the_known_lambda_forgery(pkg, O, fixtures, L):
     """The (H + lambda D, H' - D) forgery against round 1's published batching constant (tests/kzg_forgery.py): the oracle run with that
     constant accepts it; the product, which now draws a fresh scalar per proof like the reference (plonk/kzg.rs:149-154), answers
