@@ -305,7 +305,7 @@ def _valu_roofline(dom, launches_ms, per_launch, passes=None):
     traffic = (_load_json("pmc_traffic.json") or {}).get(dom)
     r = {"bound": "valu", "kernel": dom, "unit": "T mad/s", "peak": VALU_PEAK_MAD_PER_S / 1e12, "avg_launch_ms": avg_ms,
          "launches_timed": launches, "proofs_per_launch": per_launch, "union_ms": union_ms, "overlap": total_ms / union_ms if union_ms else None,
-         "traffic": (traffic["read_bytes_per_proof"] + traffic["write_bytes_per_proof"]) * per_launch if traffic else None,
+         "traffic": (traffic["read_bytes_per_proof"] + traffic["write_bytes_per_proof"]) * per_launch * (passes / max(1, launches) if traffic and traffic.get("per_pass") and passes else 1) if traffic else None,
          "note": "achieved = v_mad_[iu]64_[iu]32 per proof and launch (counted in the gfx950 code object: tools/count_mads.py -> profiles/kernel_mads.json) x proofs per "
                  "launch x launches / union of the launch intervals (HIP events around every launch of the kind on BOTH sub-batch streams inside the timed region, one time "
                  "base); `overlap` = summed launch durations / union (2 = the two streams ran the kernel side by side the whole time); avg_launch_ms is what rocprofv3's "
@@ -355,7 +355,7 @@ def _traffic_whole_path(breakdown, algo):
         if e is None:
             missing.append(k)
             continue
-        total += cnt * (e["read_bytes_per_proof"] + e["write_bytes_per_proof"])
+        total += (1 if e.get("per_pass") else cnt) * (e["read_bytes_per_proof"] + e["write_bytes_per_proof"])
     return {"counter_bytes_per_proof": total, "algorithmic_bytes_per_proof": algo, "ratio": total / algo,
             "kernels_without_counters": missing}
 

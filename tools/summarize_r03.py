@@ -84,7 +84,7 @@ except Exception:
 traffic = {k: v for k, v in old.items() if not k.startswith("_")}
 traffic["_note"] = ("HBM bytes per proof and launch of each kernel kind from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, batch 2^18, one stream, bench.py --steps 1 "
                     "--warmup 0); FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md prescribes for gfx950 (checked on k_f12_sqr, whose reads are exactly 432 B/proof), WRITE_SIZE "
-                    "(KB) as reported.  Round 3 rows (tools/summarize_r03.py) replace the round 2 rows of the same kernels; k_miller_run is ONE launch for the whole Miller loop")
+                    "(KB) as reported.  Round 3 rows (tools/summarize_r03.py) replace the round 2 rows of the same kernels; k_miller_run: bytes per pass over a sub-batch (the whole Miller loop, however many launches)")
 lines = ["kernel,launches,valu_active_frac,any_active_frac,wait_any_frac,wait_inst_frac,valu_insts_per_wave,int64_insts_per_wave,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_read_B_per_proof(2xFETCH),hbm_write_B_per_proof,"
          "ifetch_per_wave,icache_req_per_launch,icache_hit_frac,icache_miss_frac(incl_duplicates)"]
 for k in sorted(sq, key=lambda k: -sq[k]["SQ_WAVE_CYCLES"]):
@@ -92,6 +92,9 @@ for k in sorted(sq, key=lambda k: -sq[k]["SQ_WAVE_CYCLES"]):
     f_ = fs[k]["FETCH_SIZE"] / nl; w_ = ws[k]["WRITE_SIZE"] / nl
     rd = 2 * f_ * 1024 / n; wr = w_ * 1024 / n
     traffic[k] = {"read_bytes_per_proof": round(rd, 1), "write_bytes_per_proof": round(wr, 1)}
+    if k == "k_miller_run":
+        # the 88 steps run in 1, 2, 4 or 8 launches depending on the sub-batch size: bytes per PASS over a sub-batch (all its launches), as kernel_mads.json counts it
+        traffic[k] = {"read_bytes_per_proof": round(rd * nl, 1), "write_bytes_per_proof": round(wr * nl, 1), "per_pass": True, "launches_in_this_run": nl}
     req = ic[k]["SQC_ICACHE_REQ"] or 1
     lines.append("%s,%d,%.3f,%.3f,%.3f,%.3f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.4f,%.4f" % (
         k, cnt[k], c["SQ_ACTIVE_INST_VALU"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_WAIT_ANY"] / wc, c["SQ_WAIT_INST_ANY"] / wc,
@@ -104,8 +107,8 @@ json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, s
 print("\n".join(lines))
 if "k_miller_run" in sq:
     c = sq["k_miller_run"]; w = waves["k_miller_run"]; nl = cnt["k_miller_run"]
-    json.dump({"SQ_INSTS_VALU": c["SQ_INSTS_VALU"] / nl / w, "SQ_INSTS_VALU_INT64": c["SQ_INSTS_VALU_INT64"] / nl / w, "wavefronts": w,
-               "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 (r03 SQ pass): instructions per wavefront of k_miller_run (one launch = the whole Miller loop of 2^18 proofs)"},
+    json.dump({"SQ_INSTS_VALU": c["SQ_INSTS_VALU"] / w, "SQ_INSTS_VALU_INT64": c["SQ_INSTS_VALU_INT64"] / w, "wavefronts": w, "launches": nl,
+               "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 (r03 SQ pass): instructions per wavefront of k_miller_run over the whole Miller loop of 2^18 proofs (all its launches)"},
               open(os.path.join(out, "miller_run_pmc_counts.json"), "w"), indent=1)
 # the one-launch-per-step kernels' traffic in the same round (comparison)
 fs0, c0, _ = load("pmc_steps_FETCH_SIZE/**/*counter_collection.csv")
