@@ -1265,13 +1265,17 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     std::lock_guard<std::mutex> lk(pvk->mu);
     if ((rc = plonk_ensure_dev(pvk, device, &d))) return rc;
   }
-  // sub-batches: at least 512 proofs each, at most PLONK_WORKERS in flight, each at most PLONK_MAX_LAUNCH proofs per pass
+  // sub-batches: at most PLONK_WORKERS in flight (one context each), each at most PLONK_MAX_LAUNCH proofs per pass
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
   static const int max_workers = [] { const char* e = getenv("BN254_PLONK_WORKERS"); int v = e ? atoi(e) : PLONK_WORKERS; return v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v); }();
   // BN254_PLONK_HOST=1: the transcripts and the Fr arithmetic on host threads (rounds 1-2) instead of the device kernels of bn254_k_plonk.hip
   static const bool dev_stages = [] { const char* e = getenv("BN254_PLONK_HOST"); return !(e && atoi(e) != 0); }();
-  // below ~16 k proofs every GPU stage is latency-bound (one wave generation): sub-batches would only repeat those latencies side by side
-  int workers = (int)(n / 8192); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
+  // Sub-batches of at most 5120 proofs while there are contexts left: up to that size every launch of a sub-batch is one wavefront generation (the scalar-multiplication
+  // launch has 11 .. 13 lanes per proof and keeps its two-bit-window form up to 65 536 lanes), and two to four such chains side by side fill the GPU better than one
+  // chain of larger launches: 8192 proofs 9.9 -> 8.2 ms, 16 384 proofs 15.7 -> 12.9 ms (profiles/r03_batch_sweep_fine.txt); from 24 576 proofs on the rule makes no difference.
+  // (Until round 3: one sub-batch per 8192 proofs.)  BN254_PLONK_PER_WORKER overrides.
+  static const size_t per_worker = [] { const char* e = getenv("BN254_PLONK_PER_WORKER"); long v = e ? atol(e) : 5120; return (size_t)(v < 256 ? 256 : v); }();
+  int workers = (int)((n + per_worker - 1) / per_worker); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
   const size_t per = (n + workers - 1) / workers;
   PlonkLease lease(d, workers);   // waits until that many contexts are free
   for (int w = 0; w < workers; w++) { size_t m = per < (size_t)PLONK_MAX_LAUNCH ? per : (size_t)PLONK_MAX_LAUNCH; if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), m))) return rc; }
