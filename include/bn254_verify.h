@@ -151,8 +151,8 @@ int bn254_groth16_proof_write_raw(const uint8_t a[64], const uint8_t b[128], con
  * selects), every group operation (24 G1 scalar multiplications and the two-pair pairing check per proof) as before.
  * Status bytes: BN254_ACCEPT or an error code; PlonK never returns BN254_REJECT (plonk/verify.rs:316).  Each proof occupies
  * proof_stride bytes (>= its length: 904 for the SP1 circuits); public inputs are n_public x 32 big-endian bytes per proof.
- * Threads: a prepared key may be used from several host threads at once.  Each call takes one of the key's four per-device contexts (stream, device
- * buffers, pinned staging) per sub-batch -- one up to 5120 proofs, then one per 5120 proofs up to all four -- and a call that finds too few free waits; up to four batches of 4096 are therefore in
+ * Threads: a prepared key may be used from several host threads at once.  Each call takes one of the key's eight per-device contexts (stream, device
+ * buffers, pinned staging) per sub-batch -- one per 5040 proofs, up to all eight -- and a call that finds too few free waits; up to eight batches of 4096 are therefore in
  * flight on one key, which is how a verifier that always has requests pending should drive it: a single batch of that size is a chain of latency-bound
  * launches (0.76 M proofs/s), two in flight give 1.04 M proofs/s, four 1.3 M. */
 typedef struct bn254_plonk_pvk bn254_plonk_pvk;

@@ -213,7 +213,7 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 // One PlonkCtx = one sub-batch in flight: its own stream, device buffers and pinned host staging.  A batch is cut into sub-batches that worker
 // threads drive concurrently, so the host stages of one sub-batch (transcripts, Fr arithmetic) overlap the GPU stages of the others; every
 // wait is stream-scoped.
-#define PLONK_WORKERS 4
+#define PLONK_WORKERS 8
 #define PLONK_MAX_LAUNCH 65536
 struct PlonkCtx {
   size_t cap = 0;                      // proofs the buffers below hold
@@ -222,6 +222,8 @@ struct PlonkCtx {
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
   std::vector<PlonkWork> work;        // host scratch per proof (kept across calls)
   int32_t *ws = nullptr, *part = nullptr, *glv_tab = nullptr;   // glv_tab: scratch of the two-bit-window scalar multiplications (small batches)
+  size_t glv_lanes = 0;                // lanes glv_tab holds; a launch that would need more runs without the table (glv_for)
+  int32_t* glv_for(size_t m, int n_terms) const { return bn254_g1_msm_tab_lanes(m, n_terms) <= glv_lanes ? glv_tab : nullptr; }
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
   MsmTerm* h_terms = nullptr; uint8_t *h_flags = nullptr, *h_status = nullptr, *h_inf = nullptr; uint32_t* h_words = nullptr;
@@ -236,10 +238,9 @@ struct PlonkDev {
   // The contexts are handed out to calls: a call takes one per sub-batch (all at once, so two calls cannot wait for each other) and returns them when it
   // is done.  Calls on ONE prepared key from several host threads therefore run side by side, up to PLONK_WORKERS sub-batches in flight; at 4096 proofs a
   // batch is a chain of latency-bound launches that leaves most of the GPU idle, and two batches in flight verify 1.35 x as many proofs per second.
-  std::mutex pool_mu; std::condition_variable pool_cv; bool busy[PLONK_WORKERS] = {false, false, false, false};
+  std::mutex pool_mu; std::condition_variable pool_cv; bool busy[PLONK_WORKERS] = {};
   float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;   // first sub-batch of the call that finished last
 };
-static_assert(PLONK_WORKERS == 4, "PlonkDev::busy initialiser");
 struct PlonkLease {   // the contexts of one call
   PlonkDev* d; int idx[PLONK_WORKERS]; int n = 0;
   PlonkLease(PlonkDev* d_, int want) : d(d_) {
@@ -314,22 +315,24 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
     for (auto q : dp) { if (*q) (void)hipFree(*q); *q = nullptr; }
     void** hp[] = {(void**)&c.h_terms, (void**)&c.h_flags, (void**)&c.h_status, (void**)&c.h_inf, (void**)&c.h_words};
     for (auto q : hp) { if (*q) (void)hipHostFree(*q); *q = nullptr; }
-    c.cap = 0;
+    c.cap = 0; c.glv_lanes = 0;
   };
   drop();
   const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
   const size_t tmax = (size_t)(TT > T1 ? TT : T1);
-  // scratch of the two-bit-window scalar multiplications: only launches of at most 65536 lanes use it (bn254_g1_msm_tab_lanes)
-  size_t tab_lanes = bn254_g1_msm_tab_lanes(need, T1);
-  if (bn254_g1_msm_tab_lanes(need, TT) > tab_lanes) tab_lanes = bn254_g1_msm_tab_lanes(need, TT);
-  // smaller batches on the same context may use it where `need` proofs do not: a context of this capacity sees every batch size up to `need`
-  if (tab_lanes == 0 && bn254_g1_msm_tab_lanes(1, T1) != 0) tab_lanes = 65536;
+  // Scratch of the two-bit-window scalar multiplications: only launches of at most 65536 lanes use it (bn254_g1_msm_tab_lanes), and a context of this capacity
+  // sees EVERY batch size up to `need` with either term count, split over two lanes per term or not -- so the bound is the largest lane count any of them can
+  // have, not the count at `need` itself.  (Rounds 2-3 sized it from `need`: a capacity of 5120 proofs gave 56 320 lanes, and a batch of 5000 proofs, whose 13-term
+  // launch has 65 000 lanes, wrote 15 MB past the end; found when sub-batches of that size became the rule.)
+  size_t tab_lanes = 0;
+  if (bn254_g1_msm_tab_lanes(1, T1) != 0) { tab_lanes = need * tmax * 2; if (tab_lanes > 65536) tab_lanes = 65536; }
   hipError_t e = hipSuccess;
   auto dm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes ? bytes : 1); };
   auto hm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipHostMalloc(q, bytes ? bytes : 1, hipHostMallocDefault); };
   dm((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF);
   dm((void**)&c.part, need * tmax * 2 * 27 * sizeof(int32_t));     // x 2: the split scalar-multiplication launch writes two partial results per term
   if (tab_lanes) dm((void**)&c.glv_tab, tab_lanes * (size_t)G1_GLV_TAB_BYTES_PER_LANE);   // at most 65536 lanes = 117 MB
+  c.glv_lanes = tab_lanes;
   dm((void**)&c.terms, need * tmax * sizeof(MsmTerm));
   dm((void**)&c.flags, need * tmax);
   dm((void**)&c.words, need * 16 * sizeof(uint32_t));
@@ -1131,7 +1134,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)T1, hipMemcpyHostToDevice, c.stream));   // GLV signs (bn254_plonk.hpp::put_term)
   HIPCK(hipEventRecord(c.tk[0], c.stream));
-  hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_tab, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
+  hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_for(m, T1), c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[1], c.stream));
   HIPCK(hipMemcpyAsync(c.h_words, c.words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
@@ -1156,7 +1159,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * TT * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)TT, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipEventRecord(c.tk[2], c.stream));
-  e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_tab, c.stream);
+  e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_for(m, TT), c.stream);
   HIPCK(hipEventRecord(c.tk[3], c.stream));
   if (e == hipSuccess) e = bn254_launch_g1_sum2((const int32_t*)c.part, 0, T2, T2, 2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
@@ -1211,12 +1214,12 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
   const uint8_t* d_proofs = c.d_in; const uint8_t* d_inputs = c.d_in + pb;
   HIPCK(hipEventRecord(c.tk[0], c.stream));
   hipError_t e = bn254_launch_plonk_stage1(d->d_key, d_proofs, proof_stride, d_inputs, n_public, m, lam_key, c.d_work, c.terms, c.flags, T1, c.stream);
-  if (e == hipSuccess) e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_tab, c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_for(m, T1), c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 1 launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[1], c.stream));
   e = bn254_launch_plonk_stage2(d->d_key, d_proofs, proof_stride, m, c.d_work, c.words, c.inf, c.terms, c.flags, c.status, TT, T2, c.stream);
   HIPCK(hipEventRecord(c.tk[2], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_tab, c.stream);
+  if (e == hipSuccess) e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_for(m, TT), c.stream);
   HIPCK(hipEventRecord(c.tk[3], c.stream));
   if (e == hipSuccess) e = bn254_launch_g1_sum2((const int32_t*)c.part, 0, T2, T2, 2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 2 launch: ") + hipGetErrorString(e));
@@ -1265,25 +1268,28 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     std::lock_guard<std::mutex> lk(pvk->mu);
     if ((rc = plonk_ensure_dev(pvk, device, &d))) return rc;
   }
-  // sub-batches: at most PLONK_WORKERS in flight (one context each), each at most PLONK_MAX_LAUNCH proofs per pass
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
   static const int max_workers = [] { const char* e = getenv("BN254_PLONK_WORKERS"); int v = e ? atoi(e) : PLONK_WORKERS; return v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v); }();
   // BN254_PLONK_HOST=1: the transcripts and the Fr arithmetic on host threads (rounds 1-2) instead of the device kernels of bn254_k_plonk.hip
   static const bool dev_stages = [] { const char* e = getenv("BN254_PLONK_HOST"); return !(e && atoi(e) != 0); }();
-  // Sub-batches of at most 5120 proofs while there are contexts left: up to that size every launch of a sub-batch is one wavefront generation (the scalar-multiplication
-  // launch has 11 .. 13 lanes per proof and keeps its two-bit-window form up to 65 536 lanes), and two to four such chains side by side fill the GPU better than one
-  // chain of larger launches: 8192 proofs 9.9 -> 8.2 ms, 16 384 proofs 15.7 -> 12.9 ms (profiles/r03_batch_sweep_fine.txt); from 24 576 proofs on the rule makes no difference.
-  // (Until round 3: one sub-batch per 8192 proofs.)  BN254_PLONK_PER_WORKER overrides.
-  static const size_t per_worker = [] { const char* e = getenv("BN254_PLONK_PER_WORKER"); long v = e ? atol(e) : 5120; return (size_t)(v < 256 ? 256 : v); }();
-  int workers = (int)((n + per_worker - 1) / per_worker); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
-  const size_t per = (n + workers - 1) / workers;
+  // Plan (round 3): the batch is cut into up to PLONK_WORKERS contiguous sub-batches, one context and one host thread each, and every sub-batch runs in passes of
+  // at most `piece` = 5040 proofs (balanced: a sub-batch of 6144 is two passes of 3072).  5040 because up to there every launch of a pass is ONE wavefront
+  // generation and the 13-term scalar-multiplication launch (65 520 lanes) keeps its two-bit-window form; several such chains of latency-bound launches side
+  // by side fill the GPU where one chain of larger launches does not.  Measured against rounds 1-3a's plan (one sub-batch per 8192 proofs, at most four, one pass
+  // each): 8192 proofs 9.9 -> 8.3 ms, 16 384 15.7 -> 13.1 ms, 32 768 1.18 -> 1.39 M proofs/s, 131 072 1.28 -> 1.53 M proofs/s (profiles/r03_batch_sweep_fine.txt).
+  // BN254_PLONK_PIECE / BN254_PLONK_WORKERS override.  (PLONK_HOST=1 keeps the plan; its host stages then share the thread pool.)
+  static const size_t piece = [] { const char* e = getenv("BN254_PLONK_PIECE"); long v = e ? atol(e) : 5040; return (size_t)(v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? PLONK_MAX_LAUNCH : v)); }();
+  int workers = (int)((n + piece - 1) / piece); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
+  const size_t per = (n + workers - 1) / workers;                    // proofs per sub-batch
+  const size_t npass = (per + piece - 1) / piece;                    // passes of a sub-batch ...
+  const size_t pass_cap = (per + npass - 1) / npass;                 // ... of equal size
   PlonkLease lease(d, workers);   // waits until that many contexts are free
-  for (int w = 0; w < workers; w++) { size_t m = per < (size_t)PLONK_MAX_LAUNCH ? per : (size_t)PLONK_MAX_LAUNCH; if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), m))) return rc; }
+  for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap))) return rc;
   std::vector<int> rcs(workers, BN254_OK); std::vector<std::string> errs(workers);
   auto body = [&](int w) {
     const size_t lo = (size_t)w * per, hi = lo + per < n ? lo + per : n;
-    for (size_t off = lo; off < hi; off += PLONK_MAX_LAUNCH) {
-      const size_t m = hi - off < (size_t)PLONK_MAX_LAUNCH ? hi - off : (size_t)PLONK_MAX_LAUNCH;
+    for (size_t off = lo; off < hi; off += pass_cap) {
+      const size_t m = hi - off < pass_cap ? hi - off : pass_cap;
       int r = dev_stages ? plonk_run_device(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off)
                          : plonk_run(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
                                      (hw + workers - 1) / workers);

@@ -264,6 +264,24 @@ def test_plonk_calls_in_flight_on_one_key(pkg, O, fixtures):
     pvk.close()
 
 
+def test_plonk_batch_sizes_around_the_window_table_limit(pkg, O, fixtures):
+    """Regression (round 3): the scratch of the two-bit-window scalar multiplications was sized from a context's CAPACITY (a multiple of 256 proofs), while
+    the launch that uses it is chosen by the batch's own lane count -- 5000 proofs on a context of 5120 (13 terms: 65 000 lanes, 56 320 allocated), 2500 on
+    2560 with two lanes per term, 4500 on a context that an earlier call had grown to 5120 -- and wrote past its end.  Sizes on both sides of each limit
+    (65 536 lanes: 5041 proofs x 13 terms, 2520 x 13 x 2), one prepared key throughout so that the contexts keep their capacity; statuses against the oracle's."""
+    rng = random.Random(34)
+    cases, vk = _plonk_cases(O, fixtures, rng, 5)
+    exp = bytes(O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) for c in cases)
+    pb, ib = b"".join(c[0] for c in cases), b"".join(c[1] for c in cases)
+    pvk = pkg.PreparedPlonkVk(vk)
+    k = len(cases)
+    for n in (2496, 2520, 2544, 4992, 5040, 5064, 4488, 4344, 2184, 9984, 10080, 20064):
+        reps, tail = divmod(n, k)
+        st = pvk.verify_batch(pb * reps + pb[:904 * tail], ib * reps + ib[:64 * tail])
+        assert st == exp * reps + exp[:tail], n
+    pvk.close()
+
+
 @pytest.mark.parametrize("n_public", [17, 40, 300, 1024])
 def test_many_public_inputs_vs_oracle(pkg, O, n_public):
     """Keys with many public inputs (BASELINE configs[4]: 1024) take the wide MSM path: the inputs of one proof are summed by
