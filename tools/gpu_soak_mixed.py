@@ -18,7 +18,7 @@ pl_vk = open(os.path.join(ROOT, "tests", "golden", "plonk_vk.bin"), "rb").read()
 base = [(bytes.fromhex(f["raw_proof"]), b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"])) for f in fx.values() if f["variant"] == "plonk"]
 rng = random.Random(5)
 pp, pi = [], []
-for i in range(1500):
+for i in range(5200):
     p, q = base[i % len(base)]
     if i % 5 == 4:
         q = bytearray(q); q[rng.randrange(64)] ^= 1 << rng.randrange(8); q = bytes(q)
@@ -28,7 +28,7 @@ wide = pkg.synth_groth16(0xB2540C00, 300, 3000, invalid_every=9, agree=True, thr
 wide_pvk = pkg.PreparedVk(wide[0])
 plonk = pkg.PreparedPlonkVk(pl_vk)
 plonk_ref = plonk.verify_batch(ppb, pib)
-assert plonk_ref.count(bytes([pkg.ACCEPT])) == 1200
+assert plonk_ref.count(bytes([pkg.ACCEPT])) == 4160
 stop = time.time() + secs
 errors, counts, lock = [], {}, threading.Lock()
 
@@ -76,8 +76,8 @@ def g16_wide(seed):
 def plonk_batches(seed):
     r = random.Random(seed)
     while time.time() < stop and not errors:
-        n = r.choice([1, 33, 700, 1500])
-        off = r.randrange(0, 1500 - n + 1)
+        n = r.choice([1, 33, 700, 1500, 2500, 4500, 5000, 5200])      # 2500 / 4500 / 5000: the window-table limits of a context
+        off = r.randrange(0, 5200 - n + 1)
         st = plonk.verify_batch(ppb[904 * off:904 * (off + n)], pib[64 * off:64 * (off + n)], n)
         if st != plonk_ref[off:off + n]:
             errors.append(("plonk batch", n, off))
