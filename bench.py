@@ -283,6 +283,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
             dom = max(prof, key=lambda k: prof[k][1])
             out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, passes=args.steps * (2 if per_launch < n else 1))
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
+            out["valu_issue_bound"] = _valu_issue_bound(breakdown, ms_per_step, n)
             out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown, algo)
         emit(json.dumps(out))
     return out
@@ -341,6 +342,27 @@ def _valu_whole_path(breakdown, proofs_per_s_per_gpu):
     ach = mads * proofs_per_s_per_gpu
     return {"mads_per_proof": mads, "achieved": ach / 1e12, "peak": VALU_PEAK_MAD_PER_S / 1e12, "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S,
             "kernels_without_count": missing}
+
+
+def _valu_issue_bound(breakdown, ms_per_batch, proofs_per_batch_per_gpu):
+    """How close the batch runs to the issue bound of its own instruction stream: VALU instructions per proof of every kernel kind (counters: profiles/
+    kernel_valu_counts.json) x its launches per batch, priced at the measured issue rates of the two instruction classes (profiles/r01_ubench_valu.txt: a 64-bit integer
+    instruction -- multiply-add, 64-bit shift / add -- 4.48 cycles per wavefront and SIMD, a plain 32-bit one 2.45), on 1024 SIMDs at 2.4 GHz."""
+    t = _load_json("kernel_valu_counts.json")
+    if not t:
+        return None
+    cycles, missing = 0.0, []
+    for k, (cnt, _ms) in breakdown.items():
+        e = t.get(k)
+        if e is None:
+            missing.append(k)
+            continue
+        cycles += (1 if e.get("per_pass") else cnt) * (e["int64"] * 4.48 + (e["valu"] - e["int64"]) * 2.45)
+    waves_per_simd = proofs_per_batch_per_gpu / 65536.0          # 1024 SIMDs x 64 lanes
+    issue_ms = cycles * waves_per_simd / 2.4e9 * 1e3
+    return {"issue_ms_per_batch": issue_ms, "ms_per_batch": ms_per_batch, "frac": issue_ms / ms_per_batch if ms_per_batch else None, "cycles_per_proof": cycles,
+            "kernels_without_counters": missing,
+            "note": "VALU issue time of the batch's own instruction stream / its wall time (1 = nothing but instruction issue; the multiply-add roofline above is a part of it)"}
 
 
 def _traffic_whole_path(breakdown, algo):

@@ -104,6 +104,16 @@ open(os.path.join(out, tag + "_pmc_summary.csv"), "w").write(
     "# rocprofv3 --pmc passes (SQ activity | FETCH_SIZE | WRITE_SIZE | SQ_IFETCH | SQC_ICACHE_*), each its own run of: BN254_STREAMS=1 python3 bench.py --steps 1 --warmup 0 "
     "--no-cpu-baseline --no-rlc --no-configs --batch-log2 18 (one batch of 2^18 proofs, one stream)\n" + "\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+# VALU instructions per wavefront (= per lane = per proof) and launch of every kernel kind, all of them and the 64-bit integer class (multiply-adds, 64-bit shifts / adds):
+# bench.py prices them at the measured issue rates for its `valu_issue_bound` (k_miller_run: per pass over a sub-batch)
+valu = {"_note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 (batch 2^18, one stream): instructions per wavefront and launch; k_miller_run per pass (all its launches)"}
+for k in sq:
+    nl = max(cnt[k], 1); w = max(waves.get(k, 1), 1)
+    per = 1 if k == "k_miller_run" else nl
+    valu[k] = {"valu": sq[k]["SQ_INSTS_VALU"] / per / w, "int64": sq[k]["SQ_INSTS_VALU_INT64"] / per / w}
+    if k == "k_miller_run":
+        valu[k]["per_pass"] = True
+json.dump(valu, open(os.path.join(out, "kernel_valu_counts.json"), "w"), indent=1, sort_keys=True)
 print("\n".join(lines))
 if "k_miller_run" in sq:
     c = sq["k_miller_run"]; w = waves["k_miller_run"]; nl = cnt["k_miller_run"]
