@@ -253,19 +253,23 @@ def test_profile_accumulates_over_batches(pkg, L):
     run = lambda: pvk.verify_batch_device(dp.data_ptr(), di.data_ptr(), ds.data_ptr(), n, 256, 2, 0, st.cuda_stream)
     try:
         L.bn254_set_profiling(1)
-        pkg.set_profile_kernels(["k_miller_run"])
+        pkg.set_profile_kernels(None)
+        run(); torch.cuda.synchronize(dev)
+        every, _ = pvk.kernel_profile_all(0)
+        dom = max(every, key=lambda k: every[k][1])        # k_miller_run (k_miller_step_dbl under BN254_MILLER_RUN_STEPS=0)
+        pkg.set_profile_kernels([dom])
         run(); run(); torch.cuda.synchronize(dev)
         one, per = pvk.kernel_profile_all(0)
-        assert per == n // 2 and set(one) == {"k_miller_run"}
+        assert per in (n, n // 2, n // 3 + 1, n // 4) and set(one) == {dom}       # two sub-batches unless BN254_STREAMS says otherwise
         L.bn254_set_profiling(2)
         run(); run(); run(); torch.cuda.synchronize(dev)
         three, _ = pvk.kernel_profile_all(0)
-        assert three["k_miller_run"][0] == 3 * one["k_miller_run"][0]
-        assert 2.0 * one["k_miller_run"][2] < three["k_miller_run"][2] < 4.5 * one["k_miller_run"][2]       # union of the launch intervals: three batches' worth
-        pkg.set_profile_kernels(["k_miller_run"])                                                          # a setter call: start over
+        assert three[dom][0] == 3 * one[dom][0]
+        assert 2.0 * one[dom][2] < three[dom][2] < 4.5 * one[dom][2]       # union of the launch intervals: three batches' worth
+        pkg.set_profile_kernels([dom])                                     # a setter call: start over
         run(); torch.cuda.synchronize(dev)
         again, _ = pvk.kernel_profile_all(0)
-        assert again["k_miller_run"][0] == one["k_miller_run"][0]
+        assert again[dom][0] == one[dom][0]
         assert bytes(ds.cpu().numpy().tobytes()) == exp
     finally:
         pkg.set_profile_kernels(None)
