@@ -41,6 +41,11 @@ hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs,
 
 hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_zeta, uint8_t* d_status, hipStream_t s);
 
+// The HIP runtime multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues -- four by default -- and streams that share a queue run one
+// after the other: the two sub-batch streams of a large Groth16 batch then lose their overlap once a third party (RCCL) has streams too, and eight PlonK chains
+// run at 1.20 instead of 1.51 M proofs/s (profiles/r03_batch_sweep_fine.txt).  The runtime reads the variable when it initialises, at the first HIP call of the
+// process; loading this library asks for eight queues unless the environment already says something.  (No effect if the runtime is up already.)
+__attribute__((constructor)) static void bn254_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 static thread_local std::string g_err;
 static std::atomic<int> g_profiling{0};
 static std::atomic<unsigned> g_prof_mask{0xffffffffu};
