@@ -86,6 +86,15 @@ def plonk_batches(seed):
 
 th = [threading.Thread(target=g16_batches, args=(1,)), threading.Thread(target=g16_batches, args=(2,)), threading.Thread(target=g16_single, args=(3,)), threading.Thread(target=g16_wide, args=(6,)),
       threading.Thread(target=plonk_batches, args=(4,)), threading.Thread(target=plonk_batches, args=(5,)), threading.Thread(target=plonk_batches, args=(7,))]   # three callers on ONE PlonK key: its context pool
+def progress():
+    # a line a minute: a run that stays silent for minutes looks hung to whoever watches it
+    while time.time() < stop and not errors:
+        time.sleep(min(60.0, max(0.1, stop - time.time())))
+        with lock:
+            print(json.dumps({"elapsed_s": round(secs - (stop - time.time())), "calls": dict(counts)}), file=sys.stderr, flush=True)
+
+
+th.append(threading.Thread(target=progress))
 for t in th: t.start()
 for t in th: t.join()
 print(json.dumps({"seconds": secs, "calls": counts, "errors": errors[:5], "all_ok": not errors}))
