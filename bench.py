@@ -246,6 +246,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     gather_ms = sum(v.elapsed_ms(a, b) for a, b in gathers) / max(1, len(gathers))
+    breakdown_is_first_subbatch = breakdown is not None       # the warm-up's breakdown counts the launches of the FIRST sub-batch of one batch
     if breakdown is None:
         breakdown = {k: (c // args.steps, m / args.steps) for k, (c, m, _u) in prof.items()}
 
@@ -281,7 +282,11 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
         }
         if prof:
             dom = max(prof, key=lambda k: prof[k][1])
-            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, passes=args.steps * (2 if per_launch < n else 1))
+            # passes over a sub-batch that the recorded launches make up: launches / launches per pass (from the warm-up's per-batch breakdown of the first sub-batch);
+            # equal to steps x sub-batches unless the event pool (1024 launches per sub-batch stream) filled up during a very long run
+            per_pass_launches = breakdown.get(dom, (0, 0.0))[0] if breakdown_is_first_subbatch else 0
+            passes = prof[dom][0] / per_pass_launches if per_pass_launches else args.steps * (2 if per_launch < n else 1)
+            out["roofline"] = _valu_roofline(dom, prof[dom], per_launch, passes=passes)
             out["valu_whole_path"] = _valu_whole_path(breakdown, value / world)
             out["valu_issue_bound"] = _valu_issue_bound(breakdown, ms_per_step, n)
             out["hbm_roofline"]["traffic_bytes_per_proof"] = _traffic_whole_path(breakdown, algo)
