@@ -248,6 +248,12 @@ int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, si
 /* host-only probe of the GLV scalar decomposition the PlonK MSMs use: k = (-1)^neg1 k1 + (-1)^neg2 k2 lambda (mod r), k1, k2 < 2^127 */
 int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2);
 
+/* host-only probes of the PlonK batch plan (sub-batches side by side, proofs per sub-batch, proofs per pass) and of the sizing of the window-table scratch: a context of
+ * `capacity` proofs must hold bn254_dbg_msm_table_lanes(m, t) lanes for every batch m <= capacity and term count t <= max_terms (0 = that launch does not use the table) */
+int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per_worker, size_t* per_pass);
+size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int max_terms);
+size_t bn254_dbg_msm_table_lanes(size_t n, int n_terms);
+
 /* host-only probe of the modular inversion of the PlonK stages (binary extended GCD; which = 1: the Fermat form; field 0: Fr, 1: Fp); 32-byte big-endian in / out */
 int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field);
 

@@ -305,6 +305,20 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
   *out = &d;
   return BN254_OK;
 }
+// lanes of window-table scratch a context of capacity `need` proofs must hold: the largest launch of the table form that ANY batch of up to `need` proofs with up to `tmax`
+// terms can make (two lanes per term while that stays within 65 536 lanes)
+static size_t plonk_scratch_lanes(size_t need, int tmax) {
+  if (bn254_g1_msm_tab_lanes(1, tmax) == 0) return 0;      // the table form is switched off (BN254_MSM_W2=0)
+  size_t lanes = need * (size_t)tmax * 2;
+  return lanes > 65536 ? 65536 : lanes;
+}
+// the plan of a batch (bn254_plonk_verify_batch): sub-batches side by side, proofs per sub-batch, proofs per pass of a sub-batch
+static void plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per, size_t* pass) {
+  int w = (int)((n + piece - 1) / piece); if (w > max_workers) w = max_workers; if (w < 1) w = 1;
+  const size_t p = (n + (size_t)w - 1) / (size_t)w;
+  const size_t npass = (p + piece - 1) / piece;
+  *workers = w; *per = p; *pass = npass ? (p + npass - 1) / npass : p;
+}
 static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   if (!c.stream) {
     HIPCK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
@@ -329,8 +343,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   // sees EVERY batch size up to `need` with either term count, split over two lanes per term or not -- so the bound is the largest lane count any of them can
   // have, not the count at `need` itself.  (Rounds 2-3 sized it from `need`: a capacity of 5120 proofs gave 56 320 lanes, and a batch of 5000 proofs, whose 13-term
   // launch has 65 000 lanes, wrote 15 MB past the end; found when sub-batches of that size became the rule.)
-  size_t tab_lanes = 0;
-  if (bn254_g1_msm_tab_lanes(1, T1) != 0) { tab_lanes = need * tmax * 2; if (tab_lanes > 65536) tab_lanes = 65536; }
+  const size_t tab_lanes = plonk_scratch_lanes(need, (int)tmax);
   hipError_t e = hipSuccess;
   auto dm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes ? bytes : 1); };
   auto hm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipHostMalloc(q, bytes ? bytes : 1, hipHostMallocDefault); };
@@ -1284,10 +1297,8 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   // each): 8192 proofs 9.9 -> 8.3 ms, 16 384 15.7 -> 13.1 ms, 32 768 1.18 -> 1.39 M proofs/s, 131 072 1.28 -> 1.53 M proofs/s (profiles/r03_batch_sweep_fine.txt).
   // BN254_PLONK_PIECE / BN254_PLONK_WORKERS override.  (PLONK_HOST=1 keeps the plan; its host stages then share the thread pool.)
   static const size_t piece = [] { const char* e = getenv("BN254_PLONK_PIECE"); long v = e ? atol(e) : 5040; return (size_t)(v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? PLONK_MAX_LAUNCH : v)); }();
-  int workers = (int)((n + piece - 1) / piece); if (workers > max_workers) workers = max_workers; if (workers < 1) workers = 1;
-  const size_t per = (n + workers - 1) / workers;                    // proofs per sub-batch
-  const size_t npass = (per + piece - 1) / piece;                    // passes of a sub-batch ...
-  const size_t pass_cap = (per + npass - 1) / npass;                 // ... of equal size
+  int workers; size_t per, pass_cap;                                  // sub-batches, proofs per sub-batch, proofs per (equal-sized) pass of a sub-batch
+  plonk_plan(n, piece, max_workers, &workers, &per, &pass_cap);
   PlonkLease lease(d, workers);   // waits until that many contexts are free
   for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap))) return rc;
   std::vector<int> rcs(workers, BN254_OK); std::vector<std::string> errs(workers);
@@ -1513,6 +1524,14 @@ int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2
 
 // host-only probe of the Fr inversion the PlonK stages use (bn254_plonk.hpp::FrCtx::inverse, binary extended GCD; which = 1: the Fermat form it replaced;
 // field = 1: the same code instantiated for Fp, as the curve checks of the proof points use it).  in / out: 32-byte big-endian canonical values.
+// host-only probes of the PlonK batch plan and of the scratch sizing (tests: every pass of every plan must fit the scratch of a context of its capacity)
+int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per_worker, size_t* per_pass) {
+  if (!workers || !per_worker || !per_pass || n == 0 || piece == 0 || max_workers < 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  plonk_plan(n, piece, max_workers, workers, per_worker, per_pass);
+  return BN254_OK;
+}
+size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int max_terms) { return plonk_scratch_lanes(capacity, max_terms); }
+size_t bn254_dbg_msm_table_lanes(size_t n, int n_terms) { return bn254_g1_msm_tab_lanes(n, n_terms); }
 int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field) {
   if (!in32 || !out32) return set_err(BN254_E_BAD_ARG, "bad argument");
   const FrCtx& F = field ? fp64_ctx().F : fr_ctx();
