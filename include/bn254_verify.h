@@ -17,6 +17,8 @@
  *   - A prepared vk is immutable and may be shared between threads.  The library keeps one workspace per (key, device): batches
  *     against the same key and device are serialised by the library itself (enqueue under a per-device lock, each batch waits
  *     on the previous batch's completion event before it touches the workspace), whatever streams the callers use.
+ *     (PlonK keys hand out contexts instead and run calls side by side: see there.)  A handle must not be freed while a call that uses it is in flight
+ *     on another thread; the free functions wait for the GPU work the handle has enqueued and release its device memory.
  *   - There is NO CPU fallback: every verify entry point runs the HIP kernels and fails with BN254_E_NO_DEVICE if
  *     no gfx950 device is usable.
  */
