@@ -532,11 +532,10 @@ def device_config(pkg, local_rank, label, n_public, n, steps, warmup, seed, orac
     return out
 
 
-def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
-    """BASELINE configs[3]: PlonK batch (the reference's 4 fixtures + mutated copies, every 8th proof invalid), host buffers in, status bytes
-    out.  Statuses of the first cpu_sample proofs against the oracle; cpu_baseline = the oracle's PlonK verifier on one core."""
+def plonk_workload(batch):
+    """The PlonK batch of BASELINE configs[3]: the reference's 4 fixtures + copies with one flipped public-input bit at every 8th position.
+    Returns (vk, proof bytes, input bytes, [proof], [inputs])."""
     import random
-    from oracle import oracle as O
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))
     vk = open(os.path.join(ROOT, "tests", "golden", "plonk_vk.bin"), "rb").read()
     base = [(bytes.fromhex(f["raw_proof"]), b"".join(int(x).to_bytes(32, "big") for x in f["public_inputs"])) for f in fx.values() if f["variant"] == "plonk"]
@@ -547,7 +546,14 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
         if i % 8 == 7:
             q = bytearray(q); q[rng.randrange(64)] ^= 1 << rng.randrange(8); q = bytes(q)
         proofs.append(p); inputs.append(q)
-    pb, ib = b"".join(proofs), b"".join(inputs)
+    return vk, b"".join(proofs), b"".join(inputs), proofs, inputs
+
+
+def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
+    """BASELINE configs[3]: PlonK batch (the reference's 4 fixtures + mutated copies, every 8th proof invalid), host buffers in, status bytes
+    out.  Statuses of the first cpu_sample proofs against the oracle; cpu_baseline = the oracle's PlonK verifier on one core."""
+    from oracle import oracle as O
+    vk, pb, ib, proofs, inputs = plonk_workload(batch)
     pvk = pkg.PreparedPlonkVk(vk)
     for _ in range(warmup):
         st = pvk.verify_batch(pb, ib)

@@ -165,10 +165,12 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
                              size_t n_public, size_t n, uint8_t* status, int device);
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                        size_t n_public, uint8_t* status);
-/* Durations (ms) of the first sub-batch of the bn254_plonk_verify_batch that finished last on `device`: host stage 1, digest MSM (wall, copies included),
- * host stage 2, folding MSMs + pairing check (wall); then from HIP events on the sub-batch's stream: digest MSM kernels, the merged
- * k_g1_scalar_mul launch of stage 2, the pairing check.  lanes: scalar multiplications (= lanes) of the two k_g1_scalar_mul launches. */
-#define BN254_PLONK_NUM_TIMINGS 7
+/* Durations (ms) of the first sub-batch of the bn254_plonk_verify_batch that finished last on `device`, from HIP events on the sub-batch's stream:
+ *   [0] host: staging copy into pinned memory (with BN254_PLONK_HOST=1: stage 1 on host threads)      [1] k_plonk_stage1
+ *   [2] k_g1_msm_rows of the linearised-polynomial digest   [3] its k_g1_sum_affine                   [4] k_plonk_stage2 (BN254_PLONK_HOST=1: host stage 2)
+ *   [5] k_g1_msm_rows of the KZG check (P0 and P1)          [6] their k_g1_sum_affine                 [7] the pairing check     [8] the sub-batch, host wall time
+ * lanes: lanes (rows x items rounded up to 64) of the two k_g1_msm_rows launches. */
+#define BN254_PLONK_NUM_TIMINGS 9
 int bn254_plonk_last_timing(const bn254_plonk_pvk* pvk, int device, float ms[BN254_PLONK_NUM_TIMINGS], size_t lanes[2]);
 
 /* ---- gnark / SP1 formats, both directions (host only) ------------------------------------------------------------------
@@ -250,13 +252,18 @@ int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, si
 /* host-only probe of the GLV scalar decomposition the PlonK MSMs use: k = (-1)^neg1 k1 + (-1)^neg2 k2 lambda (mod r), k1, k2 < 2^127 */
 int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2);
 
-/* host-only probes of the PlonK batch plan (sub-batches side by side, proofs per sub-batch, proofs per pass) and of the sizing of the window-table scratch: a context of
- * `capacity` proofs must hold bn254_dbg_msm_table_lanes(m, t) lanes for every batch m <= capacity and term count t <= max_terms (0 = that launch does not use the table) */
+/* host-only probes of the PlonK batch plan (sub-batches side by side, proofs per sub-batch, proofs per pass) and of the MSM launches (csrc/bn254_msm.h): the row plan of
+ * the stage-1 / stage-2 launch for a key with n_qcp commitments and n proofs under a lane budget (0 = the library's) -- rows, rows that use window-table scratch, the
+ * scratch lanes that launch needs, its longest row in the planner's cost units, rows and fixed terms per sum, optionally the rows themselves (MSM rows x 8 ints:
+ * variable term, pos_lo, pos_hi, unit term, sum, scratch slot, fixed windows [lo, hi)); and the scratch lanes a context of `capacity` proofs allocates for launches
+ * of n_var variable terms.  tests/test_capi_cpu.py: need <= allocation for every n <= capacity. */
 int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per_worker, size_t* per_pass);
-size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int max_terms);
-size_t bn254_dbg_msm_table_lanes(size_t n, int n_terms);
+size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int n_var);
+int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget, int* n_rows, int* n_var_rows, size_t* scratch_lanes, int* chain, int sum_rows[2],
+                             int fixed_terms[2], int* rows_out);
 
-/* host-only probe of the modular inversion of the PlonK stages (binary extended GCD; which = 1: the Fermat form; field 0: Fr, 1: Fp); 32-byte big-endian in / out */
+/* host-only probe of the modular inversion of the PlonK stages (which = 0: the constant-time form the stages use, 1: the Fermat form, 2: the classic
+ * shift-and-subtract binary GCD; field 0: Fr, 1: Fp); 32-byte big-endian in / out */
 int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field);
 
 /* host-only probe of the comb tables used for keys with many public inputs (csrc/bn254_host.hpp::build_comb_table): x * P computed from P's table

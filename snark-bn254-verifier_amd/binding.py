@@ -17,7 +17,8 @@ class Bn254Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libbn254_verify_amd.so")
+    # BN254_LIB_PATH: a diagnostics build of the same library (tools/plonk_stage_marks.py); never set in tests or the bench
+    return os.environ.get("BN254_LIB_PATH") or os.path.join(HERE, "libbn254_verify_amd.so")
 
 
 def build(verbose=False):
@@ -144,10 +145,10 @@ class PreparedPlonkVk:
 
     def last_timing(self, device=0):
         """Stage and kernel durations (ms) of the first sub-batch of the last verify_batch (bn254_plonk_last_timing)."""
-        ms = (C.c_float * 7)()
+        ms = (C.c_float * 9)()
         lanes = (C.c_size_t * 2)()
         _check(lib().bn254_plonk_last_timing(self._h, device, ms, lanes))
-        names = ("host_stage1", "digest_msm_wall", "host_stage2", "fold_msm_pairing_wall", "digest_msm_kernels", "k_g1_scalar_mul_stage2", "pairing_check")
+        names = ("host_copy", "k_plonk_stage1", "k_g1_msm_rows_digest", "k_g1_sum_affine_digest", "k_plonk_stage2", "k_g1_msm_rows_kzg", "k_g1_sum_affine_kzg", "pairing_check", "sub_batch_wall")
         return dict(zip(names, ms)), (lanes[0], lanes[1])
 
     def close(self):

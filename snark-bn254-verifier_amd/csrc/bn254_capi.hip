@@ -223,12 +223,11 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 struct PlonkCtx {
   size_t cap = 0;                      // proofs the buffers below hold
   hipStream_t stream = nullptr, aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t tk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // timing: digest MSM, scalar multiplications of stage 2, pairing check
-  float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
+  hipEvent_t tk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // timing: before stage 1 | after it | MSM rows | sum | stage 2 | MSM rows | sums | pairing check
+  float last_ms[BN254_PLONK_NUM_TIMINGS] = {0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
   std::vector<PlonkWork> work;        // host scratch per proof (kept across calls)
-  int32_t *ws = nullptr, *part = nullptr, *glv_tab = nullptr;   // glv_tab: scratch of the two-bit-window scalar multiplications (small batches)
-  size_t glv_lanes = 0;                // lanes glv_tab holds; a launch that would need more runs without the table (glv_for)
-  int32_t* glv_for(size_t m, int n_terms) const { return bn254_g1_msm_tab_lanes(m, n_terms) <= glv_lanes ? glv_tab : nullptr; }
+  int32_t *ws = nullptr, *part = nullptr, *glv_tab = nullptr;   // part: the rows of an MSM launch (bn254_msm.h); glv_tab: the window tables of its variable rows
+  size_t glv_lanes = 0;                // lanes glv_tab holds (plonk_scratch_lanes of the capacity); a launch checks its need against it before it is enqueued
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
   MsmTerm* h_terms = nullptr; uint8_t *h_flags = nullptr, *h_status = nullptr, *h_inf = nullptr; uint32_t* h_words = nullptr;
@@ -238,13 +237,14 @@ struct PlonkCtx {
 struct PlonkDev {
   bool ready = false;
   int32_t *tab0 = nullptr, *tab1 = nullptr, *one = nullptr;
+  int32_t* fixed_tabs = nullptr;       // byte-window tables of the key's G1 points (plonk_num_tables x 32 x 255 entries)
   void* d_key = nullptr;               // the parsed key (PlonkKey) for the device-side stages
   PlonkCtx ctx[PLONK_WORKERS];
   // The contexts are handed out to calls: a call takes one per sub-batch (all at once, so two calls cannot wait for each other) and returns them when it
   // is done.  Calls on ONE prepared key from several host threads therefore run side by side, up to PLONK_WORKERS sub-batches in flight; at 4096 proofs a
   // batch is a chain of latency-bound launches that leaves most of the GPU idle, and two batches in flight verify 1.35 x as many proofs per second.
   std::mutex pool_mu; std::condition_variable pool_cv; bool busy[PLONK_WORKERS] = {};
-  float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;   // first sub-batch of the call that finished last
+  float last_ms[BN254_PLONK_NUM_TIMINGS] = {0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;   // first sub-batch of the call that finished last
 };
 struct PlonkLease {   // the contexts of one call
   PlonkDev* d; int idx[PLONK_WORKERS]; int n = 0;
@@ -258,7 +258,7 @@ struct PlonkLease {   // the contexts of one call
     {
       std::lock_guard<std::mutex> lk(d->pool_mu);
       const PlonkCtx& c = d->ctx[idx[0]];
-      if (c.last_valid) { for (int i = 0; i < 8; i++) d->last_ms[i] = c.last_ms[i]; d->last_lanes[0] = c.last_lanes[0]; d->last_lanes[1] = c.last_lanes[1]; d->last_valid = true; }
+      if (c.last_valid) { for (int i = 0; i < BN254_PLONK_NUM_TIMINGS; i++) d->last_ms[i] = c.last_ms[i]; d->last_lanes[0] = c.last_lanes[0]; d->last_lanes[1] = c.last_lanes[1]; d->last_valid = true; }
       for (int i = 0; i < n; i++) d->busy[idx[i]] = false;
     }
     d->pool_cv.notify_all();
@@ -268,6 +268,8 @@ struct PlonkLease {   // the contexts of one call
 struct bn254_plonk_pvk {
   PlonkKey key;
   std::vector<int32_t> tab0, tab1, one;
+  std::vector<int32_t> fixed_tabs;     // bn254_host.hpp::build_window_table of every key point that enters an MSM (bn254_plonk.hpp::plonk_table_point)
+  MsmShape shape1, shape2;             // term kinds of the two MSM launches (plonk_msm1_shape / plonk_msm2_shape)
   mutable std::mutex mu;               // protects the map below (lookup / insertion / first upload); batches take contexts from the device's pool
   mutable std::map<int, PlonkDev> dev;
 };
@@ -284,17 +286,17 @@ static void plonk_ctx_free(PlonkCtx& c) {
   c = PlonkCtx();
 }
 static void plonk_dev_free(PlonkDev& d) {
-  void* ptrs[] = {d.tab0, d.tab1, d.one, d.d_key};
+  void* ptrs[] = {d.tab0, d.tab1, d.one, d.fixed_tabs, d.d_key};
   for (auto q : ptrs) if (q) (void)hipFree(q);
   for (auto& c : d.ctx) plonk_ctx_free(c);
-  d.ready = false; d.tab0 = d.tab1 = d.one = nullptr; d.d_key = nullptr;
+  d.ready = false; d.tab0 = d.tab1 = d.one = d.fixed_tabs = nullptr; d.d_key = nullptr;
 }
 static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** out) {
   int rc = check_device(device);
   if (rc) return rc;
   PlonkDev& d = pvk->dev[device];
   if (!d.ready) {
-    if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
+    if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one)) || (rc = upload(&d.fixed_tabs, pvk->fixed_tabs))) return rc;
     // the key and the field constants for the device-side stages
     if (sizeof(PlonkKey) != bn254_plonk_key_bytes()) return set_err(BN254_E_HIP, "PlonK key layout differs between the translation units");
     HIPCK(bn254_plonk_dev_init(device));
@@ -305,13 +307,18 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
   *out = &d;
   return BN254_OK;
 }
-// lanes of window-table scratch a context of capacity `need` proofs must hold: the largest launch of the table form that ANY batch of up to `need` proofs with up to `tmax`
-// terms can make (two lanes per term while that stays within 65 536 lanes)
-static size_t plonk_scratch_lanes(size_t need, int tmax) {
-  if (bn254_g1_msm_tab_lanes(1, tmax) == 0) return 0;      // the table form is switched off (BN254_MSM_W2=0)
-  size_t lanes = need * (size_t)tmax * 2;
-  return lanes > 65536 ? 65536 : lanes;
+// lanes an MSM launch may use at one wavefront per SIMD: the planner splits variable terms over two rows while the launch stays within it (bn254_msm.h)
+static size_t msm_lane_budget() { static const size_t v = [] { const char* e = getenv("BN254_MSM_LANE_BUDGET"); long x = e ? atol(e) : 65536; return (size_t)(x < 64 ? 64 : x); }(); return v; }
+// Lanes of window-table scratch a context of capacity `need` proofs must hold: the largest launch ANY batch of up to `need` proofs can make with a launch of
+// `n_var` variable terms -- split (2 n_var rows) while that stays within the budget, one row per term above.  (Rounds 2-3 sized the scratch from `need`
+// itself while the launch form follows the batch's own size, and a 5000-proof batch on a 5120-proof context wrote 15 MB past the end.)
+static size_t plonk_scratch_lanes(size_t need, int n_var) {
+  const size_t need_pad = (need + 63) & ~(size_t)63, b = msm_lane_budget() / 64 * 64;
+  size_t split = 2 * (size_t)n_var * need_pad; if (split > b) split = b;
+  const size_t full = (size_t)n_var * need_pad;
+  return split > full ? split : full;
 }
+static int shape_var(const MsmShape& sh) { int v = 0; for (int s = 0; s < sh.n_sums; s++) v += sh.n_var[s]; return v; }
 // the plan of a batch (bn254_plonk_verify_batch): sub-batches side by side, proofs per sub-batch, proofs per pass of a sub-batch
 static void plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per, size_t* pass) {
   int w = (int)((n + piece - 1) / piece); if (w > max_workers) w = max_workers; if (w < 1) w = 1;
@@ -339,17 +346,15 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
   drop();
   const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
   const size_t tmax = (size_t)(TT > T1 ? TT : T1);
-  // Scratch of the two-bit-window scalar multiplications: only launches of at most 65536 lanes use it (bn254_g1_msm_tab_lanes), and a context of this capacity
-  // sees EVERY batch size up to `need` with either term count, split over two lanes per term or not -- so the bound is the largest lane count any of them can
-  // have, not the count at `need` itself.  (Rounds 2-3 sized it from `need`: a capacity of 5120 proofs gave 56 320 lanes, and a batch of 5000 proofs, whose 13-term
-  // launch has 65 000 lanes, wrote 15 MB past the end; found when sub-batches of that size became the rule.)
-  const size_t tab_lanes = plonk_scratch_lanes(need, (int)tmax);
+  // window-table scratch of the variable rows: the bound over every batch size up to `need` and both launches (plonk_scratch_lanes)
+  const int v1 = shape_var(pvk->shape1), v2 = shape_var(pvk->shape2);
+  const size_t tab_lanes = plonk_scratch_lanes(need, v1 > v2 ? v1 : v2);
   hipError_t e = hipSuccess;
   auto dm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes ? bytes : 1); };
   auto hm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipHostMalloc(q, bytes ? bytes : 1, hipHostMallocDefault); };
   dm((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF);
-  dm((void**)&c.part, need * tmax * 2 * 27 * sizeof(int32_t));     // x 2: the split scalar-multiplication launch writes two partial results per term
-  if (tab_lanes) dm((void**)&c.glv_tab, tab_lanes * (size_t)G1_GLV_TAB_BYTES_PER_LANE);   // at most 65536 lanes = 117 MB
+  dm((void**)&c.part, need * (size_t)MSM_MAX_ROWS * 27 * sizeof(int32_t));     // one projective point per row of a launch's plan
+  dm((void**)&c.glv_tab, tab_lanes * (size_t)G1_GLV_TAB_BYTES_PER_LANE);       // 65536 lanes = 117 MB for capacities up to 8192 proofs
   c.glv_lanes = tab_lanes;
   dm((void**)&c.terms, need * tmax * sizeof(MsmTerm));
   dm((void**)&c.flags, need * tmax);
@@ -1075,6 +1080,19 @@ int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** o
   }
   p->one.resize(12 * BN_NL);
   put_fp12(p->one.data(), fp12_one());
+  // byte-window tables of the key's G1 points that enter the MSMs with per-proof scalars (plonk/verify.rs:253-284: ql, qr, qm, qo, qk, s3; plonk/kzg.rs:74-85:
+  // s1, s2, qcp[]; kzg.rs:169: the KZG generator): 32 mixed additions per term instead of a 128-step double-and-add chain
+  {
+    const int nt = plonk_num_tables(p->key);
+    const size_t per = (size_t)32 * 255 * MSM_ENTRY_DWORDS;
+    p->fixed_tabs.assign((size_t)nt * per, 0);
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > (unsigned)nt) hw = (unsigned)nt;
+    std::vector<std::thread> th;
+    for (unsigned t_ = 0; t_ < hw; t_++)
+      th.emplace_back([&, t_]() { for (int i = (int)t_; i < nt; i += (int)hw) build_window_table(p->fixed_tabs.data() + (size_t)i * per, plonk_table_point(p->key, i)); });
+    for (auto& x : th) x.join();
+  }
+  plonk_msm1_shape(p->key, p->shape1); plonk_msm2_shape(p->key, p->shape2);
   *out = p;
   return BN254_OK;
 }
@@ -1085,6 +1103,23 @@ void bn254_plonk_vk_free(bn254_plonk_pvk* pvk) {
 }
 size_t bn254_plonk_vk_num_public(const bn254_plonk_pvk* pvk) { return pvk ? (size_t)pvk->key.nb_public : 0; }
 
+// One MSM launch of a sub-batch: plan the rows for this batch size (bn254_msm.h: a pure function of the launch's term kinds, the item count and the lane
+// budget), check the plan against what the context holds -- the launch form follows the BATCH, the buffers the context's CAPACITY -- and enqueue rows + sums.
+static int plonk_msm(const PlonkDev* d, PlonkCtx& c, const MsmShape& shape, size_t m, int n_terms, bool to_words, size_t* lanes_out, hipEvent_t ev_rows) {
+  MsmPlan plan;
+  const size_t m_pad = (m + 63) & ~(size_t)63;
+  if (!msm_plan_build(plan, shape, m_pad, msm_lane_budget())) return set_err(BN254_E_BAD_ARG, "PlonK key shape needs more MSM rows than the launch supports");
+  if (m > c.cap || bn254_g1_msm_scratch_lanes(plan, m) > c.glv_lanes || (size_t)plan.n_rows > (size_t)MSM_MAX_ROWS)
+    return set_err(BN254_E_HIP, "PlonK context smaller than the launch (internal sizing error)");
+  hipError_t e = bn254_launch_g1_msm_rows(plan, (const int32_t*)c.terms, c.flags, m, n_terms, c.part, c.glv_tab, d->fixed_tabs, c.stream);
+  if (ev_rows) HIPCK(hipEventRecord(ev_rows, c.stream));
+  if (e == hipSuccess)
+    e = to_words ? bn254_launch_g1_sum_rows(plan, c.part, m, c.words, c.inf, nullptr, nullptr, 0, 0, 0, 0, c.stream)
+                 : bn254_launch_g1_sum_rows(plan, c.part, m, nullptr, nullptr, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
+  if (lanes_out) *lanes_out = (size_t)plan.n_rows * m_pad;
+  return BN254_OK;
+}
 // one sub-batch [0, m) on its context: stage 1 (host) -> digest MSM (GPU) -> stage 2 (host) -> folding MSMs + pairing check (GPU) -> statuses
 static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c, int device, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                      size_t n_public, size_t m, uint8_t* status, unsigned host_threads) {
@@ -1152,9 +1187,11 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * T1 * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)T1, hipMemcpyHostToDevice, c.stream));   // GLV signs (bn254_plonk.hpp::put_term)
   HIPCK(hipEventRecord(c.tk[0], c.stream));
-  hipError_t e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_for(m, T1), c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
-  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[1], c.stream));
+  int mrc = plonk_msm(d, c, pvk->shape1, m, T1, true, &c.last_lanes[0], c.tk[2]);
+  if (mrc) return mrc;
+  hipError_t e = hipSuccess;
+  HIPCK(hipEventRecord(c.tk[3], c.stream));
   HIPCK(hipMemcpyAsync(c.h_words, c.words, m * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipMemcpyAsync(c.h_inf, c.inf, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
@@ -1176,24 +1213,24 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
   HIPCK(hipMemcpyAsync(c.status, c.h_status, m, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.terms, c.h_terms, m * TT * sizeof(MsmTerm), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.flags, c.h_flags, m * (size_t)TT, hipMemcpyHostToDevice, c.stream));
-  HIPCK(hipEventRecord(c.tk[2], c.stream));
-  e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_for(m, TT), c.stream);
-  HIPCK(hipEventRecord(c.tk[3], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_sum2((const int32_t*)c.part, 0, T2, T2, 2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
-  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("MSM launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[4], c.stream));
+  mrc = plonk_msm(d, c, pvk->shape2, m, TT, false, &c.last_lanes[1], c.tk[5]);
+  if (mrc) return mrc;
+  HIPCK(hipEventRecord(c.tk[6], c.stream));
   e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
-  HIPCK(hipEventRecord(c.tk[5], c.stream));
+  HIPCK(hipEventRecord(c.tk[7], c.stream));
   HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
   memcpy(status, c.h_status, m);
   {
+    // slots as bn254_plonk_last_timing names them; the stages ran on host threads: [0] stage 1, [4] stage 2 are host wall times, [1] is 0
     auto t4_ = now();
-    c.last_ms[0] = (float)ms(t0, t1_); c.last_ms[1] = (float)ms(t1_, t2_); c.last_ms[2] = (float)ms(t2_, t3_); c.last_ms[3] = (float)ms(t3_, t4_);
-    HIPCK(hipEventElapsedTime(&c.last_ms[4], c.tk[0], c.tk[1])); HIPCK(hipEventElapsedTime(&c.last_ms[5], c.tk[2], c.tk[3]));
-    HIPCK(hipEventElapsedTime(&c.last_ms[6], c.tk[4], c.tk[5])); c.last_ms[7] = 0.f;
-    c.last_lanes[0] = m * (size_t)T1; c.last_lanes[1] = m * (size_t)TT; c.last_valid = true;
+    c.last_ms[0] = (float)ms(t0, t1_); c.last_ms[1] = 0.f; c.last_ms[4] = (float)ms(t2_, t3_); c.last_ms[8] = (float)ms(t0, t4_);
+    HIPCK(hipEventElapsedTime(&c.last_ms[2], c.tk[1], c.tk[2])); HIPCK(hipEventElapsedTime(&c.last_ms[3], c.tk[2], c.tk[3]));
+    HIPCK(hipEventElapsedTime(&c.last_ms[5], c.tk[4], c.tk[5])); HIPCK(hipEventElapsedTime(&c.last_ms[6], c.tk[5], c.tk[6]));
+    HIPCK(hipEventElapsedTime(&c.last_ms[7], c.tk[6], c.tk[7]));
+    c.last_valid = true;
   }
   if (timing) fprintf(stderr, "plonk sub-batch %zu: stage1 %.2f ms, msm1 %.2f ms, stage2 %.2f ms, msm2+pairing %.2f ms\n", m, ms(t0, t1_), ms(t1_, t2_), ms(t2_, t3_), ms(t3_, now()));
   return BN254_OK;
@@ -1232,30 +1269,29 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
   const uint8_t* d_proofs = c.d_in; const uint8_t* d_inputs = c.d_in + pb;
   HIPCK(hipEventRecord(c.tk[0], c.stream));
   hipError_t e = bn254_launch_plonk_stage1(d->d_key, d_proofs, proof_stride, d_inputs, n_public, m, lam_key, c.d_work, c.terms, c.flags, T1, c.stream);
-  if (e == hipSuccess) e = bn254_launch_g1_msm((const int32_t*)c.terms, c.flags, m, T1, c.part, c.glv_for(m, T1), c.words, c.inf, nullptr, nullptr, 0, 0, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 1 launch: ") + hipGetErrorString(e));
   HIPCK(hipEventRecord(c.tk[1], c.stream));
-  e = bn254_launch_plonk_stage2(d->d_key, d_proofs, proof_stride, m, c.d_work, c.words, c.inf, c.terms, c.flags, c.status, TT, T2, c.stream);
-  HIPCK(hipEventRecord(c.tk[2], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_scalar_muls((const int32_t*)c.terms, c.flags, m, TT, c.part, c.glv_for(m, TT), c.stream);
+  int mrc = plonk_msm(d, c, pvk->shape1, m, T1, true, &c.last_lanes[0], c.tk[2]);
+  if (mrc) return mrc;
   HIPCK(hipEventRecord(c.tk[3], c.stream));
-  if (e == hipSuccess) e = bn254_launch_g1_sum2((const int32_t*)c.part, 0, T2, T2, 2, TT, m, c.ws, c.status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
-  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 2 launch: ") + hipGetErrorString(e));
+  e = bn254_launch_plonk_stage2(d->d_key, d_proofs, proof_stride, m, c.d_work, c.words, c.inf, c.terms, c.flags, c.status, TT, T2, c.stream);
   HIPCK(hipEventRecord(c.tk[4], c.stream));
+  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 2 launch: ") + hipGetErrorString(e));
+  mrc = plonk_msm(d, c, pvk->shape2, m, TT, false, &c.last_lanes[1], c.tk[5]);
+  if (mrc) return mrc;
+  HIPCK(hipEventRecord(c.tk[6], c.stream));
   e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
-  HIPCK(hipEventRecord(c.tk[5], c.stream));
+  HIPCK(hipEventRecord(c.tk[7], c.stream));
   HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
   memcpy(status, c.h_status, m);
   {
     auto t4_ = now();
-    // slots as bn254_plonk_last_timing names them; the host stages are the staging copy and nothing: [0] host copy into pinned memory, [2] 0
-    c.last_ms[0] = (float)ms(t0, t1_); c.last_ms[2] = 0.f; c.last_ms[3] = (float)ms(t1_, t4_);
-    HIPCK(hipEventElapsedTime(&c.last_ms[4], c.tk[0], c.tk[1])); HIPCK(hipEventElapsedTime(&c.last_ms[5], c.tk[2], c.tk[3]));
-    HIPCK(hipEventElapsedTime(&c.last_ms[6], c.tk[4], c.tk[5])); HIPCK(hipEventElapsedTime(&c.last_ms[7], c.tk[1], c.tk[2]));
-    c.last_ms[1] = c.last_ms[4];
-    c.last_lanes[0] = m * (size_t)T1; c.last_lanes[1] = m * (size_t)TT; c.last_valid = true;
+    // slots as bn254_plonk_last_timing names them; [0] is the host copy into pinned memory, everything else a kernel of the chain
+    c.last_ms[0] = (float)ms(t0, t1_); c.last_ms[8] = (float)ms(t0, t4_);
+    for (int k = 1; k <= 7; k++) HIPCK(hipEventElapsedTime(&c.last_ms[k], c.tk[k - 1], c.tk[k]));
+    c.last_valid = true;
   }
   return BN254_OK;
 }
@@ -1530,13 +1566,34 @@ int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, 
   plonk_plan(n, piece, max_workers, workers, per_worker, per_pass);
   return BN254_OK;
 }
-size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int max_terms) { return plonk_scratch_lanes(capacity, max_terms); }
-size_t bn254_dbg_msm_table_lanes(size_t n, int n_terms) { return bn254_g1_msm_tab_lanes(n, n_terms); }
+size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int n_var) { return plonk_scratch_lanes(capacity, n_var); }
+// the row plan of one MSM launch of the PlonK path (stage 1: the digest; 2: the KZG check) for a key with n_qcp commitments and a batch of n proofs:
+// rows, rows with a window table, scratch lanes the launch needs, the longest row in the planner's cost units, rows per sum; rows_out (optional):
+// MSM_MAX_ROWS x 8 ints {variable term, pos_lo, pos_hi, unit term, sum, scratch slot, first fixed window, one past the last}
+int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget, int* n_rows, int* n_var_rows, size_t* scratch_lanes, int* chain, int sum_rows[2],
+                             int fixed_terms[2], int* rows_out) {
+  if (n_qcp < 0 || n_qcp > PLONK_MAX_QCP || (stage != 1 && stage != 2) || n == 0 || !n_rows || !n_var_rows || !scratch_lanes || !chain || !sum_rows || !fixed_terms)
+    return set_err(BN254_E_BAD_ARG, "bad argument");
+  PlonkKey key; key.n_qcp = (uint32_t)n_qcp;
+  MsmShape sh;
+  if (stage == 1) plonk_msm1_shape(key, sh); else plonk_msm2_shape(key, sh);
+  MsmPlan plan;
+  if (!msm_plan_build(plan, sh, (n + 63) & ~(size_t)63, lane_budget ? lane_budget : msm_lane_budget())) return set_err(BN254_E_BAD_ARG, "shape cannot be planned");
+  *n_rows = plan.n_rows; *n_var_rows = plan.n_var_rows; *scratch_lanes = bn254_g1_msm_scratch_lanes(plan, n); *chain = msm_plan_chain(plan);
+  for (int k = 0; k < 2; k++) { sum_rows[k] = plan.count[k]; fixed_terms[k] = plan.n_fixed[k]; }
+  if (rows_out)
+    for (int r = 0; r < plan.n_rows; r++) {
+      const MsmRow& w = plan.row[r];
+      int* o = rows_out + 8 * r;
+      o[0] = w.var_term; o[1] = w.pos_lo; o[2] = w.pos_hi; o[3] = w.unit_term; o[4] = w.sum; o[5] = w.glv_slot; o[6] = w.fw_lo; o[7] = w.fw_hi;
+    }
+  return BN254_OK;
+}
 int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field) {
   if (!in32 || !out32) return set_err(BN254_E_BAD_ARG, "bad argument");
   const FrCtx& F = field ? fp64_ctx().F : fr_ctx();
   const FrM a = F.from_be_reduce(in32, 32);
-  F.to_be(out32, which ? F.inverse_fermat(a) : F.inverse(a));
+  F.to_be(out32, which == 1 ? F.inverse_fermat(a) : which == 2 ? F.inverse_bgcd(a) : F.inverse(a));
   return BN254_OK;
 }
 

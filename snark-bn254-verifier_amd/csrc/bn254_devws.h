@@ -68,6 +68,18 @@ __device__ __forceinline__ Fp uni_ld(const int32_t* p) {
 }
 __device__ __forceinline__ Fp2 uni_ld2(const int32_t* p) { Fp2 r; r.c0 = uni_ld(p); r.c1 = uni_ld(p + BN_NL); return r; }
 
+// table entry -> affine point (80-byte entry, 16-byte aligned: five 16-byte loads)
+__device__ __forceinline__ G1Aff msm_entry(const int32_t* __restrict__ msm_tab, size_t idx) {
+  const int4* e = (const int4*)(msm_tab + idx * MSM_ENTRY_DWORDS);
+  int4 v0 = e[0], v1 = e[1], v2 = e[2], v3 = e[3], v4 = e[4];
+  G1Aff q;
+  q.x.v[0] = v0.x; q.x.v[1] = v0.y; q.x.v[2] = v0.z; q.x.v[3] = v0.w; q.x.v[4] = v1.x; q.x.v[5] = v1.y; q.x.v[6] = v1.z; q.x.v[7] = v1.w;
+  q.x.v[8] = v2.x; q.y.v[0] = v2.y; q.y.v[1] = v2.z; q.y.v[2] = v2.w; q.y.v[3] = v3.x; q.y.v[4] = v3.y; q.y.v[5] = v3.z; q.y.v[6] = v3.w;
+  q.y.v[7] = v4.x; q.y.v[8] = v4.y;
+  BN_SETB(q.x, 1.0, 0.5); BN_SETB(q.y, 1.0, 0.5);
+  return q;
+}
+
 // ---- every VM operation (bn254_vm.h) is its own kernel ------------------------------------------------------------------------
 // The VM programs (vm_miller_program, vm_final_exp_program) are host-compilable: the host walks them and enqueues one launch
 // per operation (~210 per batch, all asynchronous on the sub-batch's stream, so launch overhead hides behind the previous kernel

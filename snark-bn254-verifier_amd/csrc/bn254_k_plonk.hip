@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict_
   if (i >= n) return;
   const FrCtx& F = fr_ctx();
   PlonkWork& wk = work[i];
+  PL_MARK(0);
   {
     // the KZG batching scalar: 384 bits of the call's ChaCha20 stream (blocks 3i .. 3i+2) reduced mod r, as the host path draws it
     uint32_t lw[12];
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict_
   PlonkStage1 s;
   int st = s.a(*key, my_proof, stride, my_inputs, n_public, wk);
   if (st == PL_OK) st = s.b(F.inverse(s.acc), t, fl);
+  PL_MARK(11);
   if (st != PL_OK) for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
   wk.status = st;
 }
@@ -98,6 +100,7 @@ __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict_
   uint8_t* fl = flags + (size_t)i * TT;
   for (int k = 0; k < TT; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
   PlonkWork& wk = work[i];
+  PL_MARK(16);
   if (wk.status == PL_OK) {
     wk.pr.raw = my_proof;
     uint32_t lw[16];
@@ -159,6 +162,10 @@ __global__ void k_plonk_dbg_zeta(const PlonkWork* __restrict__ work, uint32_t n,
   status_out[i] = (uint8_t)work[i].status;
 }
 }  // namespace bn254
+#if defined(BN254_PLONK_MARKS)
+// diagnostics build: the clock stamps of the last stage launches (100 MHz ticks; bn254_plonk.hpp::PL_MARK)
+extern "C" int bn254_dbg_plonk_marks(unsigned long long out[32]) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plonk_marks), 32 * sizeof(unsigned long long)); }
+#endif
 hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_zeta, uint8_t* d_status, hipStream_t s) {
   hipLaunchKernelGGL(k_plonk_dbg_zeta, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkWork*)d_work, (uint32_t)n, d_zeta, d_status);
   return hipGetLastError();

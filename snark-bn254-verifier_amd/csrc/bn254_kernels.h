@@ -109,14 +109,13 @@ hipError_t bn254_launch_g16_rlc(const G16LaunchArgs& a, const RlcLaunchArgs& r, 
 hipError_t bn254_launch_gather_rows(uint8_t* dst, const uint8_t* src, size_t src_stride, uint32_t row_bytes, const uint32_t* idx, uint32_t m, hipStream_t s);
 hipError_t bn254_launch_scatter_status(uint8_t* status, const uint8_t* fb_status, const uint32_t* idx, uint32_t m, hipStream_t s);
 #define G1_GLV_TAB_BYTES_PER_LANE (16 * 28 * 4)
-size_t bn254_g1_msm_tab_lanes(size_t n, int n_terms);   // lanes of scratch (G1_GLV_TAB_BYTES_PER_LANE each) the launch can use for the two-bit-window form; 0: not used
-hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, uint32_t* out_words,
-                               uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
-hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, hipStream_t s);
-hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s);
-hipError_t bn254_launch_g1_sum2(const int32_t* part, int first, int count, int first_b, int count_b, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit,
-                                int e_x_b, int inf_bit_b, hipStream_t s);
-bool bn254_g1_msm_split(size_t n, int n_terms);   // the scalar-multiplication launch uses two lanes per term (part needs 2 * n_terms rows)
+// PlonK's G1 multi-scalar multiplications as rows of a plan (bn254_msm.h, bn254_k_msm.hip)
+namespace bn254 { struct MsmPlan; }
+size_t bn254_g1_msm_scratch_lanes(const bn254::MsmPlan& plan, size_t n);   // lanes of window-table scratch (G1_GLV_TAB_BYTES_PER_LANE each) a launch over n items needs
+hipError_t bn254_launch_g1_msm_rows(const bn254::MsmPlan& plan, const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab,
+                                    const int32_t* tabs, hipStream_t s);
+hipError_t bn254_launch_g1_sum_rows(const bn254::MsmPlan& plan, const int32_t* part, size_t n, uint32_t* out_words, uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit,
+                                    int e_x_b, int inf_bit_b, hipStream_t s);
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,
                                        int reject_code, hipStream_t s, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
 // cooperative layout for small batches (bn254_coop12.hip): twelve lanes per proof (one Fp number of every Fp12 value per lane), 39 KB of LDS per

@@ -245,17 +245,6 @@ k_g16_check_scalars(const uint8_t* __restrict__ inputs, int n_public, uint32_t n
 // =====================================================================================================================
 // public-input MSM for keys with many inputs (BASELINE config 5: 1024): the inputs of one proof are spread over `chunks` lanes
 // =====================================================================================================================
-// table entry -> affine point (80-byte entry, 16-byte aligned: five 16-byte loads)
-__device__ __forceinline__ G1Aff msm_entry(const int32_t* __restrict__ msm_tab, size_t idx) {
-  const int4* e = (const int4*)(msm_tab + idx * MSM_ENTRY_DWORDS);
-  int4 v0 = e[0], v1 = e[1], v2 = e[2], v3 = e[3], v4 = e[4];
-  G1Aff q;
-  q.x.v[0] = v0.x; q.x.v[1] = v0.y; q.x.v[2] = v0.z; q.x.v[3] = v0.w; q.x.v[4] = v1.x; q.x.v[5] = v1.y; q.x.v[6] = v1.z; q.x.v[7] = v1.w;
-  q.x.v[8] = v2.x; q.y.v[0] = v2.y; q.y.v[1] = v2.z; q.y.v[2] = v2.w; q.y.v[3] = v3.x; q.y.v[4] = v3.y; q.y.v[5] = v3.z; q.y.v[6] = v3.w;
-  q.y.v[7] = v4.x; q.y.v[8] = v4.y;
-  BN_SETB(q.x, 1.0, 0.5); BN_SETB(q.y, 1.0, 0.5);
-  return q;
-}
 // lane g = c * n + i: chunk c of proof i sums inputs [c * per, min((c+1) * per, n_public)); partial sums (projective, 27 dwords)
 // go to part[(c * 27 + k) * n + i]: every access of a wave is contiguous over proofs.
 __global__ void __launch_bounds__(256, 2)
@@ -395,125 +384,6 @@ k_g16_msm_reduce8(const int32_t* __restrict__ part, int chunks, uint32_t n, int3
   DevWs w(ws, n, lead ? p : DEAD_LANE);
   w.st(VE_LX, La.x); w.st(VE_LY, La.y);
   if (lead && (st & BN254_ST_PENDING) && l_inf) status[p] = st | BN254_ST_LINF;
-}
-
-// =====================================================================================================================
-// variable-base G1 multi-scalar multiplication (PlonK: linearised-polynomial digest, folded digests and quotients)
-// =====================================================================================================================
-// lane g = t * n + i: term t of item i.  terms[g * 26]: 18 digits of the affine point, 8 little-endian words of the GLV-decomposed scalar.
-// Joint double-and-add with the complete formulas (bn254_rlc.h::g1_mul_glv_w): data-independent control, no special cases.
-// flags[g] bit 0: the point is the identity (the term contributes nothing), bits 1 / 2: signs.  Partial results: part[(t * 27 + k) * n + i].
-// SPLIT (small batches, where the launch lasts as long as one lane's chain of 128 double-and-add steps): two lanes per term -- the low and the
-// high 64 joint bit positions; the high lane doubles its result 64 more times (chain: 64 steps + 64 doublings, 0.69 of the unsplit chain) and writes
-// it n_terms rows further, where k_g1_sum_affine picks it up (`second` below).
-// W2 (the same small launches): two bits of each half per step from a 15-entry table the lane builds in its own 1792 bytes of `glv_tab`
-// (bn254_rlc.h::g1_mul_glv_w2): 0.75 of the chain.
-struct DevGlvTab {
-  int32_t* base;   // this lane's 16 x 28 dwords
-  __device__ __forceinline__ void put(int i, const G1Proj& p) const {
-    const Fp x = fp_reduce(p.x), y = fp_reduce(p.y), z = fp_reduce(p.z);
-    int4* q = (int4*)(base + i * 28);
-    q[0] = make_int4(x.v[0], x.v[1], x.v[2], x.v[3]); q[1] = make_int4(x.v[4], x.v[5], x.v[6], x.v[7]); q[2] = make_int4(x.v[8], y.v[0], y.v[1], y.v[2]);
-    q[3] = make_int4(y.v[3], y.v[4], y.v[5], y.v[6]); q[4] = make_int4(y.v[7], y.v[8], z.v[0], z.v[1]); q[5] = make_int4(z.v[2], z.v[3], z.v[4], z.v[5]);
-    q[6] = make_int4(z.v[6], z.v[7], z.v[8], 0);
-  }
-  __device__ __forceinline__ G1Proj get(uint32_t i) const {
-    const int4* q = (const int4*)(base + i * 28);
-    const int4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
-    G1Proj p;
-    p.x.v[0] = a.x; p.x.v[1] = a.y; p.x.v[2] = a.z; p.x.v[3] = a.w; p.x.v[4] = b.x; p.x.v[5] = b.y; p.x.v[6] = b.z; p.x.v[7] = b.w; p.x.v[8] = c.x;
-    p.y.v[0] = c.y; p.y.v[1] = c.z; p.y.v[2] = c.w; p.y.v[3] = d.x; p.y.v[4] = d.y; p.y.v[5] = d.z; p.y.v[6] = d.w; p.y.v[7] = e.x; p.y.v[8] = e.y;
-    p.z.v[0] = e.z; p.z.v[1] = e.w; p.z.v[2] = f.x; p.z.v[3] = f.y; p.z.v[4] = f.z; p.z.v[5] = f.w; p.z.v[6] = g.x; p.z.v[7] = g.y; p.z.v[8] = g.z;
-    BN_SETB(p.x, 1.01, 0.5); BN_SETB(p.y, 1.01, 0.5); BN_SETB(p.z, 1.01, 0.5);
-    return p;
-  }
-  __device__ __forceinline__ void fence() const { __threadfence_block(); }
-};
-#define G1_GLV_TAB_DWORDS (16 * 28)
-template <bool SPLIT, bool W2>
-__global__ void __launch_bounds__(256, 2)
-k_g1_scalar_mul(const int32_t* __restrict__ terms, const uint8_t* __restrict__ flags, uint32_t n, int n_terms, int32_t* __restrict__ part, int32_t* glv_tab) {
-  const uint32_t g0 = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t lanes = n * (uint32_t)n_terms;
-  if (g0 >= (SPLIT ? 2u : 1u) * lanes) return;
-  const uint32_t half = SPLIT ? (g0 >= lanes ? 1u : 0u) : 0u;
-  const uint32_t g = g0 - half * lanes;
-  const uint32_t t = g / n, i = g - t * n;
-  const int32_t* e = terms + ((size_t)i * n_terms + t) * 26;
-  G1Aff P;
-#pragma unroll
-  for (int l = 0; l < BN_NL; l++) { P.x.v[l] = e[l]; P.y.v[l] = e[BN_NL + l]; }
-  BN_SETB(P.x, 1.0, 0.5); BN_SETB(P.y, 1.0, 0.5);
-  // the scalar arrives GLV-decomposed (bn254_plonk.hpp::glv_decompose): k = +-k1 +- k2 lambda with 128-bit magnitudes k1 (words 0..3) and k2
-  // (words 4..7), signs in the flag byte (bit 1, bit 2; bit 0: the point is the identity): 128 joint double-and-add steps instead of 256
-  uint32_t k1[4], k2[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { k1[k] = (uint32_t)e[18 + k]; k2[k] = (uint32_t)e[22 + k]; }
-  const uint8_t fl = flags[(size_t)i * n_terms + t];
-  if (fl & 1) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) { k1[k] = 0; k2[k] = 0; }
-  }
-  G1Proj acc;
-  if constexpr (SPLIT) {
-    uint32_t h1[2] = {half ? k1[2] : k1[0], half ? k1[3] : k1[1]}, h2[2] = {half ? k2[2] : k2[0], half ? k2[3] : k2[1]};
-    if constexpr (W2) { DevGlvTab tab{glv_tab + (size_t)g0 * G1_GLV_TAB_DWORDS}; acc = g1_mul_glv_w2<2>(P, h1, (fl & 2) != 0, h2, (fl & 4) != 0, tab); }
-    else acc = g1_mul_glv_w<2>(P, h1, (fl & 2) != 0, h2, (fl & 4) != 0);
-    if (half) {                                  // wave-uniform except in the one wavefront that straddles the two halves
-      for (int d = 0; d < 64; d++) acc = g1_dbl(acc);
-    }
-  } else {
-    if constexpr (W2) { DevGlvTab tab{glv_tab + (size_t)g0 * G1_GLV_TAB_DWORDS}; acc = g1_mul_glv_w2<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0, tab); }
-    else acc = g1_mul_glv_w<4>(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0);
-  }
-  int32_t* o = part + ((size_t)t + (size_t)half * (size_t)n_terms) * 27 * n + i;
-#pragma unroll
-  for (int l = 0; l < BN_NL; l++) { o[(size_t)l * n] = acc.x.v[l]; o[(size_t)(9 + l) * n] = acc.y.v[l]; o[(size_t)(18 + l) * n] = acc.z.v[l]; }
-}
-// per item: the sum of its n_terms partial results, to affine.  out_words != nullptr: 16 little-endian words (x | y, canonical) and a
-// flag byte (1 = identity) per item, for the host.  Otherwise the point goes to workspace elements (e_x, e_x + 1) as (x, y) or
-// (0, 1) for the identity, whose flag bit `inf_bit` is OR-ed into the (pending) status byte.
-__global__ void __launch_bounds__(256, 2)
-k_g1_sum_affine(const int32_t* __restrict__ part, int first, int n_terms, int second /* 0, or the row distance of the split launch's high halves */, uint32_t n,
-                uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf, int32_t* ws, uint8_t* __restrict__ status, int e_x, int inf_bit,
-                int first_b, int n_terms_b, int e_x_b, int inf_bit_b) {
-  // n_terms_b > 0: TWO sums per item in one launch (PlonK: P0 and P1 of the KZG check): the lanes from round_up(n, 64) on form the second one (a
-  // wavefront never mixes the two: the workspace accessor takes its element numbers from the first lane) -- the launch lasts as long as one lane's
-  // chain (an inversion), whatever the number of sums
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t n_pad = (n + 63u) & ~63u;
-  const bool second_sum = n_terms_b > 0 && g >= n_pad;
-  const uint32_t i = second_sum ? g - n_pad : (g < n ? g : 0xffffffffu);
-  if (second_sum) { first = first_b; n_terms = n_terms_b; e_x = e_x_b; inf_bit = inf_bit_b; }
-  const uint32_t ii = i < n ? i : n - 1;
-  G1Proj L = g1_identity();
-  const int total = second ? 2 * n_terms : n_terms;
-  for (int cc = 0; cc < total; cc++) {
-    const int c = cc < n_terms ? first + cc : first + (cc - n_terms) + second;
-    const int32_t* o = part + (size_t)c * 27 * n + ii;
-    G1Proj q;
-#pragma unroll
-    for (int l = 0; l < BN_NL; l++) { q.x.v[l] = o[(size_t)l * n]; q.y.v[l] = o[(size_t)(9 + l) * n]; q.z.v[l] = o[(size_t)(18 + l) * n]; }
-    BN_SETB(q.x, 3.0, 0.5); BN_SETB(q.y, 3.0, 0.5); BN_SETB(q.z, 3.0, 0.5);
-    L = g1_add(L, q);
-  }
-  bool l_inf = g1_is_identity(L);
-  G1Aff La = g1_to_affine(L);
-  if (out_words) {
-    if (i < n) {
-      uint32_t wx[8], wy[8];
-      fp_to_words(wx, La.x); fp_to_words(wy, La.y);
-#pragma unroll
-      for (int k = 0; k < 8; k++) { out_words[(size_t)i * 16 + k] = wx[k]; out_words[(size_t)i * 16 + 8 + k] = wy[k]; }
-      out_inf[i] = l_inf ? 1 : 0;
-    }
-  } else {
-    DevWs w(ws, n, i < n ? i : DEAD_LANE);
-    La.y = fp_select(l_inf, fp_one(), La.y);
-    w.st(e_x, La.x); w.st(e_x + 1, La.y);
-    // the two sums of an item may both flag their point: different bits of the same status byte -> an atomic OR
-    if (i < n && l_inf) { if (status[i] & BN254_ST_PENDING) atomicOr((unsigned int*)(status + (i & ~3u)), (unsigned int)inf_bit << (8 * (i & 3u))); }
-  }
 }
 
 // =====================================================================================================================
@@ -1033,58 +903,7 @@ hipError_t bn254_launch_dbg_g2_subgroup(const uint8_t* g2, uint8_t* o, size_t n,
   return hipGetLastError();
 }
 
-// ---- PlonK: G1 MSM stages and the two-fixed-pair pairing check -----------------------------------------------------------------------
-// small launches are split over two lanes per term (k_g1_scalar_mul<true>): below one wavefront per SIMD the launch time is one lane's chain.
-// Only while the split launch itself stays within one wavefront per SIMD (65536 lanes): two wavefronts that share a SIMD slow each other by about
-// 1.6 (they are not pure multiply-add streams), which is more than the 0.69 the shorter chain gains -- measured at 4096 PlonK proofs
-// (106 k lanes): 1.68 ms split against 1.45 ms.
-bool bn254_g1_msm_split(size_t n, int n_terms) {
-  static const int mode = [] { const char* e = getenv("BN254_MSM_SPLIT"); return e ? atoi(e) : -1; }();   // 0 / 1 force, default by size
-  if (mode >= 0) return mode != 0;
-  return n * (size_t)n_terms * 2 <= 65536;
-}
-// the two-bit-window form needs G1_GLV_TAB_BYTES_PER_LANE of scratch per lane and pays only where a lane's chain is the launch time
-size_t bn254_g1_msm_tab_lanes(size_t n, int n_terms) {
-  static const int mode = [] { const char* e = getenv("BN254_MSM_W2"); return e ? atoi(e) : 1; }();
-  const size_t lanes = n * (size_t)n_terms * (bn254_g1_msm_split(n, n_terms) ? 2 : 1);
-  return (mode != 0 && lanes <= 65536) ? lanes : 0;
-}
-static void launch_scalar_mul(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, bool split, hipStream_t s) {
-  const size_t lanes = n * (size_t)n_terms * (split ? 2 : 1);
-  const unsigned g1 = (unsigned)((lanes + 255) / 256);
-  const bool w2 = glv_tab != nullptr && bn254_g1_msm_tab_lanes(n, n_terms) != 0;
-  if (split && w2) hipLaunchKernelGGL((k_g1_scalar_mul<true, true>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
-  else if (split) hipLaunchKernelGGL((k_g1_scalar_mul<true, false>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
-  else if (w2) hipLaunchKernelGGL((k_g1_scalar_mul<false, true>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
-  else hipLaunchKernelGGL((k_g1_scalar_mul<false, false>), dim3(g1), dim3(256), 0, s, terms, flags, (uint32_t)n, n_terms, part, glv_tab);
-}
-// part: 2 * n_terms * 27 * n dwords (the split launch writes the high halves n_terms rows after the low ones)
-hipError_t bn254_launch_g1_msm(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, uint32_t* out_words,
-                               uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
-  const bool split = bn254_g1_msm_split(n, n_terms);
-  launch_scalar_mul(terms, flags, n, n_terms, part, glv_tab, split, s);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, (const int32_t*)part, 0, n_terms, split ? n_terms : 0, (uint32_t)n, out_words, out_inf, ws, status, e_x, inf_bit, 0, 0, 0, 0);
-  return hipGetLastError();
-}
-// the two halves of the above separately: ONE scalar-multiplication launch can feed several sums (PlonK: P0 and P1 of the KZG check); the sums
-// are told the launch's term count so that they find the high halves of a split launch
-hipError_t bn254_launch_g1_scalar_muls(const int32_t* terms, const uint8_t* flags, size_t n, int n_terms, int32_t* part, int32_t* glv_tab, hipStream_t s) {
-  launch_scalar_mul(terms, flags, n, n_terms, part, glv_tab, bn254_g1_msm_split(n, n_terms), s);
-  return hipGetLastError();
-}
-hipError_t bn254_launch_g1_sum(const int32_t* part, int first, int count, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit, hipStream_t s) {
-  const bool split = bn254_g1_msm_split(n, launch_terms);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(n)), dim3(256), 0, s, part, first, count, split ? launch_terms : 0, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status, e_x, inf_bit, 0, 0, 0, 0);
-  return hipGetLastError();
-}
-// two sums per item in ONE launch (rows [first, first + count) -> e_x / inf_bit, rows [first_b, first_b + count_b) -> e_x_b / inf_bit_b)
-hipError_t bn254_launch_g1_sum2(const int32_t* part, int first, int count, int first_b, int count_b, int launch_terms, size_t n, int32_t* ws, uint8_t* status, int e_x, int inf_bit,
-                                int e_x_b, int inf_bit_b, hipStream_t s) {
-  const bool split = bn254_g1_msm_split(n, launch_terms);
-  hipLaunchKernelGGL(k_g1_sum_affine, dim3(grid_for(((n + 63) & ~(size_t)63) + n)), dim3(256), 0, s, part, first, count, split ? launch_terms : 0, (uint32_t)n, (uint32_t*)nullptr, (uint8_t*)nullptr, ws, status,
-                     e_x, inf_bit, first_b, count_b, e_x_b, inf_bit_b);
-  return hipGetLastError();
-}
+// ---- PlonK: the two-fixed-pair pairing check (the MSM stages: bn254_k_msm.hip) -------------------------------------------------------------------
 // prod_t e(P_t, Q_t) == 1 for two key-side G2 points (line tables tab0, tab1) and per-item G1 points already in the workspace
 // (P_0 at VE_LX, P_1 at VE_CX; identity flags BN254_ST_LINF / BN254_ST_LINF2 in the status byte): ACCEPT or reject_code
 hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const int32_t* target_one,

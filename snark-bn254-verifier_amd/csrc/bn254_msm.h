@@ -1,0 +1,252 @@
+// bn254_msm.h -- the G1 multi-scalar multiplications of the PlonK verifier as ROWS (round 4): what one lane of k_g1_msm_rows does, and the plan that
+// deals the terms of a launch to rows.  Replaces bn::AffineG1::msm / `AffineG1 * Fr` at plonk/verify.rs:284 and plonk/kzg.rs:82,161,169,175.
+//
+// A launch evaluates up to two sums  S_s = sum_t k_t P_t  per item (proof).  Its terms are of three kinds:
+//   variable   P_t comes with the proof (commitments, openings): the scalar arrives GLV-decomposed, k = +-k1 +- k2 lambda with 128-bit halves, and is
+//              walked by the joint two-bit-window form of bn254_rlc.h over the 128 joint bit positions -- by ONE row, or by two rows that take the low and
+//              the high positions (the high row doubles its result 64 more times), which shortens the chain where a launch is latency-bound;
+//   fixed      P_t belongs to the verifying key: a byte-window table of the point (32 x 255 multiples, bn254_host.hpp::build_window_table) turns the term
+//              into at most 32 complete mixed additions, and those additions are dealt out window by window -- to the LOW rows of the variable terms, which
+//              have time to spare while the high rows double, and to rows of their own;
+//   unit       k_t = +-1 (the -H of the KZG check): one mixed addition.
+// Every row produces one projective point; k_g1_sum_affine adds the rows of a sum.  All formulas are the complete ones of bn254_curve.h, so no scalar or
+// point a prover chooses reaches an exceptional case.  The plan is a pure function of (term kinds, items, lane budget): bn254_dbg_msm_plan exports it and
+// tests/test_capi_cpu.py checks that every launch fits its buffers; tests/hostsim evaluates planned rows on the CPU against the oracle.
+#pragma once
+#include <cstring>
+#include <utility>
+#include "bn254_rlc.h"
+
+namespace bn254 {
+
+#define MSM_MAX_ROWS 32
+#define MSM_MAX_FIXED 16
+#define MSM_TERM_DWORDS 26       // MsmTerm (bn254_plonk.hpp): 18 digits of the affine point, 8 scalar words
+struct MsmRow {
+  int8_t var_term;      // term whose GLV halves this row walks, or -1
+  uint8_t pos_lo, pos_hi;   // joint bit positions [pos_lo, pos_hi) of the 128, both even; the row's result carries the factor 2^pos_lo
+  int8_t unit_term;     // term added as +-P, or -1
+  uint8_t sum;          // the sum the row belongs to
+  uint8_t glv_slot;     // which of the launch's window-table scratch rows it uses (variable rows only)
+  uint16_t fw_lo, fw_hi;    // byte windows [fw_lo, fw_hi) of its sum's fixed terms, flattened: window q = byte q & 31 of fixed term q >> 5
+};
+struct MsmPlan {
+  int32_t n_rows, n_var_rows;
+  int32_t first[2], count[2];                       // rows of sum s: [first[s], first[s] + count[s])
+  int32_t n_fixed[2];
+  int8_t fixed_term[2][MSM_MAX_FIXED];              // term index of the f-th fixed term of sum s (its scalar: 8 canonical words in the term's k[])
+  int8_t fixed_tab[2][MSM_MAX_FIXED];               // and which of the key's window tables it reads
+  MsmRow row[MSM_MAX_ROWS];
+};
+// what the caller says about a launch: per sum the term indices of each kind
+struct MsmShape {
+  int n_sums;
+  int n_var[2], n_unit[2], n_fixed[2];
+  int8_t var_term[2][MSM_MAX_FIXED], unit_term[2][4], fixed_term[2][MSM_MAX_FIXED], fixed_tab[2][MSM_MAX_FIXED];
+};
+// cost model of the planner, in field multiplications of one lane: a two-bit step (2 doublings + 1 addition), a doubling, a mixed addition, the table
+#define MSM_COST_STEP 30
+#define MSM_COST_DBL 8
+#define MSM_COST_MIXED 11
+#define MSM_COST_TABLE 150
+// Rows for `n_pad` items (a multiple of 64: a wavefront never straddles two rows) within `lane_budget` lanes (one wavefront per SIMD: 65536).
+//   * While twice the variable terms fit the budget the launch is latency-bound and every variable term is SPLIT over a low and a high row; the high row's 64
+//     extra doublings leave the low row (chain_hi - chain_lo) / MIXED = 46 mixed additions of slack, so the fixed windows of a sum go to its low rows first,
+//     then to rows of their own as far as the budget has rows left (a row of the sum costs k_g1_sum_affine one more addition, so own rows come second), and
+//     whatever is still left is spread over the low rows.
+//   * Otherwise (a large launch: throughput) every variable term is one row and the fixed windows form rows of about a variable row's cost.
+// Unit terms ride on the first rows of their sum.  Returns false if the shape needs more than MSM_MAX_ROWS rows.
+inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t lane_budget) {
+  std::memset(&p, 0, sizeof p);
+  if (sh.n_sums < 1 || sh.n_sums > 2 || n_pad == 0) return false;
+  int total_var = 0;
+  for (int s = 0; s < sh.n_sums; s++) {
+    if (sh.n_fixed[s] > MSM_MAX_FIXED || sh.n_var[s] > MSM_MAX_FIXED || sh.n_unit[s] > 4 || sh.n_fixed[s] < 0 || sh.n_var[s] < 0 || sh.n_unit[s] < 0) return false;
+    total_var += sh.n_var[s];
+  }
+  const bool split = total_var > 0 && (size_t)(2 * total_var) * n_pad <= lane_budget;
+  const int chain_hi = MSM_COST_TABLE + 32 * MSM_COST_STEP + 64 * MSM_COST_DBL, chain_lo = MSM_COST_TABLE + 32 * MSM_COST_STEP;
+  const int chain_full = MSM_COST_TABLE + 64 * MSM_COST_STEP;
+  const int free_cap = (chain_hi - chain_lo) / MSM_COST_MIXED;                                 // windows a low row takes without becoming the longest row
+  const int own_cap = (split ? chain_hi : chain_full) / MSM_COST_MIXED;                        // windows of a row that has nothing else to do
+  long spare = split ? (long)(lane_budget / n_pad) - 2 * total_var : MSM_MAX_ROWS;             // rows the budget still has
+  int r = 0, slot = 0;
+  for (int s = 0; s < sh.n_sums; s++) {
+    p.first[s] = r;
+    p.n_fixed[s] = sh.n_fixed[s];
+    for (int f = 0; f < sh.n_fixed[s]; f++) { p.fixed_term[s][f] = sh.fixed_term[s][f]; p.fixed_tab[s][f] = sh.fixed_tab[s][f]; }
+    const int wf = 32 * sh.n_fixed[s], L = sh.n_var[s];
+    int low_each = 0, own_rows = 0, own_each = 0;
+    if (wf > 0) {
+      if (split && L > 0) {
+        low_each = (wf + L - 1) / L;
+        if (low_each > free_cap) low_each = free_cap;
+        int rest = wf - low_each * L;
+        if (rest > 0) {
+          long want = (rest + own_cap - 1) / own_cap;
+          own_rows = (int)(want < spare ? want : (spare > 0 ? spare : 0));
+          if (own_rows > 0) { own_each = (rest + own_rows - 1) / own_rows; if (own_each > own_cap) own_each = own_cap; }
+          rest -= own_rows * own_each;
+          if (rest > 0) low_each += (rest + L - 1) / L;                                        // no rows left: the low rows get longer
+        }
+      } else {
+        own_rows = (wf + own_cap - 1) / own_cap;
+        if (split && own_rows > spare) own_rows = spare > 0 ? (int)spare : 1;                  // (a sum without variable terms in a split launch)
+        own_each = (wf + own_rows - 1) / own_rows;
+      }
+      spare -= own_rows;
+    }
+    int q = 0, unit_i = 0;                                                                      // next fixed window / unit term to hand out
+    auto fixed_slice = [&](MsmRow& w, int want) { w.fw_lo = (uint16_t)q; q = q + want < wf ? q + want : wf; w.fw_hi = (uint16_t)q; };
+    auto blank = [&](MsmRow& w) { w.var_term = -1; w.unit_term = -1; w.pos_lo = w.pos_hi = 0; w.sum = (uint8_t)s; w.glv_slot = 0; w.fw_lo = w.fw_hi = 0; };
+    for (int t = 0; t < L; t++) {
+      if (r + 2 > MSM_MAX_ROWS) return false;
+      MsmRow& lo = p.row[r++];
+      blank(lo);
+      lo.var_term = sh.var_term[s][t]; lo.pos_lo = 0; lo.pos_hi = split ? 64 : 128; lo.glv_slot = (uint8_t)slot++;
+      if (unit_i < sh.n_unit[s]) lo.unit_term = sh.unit_term[s][unit_i++];
+      fixed_slice(lo, low_each);
+      if (split) {
+        MsmRow& hi = p.row[r++];
+        blank(hi);
+        hi.var_term = sh.var_term[s][t]; hi.pos_lo = 64; hi.pos_hi = 128; hi.glv_slot = (uint8_t)slot++;
+      }
+    }
+    for (int k = 0; k < own_rows || q < wf || unit_i < sh.n_unit[s]; k++) {
+      if (r + 1 > MSM_MAX_ROWS) return false;
+      MsmRow& o = p.row[r++];
+      blank(o);
+      if (unit_i < sh.n_unit[s]) o.unit_term = sh.unit_term[s][unit_i++];
+      fixed_slice(o, k + 1 >= own_rows ? wf : own_each);
+    }
+    if (r == p.first[s]) {                                                                      // an empty sum is one row that yields the identity
+      if (r + 1 > MSM_MAX_ROWS) return false;
+      blank(p.row[r++]);
+    }
+    p.count[s] = r - p.first[s];
+  }
+  p.n_rows = r; p.n_var_rows = slot;
+  return true;
+}
+// the longest row of a plan, in the planner's cost units (tests; the roofline of the bench line)
+inline int msm_plan_chain(const MsmPlan& p) {
+  int worst = 0;
+  for (int r = 0; r < p.n_rows; r++) {
+    const MsmRow& w = p.row[r];
+    int c = (w.fw_hi - w.fw_lo) * MSM_COST_MIXED + (w.unit_term >= 0 ? MSM_COST_MIXED : 0);
+    if (w.var_term >= 0) c += MSM_COST_TABLE + (w.pos_hi - w.pos_lo) / 2 * MSM_COST_STEP + w.pos_lo * MSM_COST_DBL;
+    if (c > worst) worst = c;
+  }
+  return worst;
+}
+
+// ---- a variable term over the joint bit positions [pos_lo, pos_hi) of its GLV halves: sum over those positions, times 2^pos_lo ------------------------
+// (+-k1 +- k2 lambda) P restricted to the positions, TWO bits of each half per step: acc <- 4 acc + (d1 P1 + d2 P2), d1, d2 in 0..3, from a table of the 15
+// non-zero combinations i P1 + j P2 at index 4 i + j (P1 = +-P, P2 = +-phi(P), bn254_rlc.h).  (pos_hi - pos_lo) / 2 steps of (2 doublings + 1 addition) + 13
+// point operations for the table, against one (doubling + addition) per position for the one-bit form: 0.75 of the chain.  The table lives where TAB puts
+// it (k_g1_msm_rows: 15 x 28 dwords of global memory per lane -- one contiguous 108-byte read per step, issued before the doublings; the host test keeps it
+// in an array).  The halves are first shifted so that position pos_hi - 1 is the top bit.  pos_lo, pos_hi even and uniform over the wavefront.
+template <class TAB>
+BN_HD G1Proj g1_mul_glv_w2_range(const G1Aff& P, const uint32_t k1[4], bool neg1, const uint32_t k2[4], bool neg2, int pos_lo, int pos_hi, TAB& tab) {
+  G1Aff P1 = P, P2;
+  P1.y = fp_select(neg1, fp_neg(P.y), P.y);
+  P2.x = fp_mul(P.x, fp_from_limbs(BN_GLV_BETA)); P2.y = fp_select(neg2, fp_neg(P.y), P.y);
+  {
+    // the table is built THROUGH the table: the multiples of P1 and P2 go out as they are made, the nine mixed entries are sums of entries read back -- no array
+    // of points stays live (as local arrays the eight points would be 216 registers or, indexed by the loop counters, 864 bytes of scratch memory)
+    G1Proj t = g1_from_affine(P1); tab.put(4, t);
+    G1Proj d = g1_dbl(t); tab.put(8, d); tab.put(12, g1_add_mixed(d, P1));
+    t = g1_from_affine(P2); tab.put(1, t);
+    d = g1_dbl(t); tab.put(2, d); tab.put(3, g1_add_mixed(d, P2));
+    tab.fence();
+    for (int i = 1; i < 4; i++)
+      for (int j = 1; j < 4; j++) tab.put(4 * i + j, g1_add(tab.get(4 * i), tab.get(j)));
+  }
+  tab.fence();
+  uint32_t a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { a[i] = k1[i]; b[i] = k2[i]; }
+  for (int s = 128 - pos_hi; s >= 32; s -= 32) {
+    a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = 0;
+    b[3] = b[2]; b[2] = b[1]; b[1] = b[0]; b[0] = 0;
+  }
+  const int bs = (128 - pos_hi) & 31;
+  if (bs) {
+#pragma unroll
+    for (int i = 3; i > 0; i--) { a[i] = (a[i] << bs) | (a[i - 1] >> (32 - bs)); b[i] = (b[i] << bs) | (b[i - 1] >> (32 - bs)); }
+    a[0] <<= bs; b[0] <<= bs;
+  }
+  G1Proj acc = g1_identity();
+  const int steps = (pos_hi - pos_lo) / 2;
+  for (int step = 0; step < steps; step++) {
+    const uint32_t idx = ((a[3] >> 30) << 2) | (b[3] >> 30);
+#pragma unroll
+    for (int i = 3; i > 0; i--) { a[i] = (a[i] << 2) | (a[i - 1] >> 30); b[i] = (b[i] << 2) | (b[i - 1] >> 30); }
+    a[0] <<= 2; b[0] <<= 2;
+    const G1Proj q = tab.get(idx != 0 ? idx : 1u);
+    acc = g1_dbl(g1_dbl(acc));
+    const G1Proj c = g1_add(acc, q);
+    const bool take = idx != 0;
+    acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
+  }
+  for (int d = 0; d < pos_lo; d++) acc = g1_dbl(acc);
+  return acc;
+}
+
+// the whole term (W words per half) in one go: what a single row of an unsplit launch computes (tests/hostsim)
+template <int W, class TAB>
+BN_HD G1Proj g1_mul_glv_w2(const G1Aff& P, const uint32_t* k1, bool neg1, const uint32_t* k2, bool neg2, TAB& tab) {
+  uint32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < W; i++) { a[i] = k1[i]; b[i] = k2[i]; }
+  return g1_mul_glv_w2_range(P, a, neg1, b, neg2, 0, 32 * W, tab);
+}
+
+// ---- one row ------------------------------------------------------------------------------------------------------------------------------------------------
+// IO supplies the item's data: term(t, P, k1, k2, flags) -- the affine point, the GLV halves and the flag byte (bit 0: the point is the identity, bits 1 / 2:
+// signs; for a unit term bit 1 is the sign) of term t; scalar_byte(t, w) -- byte w (weight 2^(8 w)) of the canonical scalar of fixed term t;
+// entry(tab, w, d) -- multiple d + 1 of window w of key table `tab`.
+template <class IO, class TAB>
+BN_HD G1Proj msm_row_eval(const MsmPlan& plan, int r, IO& io, TAB& glv) {
+  const MsmRow& row = plan.row[r];
+  G1Proj acc = g1_identity();
+  if (row.var_term >= 0) {
+    G1Aff P; uint32_t k1[4], k2[4]; uint32_t fl;
+    io.term(row.var_term, P, k1, k2, fl);
+    if (fl & 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { k1[k] = 0; k2[k] = 0; }
+    }
+    acc = g1_mul_glv_w2_range(P, k1, (fl & 2) != 0, k2, (fl & 4) != 0, row.pos_lo, row.pos_hi, glv);
+  }
+  if (row.unit_term >= 0) {
+    G1Aff P; uint32_t k1[4], k2[4]; uint32_t fl;
+    io.term(row.unit_term, P, k1, k2, fl);
+    P.y = fp_select((fl & 2) != 0, fp_neg(P.y), P.y);
+    const G1Proj c = g1_add_mixed(acc, P);
+    const bool take = (fl & 1) == 0;
+    acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
+  }
+  const int s = row.sum;
+  if (row.fw_lo < row.fw_hi) {
+    // the next window's digit and table entry are fetched while the current addition runs
+    int q = row.fw_lo;
+    uint32_t dig = io.scalar_byte(plan.fixed_term[s][q >> 5], q & 31);
+    G1Aff e = io.entry(plan.fixed_tab[s][q >> 5], q & 31, dig ? dig - 1 : 0);
+    for (; q < row.fw_hi; q++) {
+      uint32_t dn = 0; G1Aff en = e;
+      if (q + 1 < row.fw_hi) {
+        const int qn = q + 1;
+        dn = io.scalar_byte(plan.fixed_term[s][qn >> 5], qn & 31);
+        en = io.entry(plan.fixed_tab[s][qn >> 5], qn & 31, dn ? dn - 1 : 0);
+      }
+      const G1Proj c = g1_add_mixed(acc, e);
+      const bool take = dig != 0;
+      acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
+      dig = dn; e = en;
+    }
+  }
+  return acc;
+}
+
+}  // namespace bn254

@@ -16,6 +16,7 @@
 #include <immintrin.h>
 #endif
 #include "bn254_host.hpp"
+#include "bn254_msm.h"
 
 // The per-proof stages (parsing, transcripts, Fr arithmetic, GLV decomposition) also run ON THE DEVICE, one proof per lane (csrc/bn254_k_plonk.hip,
 // round 3): that translation unit defines BN254_PLONK_DEVICE_TU before it includes this header, which turns PL_HD into __host__ __device__ and routes
@@ -28,6 +29,17 @@
 #endif
 
 namespace bn254host {
+
+// Diagnostics build only (make EXTRA=-DBN254_PLONK_MARKS, tools/plonk_stage_marks.py): the first lane of a launch stamps the 100 MHz wall clock at
+// the marked points of the stages, so that a run tells where one lane's chain spends its time.  Not compiled into the product.
+#if defined(BN254_PLONK_MARKS) && defined(BN254_PLONK_DEVICE_TU) && defined(__HIPCC__)
+__device__ unsigned long long g_plonk_marks[32];
+#endif
+#if defined(BN254_PLONK_MARKS) && defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+#define PL_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_plonk_marks[k] = wall_clock64(); } while (0)
+#else
+#define PL_MARK(k) ((void)0)
+#endif
 
 #if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
 // Device side: a lane's pending SHA-256 block lives in LDS, not in its private memory (a byte buffer indexed by a run-time fill level would be
@@ -259,10 +271,132 @@ struct FrCtx {
     for (int i = 255; i >= 0; i--) { r = mul(r, r); if ((e[i / 64] >> (i % 64)) & 1) r = mul(r, a); }
     return r;
   }
-  // Inverse by the binary extended Euclidean algorithm on the canonical value (HAC 14.61 for an odd modulus): invariants x1 a = u, x2 a = v (mod m);
-  // at most 2 x 256 halvings, each a few 256-bit additions / shifts -- a tenth of the 384 Montgomery products of the Fermat form, which matters on
-  // the device where a lane computes it alone.  Montgomery in, Montgomery out; 0 -> 0.
-  PL_HD FrM inverse(const FrM& a) const {
+  // Inverse in CONSTANT TIME: the binary extended GCD with approximated operands of bn254_fp.h::fp_inv (Pornin 2020, k = 30: 18 rounds of 29 inner
+  // steps on 60-bit stand-ins, then one multiply-accumulate pass over 9 digits of 29 bits for (a, b) and one for (u, v) with a Montgomery digit retired),
+  // here for the modulus of this context.  Invariants a = u y / C, b = v y / C (mod m) from (a, u, b, v) = (y, C, m, 0); with y the stored (Montgomery)
+  // value and C = 2^512 mod m the result v = C / y is the Montgomery form of the inverse.  0 -> 0.  Fixed trip counts and no data-dependent branch: on the
+  // device the 64 proofs of a wavefront stay in step (the classic shift-and-subtract form below, whose loops run a data-dependent number of times, took
+  // 416 us of the 844 us of k_plonk_stage1 -- every lane waiting for the slowest of its wavefront at each of ~1000 diverging loop heads).
+  PL_HD FrM inverse(const FrM& x) const {
+    const int LB = 29; const uint32_t MASK = (1u << 29) - 1;
+    auto digits = [&](int32_t d[9], const uint64_t l[4]) {   // 256-bit value -> 9 unsigned digits of 29 bits
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int bit = LB * i, w = bit >> 6, sh = bit & 63;
+        uint64_t v = l[w] >> sh;
+        if (sh > 64 - LB && w + 1 < 4) v |= l[w + 1] << (64 - sh);
+        d[i] = (int32_t)((uint32_t)v & MASK);
+      }
+    };
+    int32_t a[9], b[9], u[9], v[9], md[9];
+    digits(a, x.l); digits(md, m); digits(u, r2.l);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { b[i] = md[i]; v[i] = 0; }
+    const uint32_t ninv = (uint32_t)inv & MASK;                       // -1 / m mod 2^29
+    auto sext29 = [](uint32_t t) { return (int32_t)(t << 3) >> 3; };
+#pragma unroll 1
+    for (int round = 0; round < 18; round++) {
+      int32_t ah = 0, am = 0, al = 0, bh = 0, bm = 0, bl = 0, low = 0;
+      bool found = false;
+#pragma unroll
+      for (int i = 8; i >= 2; i--) {
+        const bool take = !found && ((a[i] | b[i]) != 0);
+        ah = take ? a[i] : ah; am = take ? a[i - 1] : am; al = take ? a[i - 2] : al;
+        bh = take ? b[i] : bh; bm = take ? b[i - 1] : bm; bl = take ? b[i - 2] : bl;
+        low = take ? (i == 2 ? 1 : 0) : low;
+        found = found || take;
+      }
+      const uint64_t hiA = ((uint64_t)(uint32_t)ah << LB) | (uint32_t)am, hiB = ((uint64_t)(uint32_t)bh << LB) | (uint32_t)bm;
+      const int len = 64 - bn_clz64(hiA | hiB | 1);
+      const int sh = len - 31;
+      const uint64_t topA = sh >= 0 ? (hiA >> (sh & 63)) : ((hiA << 1) | ((uint32_t)al >> 28));
+      const uint64_t topB = sh >= 0 ? (hiB >> (sh & 63)) : ((hiB << 1) | ((uint32_t)bl >> 28));
+      const uint64_t lowA = ((uint64_t)(uint32_t)a[1] << LB) | (uint32_t)a[0], lowB = ((uint64_t)(uint32_t)b[1] << LB) | (uint32_t)b[0];
+      const bool exact3 = found && low != 0 && len <= 33;
+      uint64_t A = !found ? lowA : exact3 ? ((hiA << LB) | (uint32_t)al) : ((topA << LB) | (uint32_t)a[0]);
+      uint64_t B = !found ? lowB : exact3 ? ((hiB << LB) | (uint32_t)bl) : ((topB << LB) | (uint32_t)b[0]);
+      int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+#pragma unroll 1
+      for (int j = 0; j < LB; j++) {
+        const bool odd = (A & 1) != 0;
+        const bool swap = odd && A < B;
+        const uint64_t tA = swap ? B : A, tB = swap ? A : B;
+        const int32_t tf0 = swap ? f1 : f0, tg0 = swap ? g1 : g0, tf1 = swap ? f0 : f1, tg1 = swap ? g0 : g1;
+        A = (tA - (odd ? tB : 0)) >> 1; B = tB;
+        f0 = tf0 - (odd ? tf1 : 0); g0 = tg0 - (odd ? tg1 : 0);
+        f1 = tf1 << 1; g1 = tg1 << 1;
+      }
+      int32_t na[9], nb[9];
+      {
+        int64_t ca = (int64_t)a[0] * f0 + (int64_t)b[0] * g0, cb = (int64_t)a[0] * f1 + (int64_t)b[0] * g1;
+        ca >>= LB; cb >>= LB;
+#pragma unroll
+        for (int i = 1; i < 9; i++) {
+          ca += (int64_t)a[i] * f0 + (int64_t)b[i] * g0; cb += (int64_t)a[i] * f1 + (int64_t)b[i] * g1;
+          na[i - 1] = (int32_t)((uint32_t)ca & MASK); nb[i - 1] = (int32_t)((uint32_t)cb & MASK);
+          ca >>= LB; cb >>= LB;
+        }
+        na[8] = (int32_t)ca; nb[8] = (int32_t)cb;
+      }
+      const bool nega = na[8] < 0, negb = nb[8] < 0;
+      {
+        int32_t ba = 0, bb = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const int32_t ta = -na[i] - ba, tb = -nb[i] - bb;
+          const int32_t da = i < 8 ? (ta & (int32_t)MASK) : ta, db = i < 8 ? (tb & (int32_t)MASK) : tb;
+          ba = i < 8 ? ((ta >> LB) & 1) : 0; bb = i < 8 ? ((tb >> LB) & 1) : 0;
+          a[i] = nega ? da : na[i]; b[i] = negb ? db : nb[i];
+        }
+      }
+      f0 = nega ? -f0 : f0; g0 = nega ? -g0 : g0; f1 = negb ? -f1 : f1; g1 = negb ? -g1 : g1;
+      {
+        int64_t cu = (int64_t)u[0] * f0 + (int64_t)v[0] * g0, cv = (int64_t)u[0] * f1 + (int64_t)v[0] * g1;
+        const int32_t qu = sext29((uint32_t)cu * ninv), qv = sext29((uint32_t)cv * ninv);
+        cu += (int64_t)qu * md[0]; cv += (int64_t)qv * md[0];
+        cu >>= LB; cv >>= LB;
+        int32_t nu[9], nv[9];
+#pragma unroll
+        for (int i = 1; i < 9; i++) {
+          cu += (int64_t)u[i] * f0 + (int64_t)v[i] * g0 + (int64_t)qu * md[i];
+          cv += (int64_t)u[i] * f1 + (int64_t)v[i] * g1 + (int64_t)qv * md[i];
+          nu[i - 1] = (int32_t)((uint32_t)cu & MASK); nv[i - 1] = (int32_t)((uint32_t)cv & MASK);
+          cu >>= LB; cv >>= LB;
+        }
+        nu[8] = (int32_t)cu; nv[8] = (int32_t)cv;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { u[i] = nu[i]; v[i] = nv[i]; }
+      }
+    }
+    // |v| < 12 m (fp_inv's bound: the cofactors grow by less than m / 2 + |f| + |g| digits' worth per round): w = v + 16 m in (4 m, 28 m), then
+    // conditional subtractions of 16 m, 8 m, 4 m, 2 m, m bring it into [0, m)
+    int64_t w[9];
+    {
+      int64_t c = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) { c += (int64_t)v[i] + 16 * (int64_t)md[i]; w[i] = i < 8 ? (int64_t)((uint64_t)c & MASK) : c; c = i < 8 ? (c >> LB) : 0; }
+    }
+#pragma unroll
+    for (int k = 16; k >= 1; k >>= 1) {
+      int64_t t[9], c = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) { c += w[i] - (int64_t)k * md[i]; t[i] = i < 8 ? (int64_t)((uint64_t)c & MASK) : c; c = i < 8 ? (c >> LB) : 0; }
+      const bool ge = t[8] >= 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) w[i] = ge ? t[i] : w[i];
+    }
+    FrM r = {{0, 0, 0, 0}};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int bit = LB * i, wd = bit >> 6, sh = bit & 63;
+      r.l[wd] |= (uint64_t)w[i] << sh;
+      if (sh > 64 - LB && wd + 1 < 4) r.l[wd + 1] |= (uint64_t)w[i] >> (64 - sh);
+    }
+    return r;
+  }
+  // The classic binary extended Euclidean algorithm on the canonical value (HAC 14.61 for an odd modulus): kept as the cross-check of inverse()
+  // (tests/test_capi_cpu.py::test_fr_inverse_binary_gcd).  Its loops run a data-dependent number of times: never on the device.
+  PL_HD FrM inverse_bgcd(const FrM& a) const {
     FrM u = to_canon(a), v = {{m[0], m[1], m[2], m[3]}}, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
     if (is_zero(u)) return u;
     auto is_one = [](const FrM& t) { return t.l[0] == 1 && !(t.l[1] | t.l[2] | t.l[3]); };
@@ -518,6 +652,18 @@ PL_HD void put_term(MsmTerm& t, const G1Aff& p, const FrM& k, uint8_t* flag) {
   t.k[4] = (uint32_t)g.k2[0]; t.k[5] = (uint32_t)(g.k2[0] >> 32); t.k[6] = (uint32_t)g.k2[1]; t.k[7] = (uint32_t)(g.k2[1] >> 32);
   *flag = (uint8_t)((*flag & 1) | (g.neg1 ? 2 : 0) | (g.neg2 ? 4 : 0));
 }
+// a key-side (fixed-base) term: only its scalar travels, as 8 canonical words -- the byte windows of the key's table of that point (bn254_msm.h)
+PL_HD void put_fixed(MsmTerm& t, const FrM& k, uint8_t* flag) {
+  for (int i = 0; i < 2 * BN_NL; i++) t.pt[i] = 0;
+  fr_ctx().to_words(t.k, k);
+  *flag = 0;
+}
+// a term with the scalar +-1: the point itself (flag bit 1: negated)
+PL_HD void put_unit(MsmTerm& t, const G1Aff& p, bool neg, uint8_t* flag) {
+  { const Fp cx = fp_reduce(fp_norm(p.x)), cy = fp_reduce(fp_norm(p.y)); for (int i = 0; i < BN_NL; i++) { t.pt[i] = cx.v[i]; t.pt[BN_NL + i] = cy.v[i]; } }
+  for (int i = 0; i < 8; i++) t.k[i] = 0;
+  *flag = (uint8_t)((*flag & 1) | (neg ? 2 : 0));
+}
 struct PlonkWork {
   int status;                 // PL_OK while the proof is still alive, else the final status
   PlonkProof pr;
@@ -527,6 +673,41 @@ struct PlonkWork {
 enum { PLONK_STAGE1_TERMS_BASE = 10 };  // + n_bsb
 PL_HD int plonk_stage1_terms(const PlonkKey& vk) { return PLONK_STAGE1_TERMS_BASE + (int)vk.n_qcp; }
 PL_HD int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }   // lin_digest, lro x3, s1, s2, qcp.., z, kzg_g1, batch_h, zs_h
+// The key's points that enter the MSMs with per-proof scalars get byte-window tables at bn254_plonk_vk_prepare (bn254_host.hpp::build_window_table, 653 KB each):
+// table numbers, and which terms of the two MSM launches are variable-base (proof points), fixed-base (key points) or a bare point (scalar -1).
+enum { PLONK_TAB_QL = 0, PLONK_TAB_QR, PLONK_TAB_QM, PLONK_TAB_QO, PLONK_TAB_QK, PLONK_TAB_S3, PLONK_TAB_S1, PLONK_TAB_S2, PLONK_TAB_KZG_G1, PLONK_TAB_QCP0 };
+inline int plonk_num_tables(const PlonkKey& vk) { return (int)PLONK_TAB_QCP0 + (int)vk.n_qcp; }
+inline const G1Aff& plonk_table_point(const PlonkKey& vk, int t) {
+  switch (t) {
+    case PLONK_TAB_QL: return vk.ql; case PLONK_TAB_QR: return vk.qr; case PLONK_TAB_QM: return vk.qm; case PLONK_TAB_QO: return vk.qo; case PLONK_TAB_QK: return vk.qk;
+    case PLONK_TAB_S3: return vk.s[2]; case PLONK_TAB_S1: return vk.s[0]; case PLONK_TAB_S2: return vk.s[1]; case PLONK_TAB_KZG_G1: return vk.kzg_g1;
+    default: return vk.qcp[t - PLONK_TAB_QCP0];
+  }
+}
+// stage 1 (term order of PlonkStage1::b): bsb[0..q) | ql qr qm qo qk s3 | z h0 h1 h2
+inline void plonk_msm1_shape(const PlonkKey& vk, MsmShape& sh) {
+  memset(&sh, 0, sizeof sh);
+  const int q = (int)vk.n_qcp;
+  sh.n_sums = 1;
+  for (int i = 0; i < q; i++) sh.var_term[0][sh.n_var[0]++] = (int8_t)i;
+  for (int i = 0; i < 6; i++) { sh.fixed_term[0][sh.n_fixed[0]] = (int8_t)(q + i); sh.fixed_tab[0][sh.n_fixed[0]++] = (int8_t)(PLONK_TAB_QL + i); }
+  for (int i = 0; i < 4; i++) sh.var_term[0][sh.n_var[0]++] = (int8_t)(q + 6 + i);
+}
+// stage 2 (term order of plonk_stage2): P0 = lin l r o | s1 s2 qcp[0..q) | z | kzg_g1 | batch_h zs_h ;  P1 = batch_h (scalar -1) | zs_h
+inline void plonk_msm2_shape(const PlonkKey& vk, MsmShape& sh) {
+  memset(&sh, 0, sizeof sh);
+  const int q = (int)vk.n_qcp;
+  sh.n_sums = 2;
+  for (int i = 0; i < 4; i++) sh.var_term[0][sh.n_var[0]++] = (int8_t)i;
+  sh.fixed_term[0][sh.n_fixed[0]] = 4; sh.fixed_tab[0][sh.n_fixed[0]++] = PLONK_TAB_S1;
+  sh.fixed_term[0][sh.n_fixed[0]] = 5; sh.fixed_tab[0][sh.n_fixed[0]++] = PLONK_TAB_S2;
+  for (int i = 0; i < q; i++) { sh.fixed_term[0][sh.n_fixed[0]] = (int8_t)(6 + i); sh.fixed_tab[0][sh.n_fixed[0]++] = (int8_t)(PLONK_TAB_QCP0 + i); }
+  sh.var_term[0][sh.n_var[0]++] = (int8_t)(6 + q);
+  sh.fixed_term[0][sh.n_fixed[0]] = (int8_t)(7 + q); sh.fixed_tab[0][sh.n_fixed[0]++] = PLONK_TAB_KZG_G1;
+  sh.var_term[0][sh.n_var[0]++] = (int8_t)(8 + q); sh.var_term[0][sh.n_var[0]++] = (int8_t)(9 + q);
+  sh.unit_term[1][sh.n_unit[1]++] = (int8_t)(10 + q);
+  sh.var_term[1][sh.n_var[1]++] = (int8_t)(11 + q);
+}
 
 // Stage 1 (plonk/verify.rs:46-284): everything up to the scalars of the linearised polynomial digest.  On a failed check the
 // proof's final status is returned and its terms are left zeroed.
@@ -550,7 +731,9 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   const FrCtx& F = fr_ctx();
   vkp = &vk; proof = proof_; inputs = inputs_; n_inputs = n_inputs_; wkp = &wk;
   PlonkProof& pr = wk.pr;
+  PL_MARK(1);
   int st = parse_plonk_proof(pr, proof, proof_len);                       // lib.rs:70
+  PL_MARK(2);
   if (st != PL_OK) return st;
   if (pr.n_bsb != vk.n_qcp) return PL_BSB22;                              // verify.rs:52-54
   if (n_inputs != vk.nb_public) return PL_INPUT_LEN;                      // verify.rs:57-59 (InvalidWitness)
@@ -562,6 +745,7 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   cg.bind(inputs, 32 * n_inputs);                                         // the public inputs as stored (raw big-endian)
   cg.bind(proof, 192);                                                    // l, r, o
   gamma = cg.finish(dg);
+  PL_MARK(3);
   Challenge cb("beta", 4, dg); beta = cb.finish(db);
   Challenge ca("alpha", 5, db);
   ca.bind(proof + pr.off_bsb, 64 * (size_t)pr.n_bsb);
@@ -570,6 +754,7 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   Challenge cz("zeta", 4, da);
   cz.bind(proof + 256, 192);                                              // h0, h1, h2
   zeta = cz.finish(dz);
+  PL_MARK(4);
   wk.zeta = zeta;
   // verify.rs:97-107
   zeta_n = F.pow_u64(zeta, vk.size);
@@ -589,6 +774,7 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   for (uint64_t i = 0; i < vk.n_cci; i++) den[nden++] = F.sub(zeta, vk.wpow[i]);
   acc = one;
   for (int i = 0; i < nden; i++) { zero[i] = F.is_zero(den[i]); pre[i] = acc; if (!zero[i]) acc = F.mul(acc, den[i]); }
+  PL_MARK(5);
   return PL_OK;
 }
 PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
@@ -596,6 +782,7 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   const PlonkKey& vk = *vkp; PlonkWork& wk = *wkp; PlonkProof& pr = wk.pr;
   const FrM one = F.one;
   FrM inv[MAXDEN];
+  PL_MARK(6);
   {
     FrM ai = acc_inv;
     for (int i = nden - 1; i >= 0; i--) {
@@ -614,12 +801,14 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
     pi = F.add(pi, x);
   }
   // verify.rs:139-163: BSB22 commitments enter the public-input polynomial through hash_to_field
+  PL_MARK(7);
   for (uint64_t i = 0; i < vk.n_cci; i++) {
     FrM hashed = bsb22_hash_to_field(proof + pr.off_bsb + 64 * i);
     FrM lag = F.mul(F.mul(F.mul(zs, vk.wpow[i]), inv[1 + n_in + i]), hashed);
     pi = F.add(pi, lag);
   }
   // verify.rs:165-214: the constant term of the linearised polynomial must equal the claimed opening
+  PL_MARK(8);
   const FrM &l = pr.claimed[1], &r = pr.claimed[2], &o = pr.claimed[3], &s1 = pr.claimed[4], &s2 = pr.claimed[5], &zu = pr.zs_value;
   FrM a2l1 = F.mul(F.mul(lagrange_one, alpha), alpha);
   FrM cl = F.add(F.add(F.mul(beta, s1), gamma), l);
@@ -653,12 +842,15 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   zn2sq = F.neg(F.mul(zn2sq, zh_zeta));
   FrM zh = F.neg(zh_zeta);
   // verify.rs:252-284: the MSM of the linearised polynomial digest
+  PL_MARK(9);
   int np = 0;
   auto put = [&](const G1Aff& p, const FrM& k) { tflags[np] = 0; put_term(terms[np], p, k, &tflags[np]); np++; };
+  auto fix = [&](const FrM& k) { put_fixed(terms[np], k, &tflags[np]); np++; };          // key-side points: fixed-base tables (plonk_msm1_shape)
   for (uint32_t i = 0; i < pr.n_bsb; i++) put(pr.bsb[i], pr.claimed[6 + i]);
-  put(vk.ql, l); put(vk.qr, r); put(vk.qm, rl); put(vk.qo, o);
-  put(vk.qk, one); put(vk.s[2], _s1); put(pr.z, coeff_z);
+  fix(l); fix(r); fix(rl); fix(o);                                                         // ql, qr, qm, qo
+  fix(one); fix(_s1); put(pr.z, coeff_z);                                                  // qk, s3
   put(pr.h[0], zh); put(pr.h[1], zn2); put(pr.h[2], zn2sq);
+  PL_MARK(10);
   return PL_OK;
 }
 PL_HD int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_inputs,
@@ -699,6 +891,7 @@ PL_HD void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWor
   cg.bind(proof + pr.off_claimed, 32 * (size_t)nd);         // the claimed values as stored
   cg.bind(proof + pr.off_zs_h + 64, 32);                    // z(zeta omega) as stored
   FrM kgamma = cg.finish(dgam);
+  PL_MARK(17);
   FrM gi[PLONK_MAX_QCP + 6];
   gi[0] = F.one;
   for (int i = 1; i < nd; i++) gi[i] = F.mul(gi[i - 1], kgamma);
@@ -709,19 +902,22 @@ PL_HD void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWor
   FrM fe = F.add(folded_eval, F.mul(pr.zs_value, lam));
   FrM shifted = F.mul(wk.zeta, vk.generator);
   int np = 0;
+  PL_MARK(18);
   for (int j = 0; j < plonk_stage2_terms(vk) + 2; j++) t0_inf[j] = 0;
   auto put = [&](const G1Aff& p, const FrM& k) { put_term(t0[np], p, k, &t0_inf[np]); np++; };
+  auto fix = [&](const FrM& k) { put_fixed(t0[np], k, &t0_inf[np]); np++; };              // key-side points: fixed-base tables (plonk_msm2_shape)
   t0_inf[np] = lin_inf ? 1 : 0; put(lin, gi[0]);
   put(pr.lro[0], gi[1]); put(pr.lro[1], gi[2]); put(pr.lro[2], gi[3]);
-  put(vk.s[0], gi[4]); put(vk.s[1], gi[5]);
-  for (uint32_t i = 0; i < vk.n_qcp; i++) put(vk.qcp[i], gi[6 + i]);
+  fix(gi[4]); fix(gi[5]);                                                                  // s1, s2
+  for (uint32_t i = 0; i < vk.n_qcp; i++) fix(gi[6 + i]);                                  // qcp[i]
   put(pr.z, lam);
-  put(vk.kzg_g1, F.neg(fe));
+  fix(F.neg(fe));                                                                          // kzg_g1
   put(pr.batch_h, wk.zeta);
   put(pr.zs_h, F.mul(lam, shifted));
-  // P1 = -(H_batch + lambda H_zs): the two terms follow P0's (t1 = t0 + plonk_stage2_terms(vk), their flags likewise)
-  put_term(t1[0], pr.batch_h, F.neg(F.one), &t0_inf[np]);
+  // P1 = -(H_batch + lambda H_zs): the two terms follow P0's (t1 = t0 + plonk_stage2_terms(vk), their flags likewise); the first is the bare point, negated
+  put_unit(t1[0], pr.batch_h, true, &t0_inf[np]);
   put_term(t1[1], pr.zs_h, F.neg(lam), &t0_inf[np + 1]);
+  PL_MARK(19);
 }
 
 }  // namespace bn254host

@@ -170,42 +170,6 @@ BN_HD G1Proj g1_mul_glv_w(const G1Aff& P, const uint32_t* k1, bool neg1, const u
   return acc;
 }
 BN_HD G1Proj g1_mul_glv(const G1Aff& P, const uint32_t k[4]) { return g1_mul_glv_w<2>(P, k, false, k + 2, false); }
-// The same with TWO bits of each half per step: acc <- 4 acc + (d1 P1 + d2 P2), d1, d2 in 0..3, from a table of the 15 non-zero combinations
-// i P1 + j P2 at index 4 i + j.  16 W steps of (2 doublings + 1 addition) + 13 point operations for the table, against 32 W steps of
-// (doubling + addition): 0.75 of the chain.  The table lives where TAB puts it (k_g1_scalar_mul: 15 x 28 dwords of global memory per lane --
-// one contiguous 108-byte read per step, issued before the doublings; the host test keeps it in an array): it is only worth it where one lane's
-// chain is the launch time.
-template <int W, class TAB>
-BN_HD G1Proj g1_mul_glv_w2(const G1Aff& P, const uint32_t* k1, bool neg1, const uint32_t* k2, bool neg2, TAB& tab) {
-  G1Aff P1 = P, P2;
-  P1.y = fp_select(neg1, fp_neg(P.y), P.y);
-  P2.x = fp_mul(P.x, fp_from_limbs(BN_GLV_BETA)); P2.y = fp_select(neg2, fp_neg(P.y), P.y);
-  {
-    G1Proj a[4], b[4];
-    a[1] = g1_from_affine(P1); a[2] = g1_dbl(a[1]); a[3] = g1_add_mixed(a[2], P1);
-    b[1] = g1_from_affine(P2); b[2] = g1_dbl(b[1]); b[3] = g1_add_mixed(b[2], P2);
-    for (int i = 1; i < 4; i++) { tab.put(4 * i, a[i]); tab.put(i, b[i]); }
-    for (int i = 1; i < 4; i++) for (int j = 1; j < 4; j++) tab.put(4 * i + j, g1_add(a[i], b[j]));
-  }
-  tab.fence();
-  G1Proj acc = g1_identity();
-  uint32_t a[W], b[W];
-#pragma unroll
-  for (int i = 0; i < W; i++) { a[i] = k1[i]; b[i] = k2[i]; }
-  for (int step = 0; step < 16 * W; step++) {
-    const uint32_t idx = ((a[W - 1] >> 30) << 2) | (b[W - 1] >> 30);
-#pragma unroll
-    for (int i = W - 1; i > 0; i--) { a[i] = (a[i] << 2) | (a[i - 1] >> 30); b[i] = (b[i] << 2) | (b[i - 1] >> 30); }
-    a[0] <<= 2; b[0] <<= 2;
-    const G1Proj q = tab.get(idx != 0 ? idx : 1u);
-    acc = g1_dbl(g1_dbl(acc));
-    const G1Proj c = g1_add(acc, q);
-    const bool take = idx != 0;
-    acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
-  }
-  return acc;
-}
-
 // ---- per proof: A <- r A (affine), C' <- r C (projective), t_0 = r, t_j = r x_j ---------------------------------------------------------------------
 // LX(j, out_words[8]): the j-th public input of this proof as little-endian words (raw 256-bit value, used modulo r like bn::Fr)
 template <class W, class LX>

@@ -10,6 +10,7 @@
 #include "../../snark-bn254-verifier_amd/csrc/bn254_pairing.h"
 #include "../../snark-bn254-verifier_amd/csrc/bn254_vm.h"
 #include "../../snark-bn254-verifier_amd/csrc/bn254_rlc.h"
+#include "../../snark-bn254-verifier_amd/csrc/bn254_msm.h"
 #endif
 #include <cstring>
 using namespace bn254;

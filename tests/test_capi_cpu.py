@@ -248,30 +248,28 @@ def test_glv_decomposition(pkg):
 
 
 def test_fr_inverse_binary_gcd(pkg):
-    """The inversion of the PlonK stages (binary extended GCD on 4 x 64-bit limbs, shared by the host path and the device kernels) against Python's
-    pow and against the Fermat form it replaced, in Fr and in Fp; 0 -> 0."""
+    """The inversion of the PlonK stages (constant-time binary GCD with approximated operands on 9 x 29-bit digits, shared by the host path and the device
+    kernels) against Python's pow, against the Fermat form and against the classic shift-and-subtract form it replaced on the device, in Fr and in Fp; 0 -> 0."""
     import random
     L = pkg.lib()
     R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
     P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
     rng = random.Random(12)
     for field, mod in ((0, R), (1, P)):
-        vals = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 255, (1 << 256) - 1] + [rng.randrange(1 << 256) for _ in range(60)] + [rng.randrange(1, 1 << k) for k in (3, 17, 64, 65, 128, 200)]
+        vals = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, 1 << 255, (1 << 256) - 1] + [rng.randrange(1 << 256) for _ in range(400)] + [rng.randrange(1, 1 << k) for k in (3, 17, 64, 65, 128, 200)]
         for v in vals:
-            o1 = (C.c_uint8 * 32)(); o2 = (C.c_uint8 * 32)()
+            o1 = (C.c_uint8 * 32)(); o2 = (C.c_uint8 * 32)(); o3 = (C.c_uint8 * 32)()
             assert L.bn254_dbg_fr_inverse(v.to_bytes(32, "big"), o1, 0, field) == 0 and L.bn254_dbg_fr_inverse(v.to_bytes(32, "big"), o2, 1, field) == 0
+            assert L.bn254_dbg_fr_inverse(v.to_bytes(32, "big"), o3, 2, field) == 0
             want = pow(v % mod, -1, mod) if v % mod else 0
-            assert int.from_bytes(bytes(o1), "big") == want == int.from_bytes(bytes(o2), "big"), (field, hex(v))
+            assert int.from_bytes(bytes(o1), "big") == want == int.from_bytes(bytes(o2), "big") == int.from_bytes(bytes(o3), "big"), (field, hex(v))
 
 
-def test_plonk_plan_and_scratch_sizing(pkg):
-    """The PlonK batch plan (sub-batches side by side, balanced passes of at most `piece` proofs) covers the batch exactly, and -- the round-3 heap overflow -- a context whose
-    capacity is a pass size rounded up to 256 proofs holds the window-table scratch of EVERY launch a batch of up to that many proofs can make: 11- and 13-term launches,
-    one or two lanes per term (bn254_dbg_msm_table_lanes: the lane count of a launch that uses the table, 0 if it does not)."""
+def test_plonk_plan(pkg):
+    """The PlonK batch plan (sub-batches side by side, balanced passes of at most `piece` proofs) covers the batch exactly.  (The sizing of the window-table scratch
+    against every launch a context can see -- the round-3 heap overflow -- is tests/test_msm_rows.py::test_plonk_context_scratch_holds_every_launch.)"""
     import ctypes as C
     L = pkg.lib()
-    L.bn254_dbg_plonk_scratch_lanes.restype = C.c_size_t; L.bn254_dbg_plonk_scratch_lanes.argtypes = [C.c_size_t, C.c_int]
-    L.bn254_dbg_msm_table_lanes.restype = C.c_size_t; L.bn254_dbg_msm_table_lanes.argtypes = [C.c_size_t, C.c_int]
     L.bn254_dbg_plonk_plan.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     for n in list(range(1, 300)) + [4096, 5039, 5040, 5041, 6144, 10080, 10081, 20000, 40320, 40321, 65536, 100000, 131072, 262144, 1000003]:
         for piece, mw in ((5040, 8), (5040, 4), (700, 3), (65536, 1)):
@@ -283,12 +281,3 @@ def test_plonk_plan_and_scratch_sizing(pkg):
             assert w == 1 or n > piece                         # one sub-batch while a single pass holds the batch
             passes = -(-per // ps)
             assert passes * ps >= per and (passes - 1) * ps < per and passes == -(-per // piece)   # no more passes than the piece size forces, all of one size
-    # the scratch of a context of capacity `need` against every batch size it can see; the windows the old sizing missed are 4333..5041 and 2167..2520 proofs
-    for need in list(range(256, 8193, 256)) + [16384, 65536]:
-        cap = L.bn254_dbg_plonk_scratch_lanes(need, 13)
-        assert cap <= 65536
-        ms = set(range(max(1, need - 255), need + 1)) | set(range(1, need + 1, 97)) | {m for m in (2166, 2167, 2520, 2521, 4332, 4333, 4864, 5040, 5041, 5042) if m <= need}
-        for m in ms:
-            for t in (11, 13, 2, 1):
-                assert L.bn254_dbg_msm_table_lanes(m, t) <= cap, (need, m, t)
-    assert L.bn254_dbg_msm_table_lanes(5000, 13) == 65000 and L.bn254_dbg_msm_table_lanes(2500, 13) == 65000      # the two launches that overflowed
