@@ -206,6 +206,13 @@ void bn254_set_profiling(int enabled);
 void bn254_set_profile_kernels(unsigned mask);
 int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[BN254_G16_NUM_KERNELS]);
 int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallback_share, unsigned* bypassed_calls);   /* BN254_FLAG_RLC, adaptive use */
+/* A large batch runs as two sub-batches on two streams; the HIP runtime maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+ * streams that share a queue run one after the other.  The library does not touch the environment (GPU_MAX_HW_QUEUES=8 is a deployment setting);
+ * it measures: the first two-stream batch of a (key, device) is bracketed with events, a later call reads them.  overlap = sum of the two sub-batches' durations /
+ * their union (~2 side by side, ~1 one after the other; -1 not measured yet); single_stream = 1: the streams were found serialised and batches that fit one launch
+ * now run as one sub-batch.  bn254_last_diagnostic (thread-local, like bn254_last_error) carries the one-line explanation when that happens. */
+int bn254_groth16_stream_overlap(const bn254_g16_pvk* pvk, int device, float* overlap, int* single_stream);
+const char* bn254_last_diagnostic(void);
 /* Knobs of BN254_FLAG_RLC (process-wide, atomics; a negative argument leaves that knob alone): the batch size from which the flag is honoured
  * (default 200 000, never below 64), the adaptive bypass on / off, and the lanes a launch part must keep for its proofs to share Miller-loop
  * accumulators (default 65536).  The environment variables BN254_RLC_MIN_BATCH / BN254_RLC_ADAPTIVE / BN254_RLC_SHARE_MIN_LANES give the
@@ -258,6 +265,16 @@ int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2
  * variable term, pos_lo, pos_hi, unit term, sum, scratch slot, fixed windows [lo, hi)); and the scratch lanes a context of `capacity` proofs allocates for launches
  * of n_var variable terms.  tests/test_capi_cpu.py: need <= allocation for every n <= capacity. */
 int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per_worker, size_t* per_pass);
+/* host-only probe of the Groth16 plan (csrc/bn254_g16_plan.h: the functions the library itself allocates and enqueues by): a key with key_inputs public inputs
+ * (comb != 0: comb tables), a context reserved for `reserved` proofs, a batch of n proofs with n_public inputs each.  alloc = {workspace bytes, partial-sum bytes,
+ * digit bytes, proofs per launch of the wide MSM}; out: 8 values per launch {chunk, first proof in the chunk, proofs, stream slot (-1 = the caller's stream),
+ * form (0 lane kernels, 1 cooperative, 2 latency mode), Miller steps per launch, first workspace byte, one past its last}.  tests/test_capi_cpu.py walks batch
+ * sizes against reservations: every launch inside the allocation, concurrent launches disjoint, the batch covered exactly once. */
+int bn254_dbg_g16_plan(size_t key_inputs, int comb, size_t reserved, size_t n, size_t n_public, int n_streams, int single_stream, uint64_t alloc[4], uint64_t* out,
+                       int max_launches, int* n_launches);
+/* ... and of BN254_FLAG_RLC's group status bytes: what the launch parts of a chunk of m proofs address (need) against what a context whose RLC buffers were sized
+ * for `reserved` proofs holds (alloc) */
+int bn254_dbg_g16_rlc_plan(size_t reserved, size_t m, int n_streams, int log2_group, int log2_share, size_t min_lanes, uint64_t* need, uint64_t* alloc);
 size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int n_var);
 int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget, int* n_rows, int* n_var_rows, size_t* scratch_lanes, int* chain, int sum_rows[2],
                              int fixed_terms[2], int* rows_out);

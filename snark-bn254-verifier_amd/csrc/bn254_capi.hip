@@ -13,6 +13,7 @@
 #include "bn254_host.hpp"
 #include "bn254_plonk.hpp"
 #include "bn254_rlc.h"
+#include "bn254_g16_plan.h"
 #include <sys/random.h>
 #include <atomic>
 #include <thread>
@@ -43,9 +44,11 @@ hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_
 
 // The HIP runtime multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues -- four by default -- and streams that share a queue run one
 // after the other: the two sub-batch streams of a large Groth16 batch then lose their overlap once a third party (RCCL) has streams too, and eight PlonK chains
-// run at 1.20 instead of 1.51 M proofs/s (profiles/r03_batch_sweep_fine.txt).  The runtime reads the variable when it initialises, at the first HIP call of the
-// process; loading this library asks for eight queues unless the environment already says something.  (No effect if the runtime is up already.)
-__attribute__((constructor)) static void bn254_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// run at 1.20 instead of 1.51 M proofs/s (profiles/r03_batch_sweep_fine.txt).  The runtime reads the variable when it initialises, so it is a DEPLOYMENT setting
+// (GPU_MAX_HW_QUEUES=8 in the environment of the process); the library does not touch the environment.  What it does instead: the first batch
+// that runs two sub-batch streams brackets them with events, the next call reads the overlap (bn254_groth16_stream_overlap), and a device whose sub-batch streams
+// were found to run one after the other gets one sub-batch per launch from then on (same work, fewer launches) and a line in bn254_last_diagnostic().
+static thread_local std::string g_diag;
 static thread_local std::string g_err;
 static std::atomic<int> g_profiling{0};
 static std::atomic<unsigned> g_prof_mask{0xffffffffu};
@@ -107,6 +110,9 @@ struct DevState {
   // the same for the SECOND sub-batch (its launches run on another stream beside the first's): bn254_groth16_kernel_profile_all
   std::vector<hipEvent_t> prof2_ev; std::vector<uint8_t> prof2_kid; G16Prof prof2{0, nullptr, nullptr, 0, 0}; bool prof2_used = false;
   RlcDev rlc;                                                       // BN254_FLAG_RLC buffers (bn254_rlc.hpp)
+  // do the sub-batch streams overlap?  ov_ev: start / end of part 0 and of part 1 of the first two-stream batch; ov_state 0: not measured, 1: events recorded,
+  // 2: measured (ov_ratio = sum of the two durations / their union: ~2 side by side, ~1 one after the other); single_stream: fall back to one sub-batch per launch
+  hipEvent_t ov_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int ov_state = 0; float ov_ratio = -1.f; bool single_stream = false;
 };
 struct bn254_g16_pvk {
   G16Prepared host;
@@ -144,28 +150,21 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
     HIPCK(hipEventCreateWithFlags(&d.busy_ev, hipEventDisableTiming));
     d.ready = true;
   }
-  if ((n > G16_MAX_BATCH ? (size_t)G16_MAX_BATCH : n) > d.ws_cap) {
+  // what a reservation of n proofs needs (bn254_g16_plan.h: the same function the plan probe and its property test read)
+  const G16Alloc need = g16_alloc_for(n, pvk->host.n_k - 1, pvk->host.msm_comb);
+  if (need.ws_proofs > d.ws_cap) {
     if (d.ws) HIPCK(hipFree(d.ws));   // hipFree waits for the device: no batch is still using the old workspace
     d.ws = nullptr; d.ws_cap = 0;
-    size_t cap = (n + 255) / 256 * 256;
-    if (cap > G16_MAX_BATCH) cap = G16_MAX_BATCH;  // larger batches run in chunks (32-bit buffer offsets)
-    HIPCK(hipMalloc((void**)&d.ws, cap * (size_t)G16_WS_BYTES_PER_PROOF));
-    d.ws_cap = cap;
+    HIPCK(hipMalloc((void**)&d.ws, need.ws_proofs * (size_t)G16_WS_BYTES_PER_PROOF));
+    d.ws_cap = need.ws_proofs;
   }
   // keys with many public inputs: partial sums (and comb digits) of the public-input MSM, for the proofs of one launch.  Sized HERE (reserve /
   // the entry points call ensure_dev before they enqueue), so that the enqueue path itself never allocates or frees
-  if (pvk->host.n_k - 1 > (size_t)G16_WIDE_MSM_MIN_INPUTS) {
-    const size_t n_public = pvk->host.n_k - 1;
-    const size_t need = n < (size_t)G16_WIDE_MSM_MAX_PROOFS ? (n + 255) / 256 * 256 : (size_t)G16_WIDE_MSM_MAX_PROOFS;
-    if (need > d.msm_part_cap) {
-      if (d.msm_part) HIPCK(hipFree(d.msm_part));
-      d.msm_part = nullptr; d.msm_part_cap = 0;
-      const size_t chunks = (n_public + G16_WIDE_MSM_INPUTS_PER_LANE - 1) / G16_WIDE_MSM_INPUTS_PER_LANE;
-      // comb tables: + the column digits of every scalar (G16_COMB_COLS x u16 per input, transposed so that the lanes of a wavefront read neighbours)
-      const size_t digits = pvk->host.msm_comb ? (size_t)G16_COMB_COLS * n_public * need * sizeof(uint16_t) : 0;
-      HIPCK(hipMalloc((void**)&d.msm_part, chunks * 27 * need * sizeof(int32_t) + digits));
-      d.msm_part_cap = need; d.msm_chunks = chunks;
-    }
+  if (need.msm_part_proofs > d.msm_part_cap) {
+    if (d.msm_part) HIPCK(hipFree(d.msm_part));
+    d.msm_part = nullptr; d.msm_part_cap = 0;
+    HIPCK(hipMalloc((void**)&d.msm_part, need.msm_part_bytes + need.msm_digit_bytes));
+    d.msm_part_cap = need.msm_part_proofs; d.msm_chunks = need.msm_chunks;
   }
   if (g_profiling.load() && !d.ev_ready) {
     for (int i = 0; i < 5; i++) HIPCK(hipEventCreate(&d.ev[i]));
@@ -200,6 +199,7 @@ static void dev_free(DevState& d) {
   for (int i = 0; i < d.aux_count; i++) (void)hipStreamDestroy(d.aux[i]);
   if (d.fork_ev) { (void)hipEventDestroy(d.fork_ev); for (int i = 0; i < 4; i++) (void)hipEventDestroy(d.join_ev[i]); }
   if (d.busy_ev) (void)hipEventDestroy(d.busy_ev);
+  for (auto& e : d.ov_ev) if (e) (void)hipEventDestroy(e);
   if (d.host_stream) (void)hipStreamDestroy(d.host_stream);
   if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
   for (int i = 0; i < 3; i++) { if (d.pin[i]) (void)hipHostFree(d.pin[i]); if (d.pin_ev[i]) (void)hipEventDestroy(d.pin_ev[i]); }
@@ -326,11 +326,22 @@ static void plonk_plan(size_t n, size_t piece, int max_workers, int* workers, si
   const size_t npass = (p + piece - 1) / piece;
   *workers = w; *per = p; *pass = npass ? (p + npass - 1) / npass : p;
 }
-static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n) {
+// n: proofs of the largest pass the context will run; in_bytes: the proof + input bytes of such a pass (device-side stages: staged through pinned memory).  Everything a pass
+// needs is sized HERE, before anything is enqueued: the run path itself neither allocates nor frees (a hipFree is a device-wide synchronisation while other contexts are in flight).
+static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n, size_t in_bytes) {
   if (!c.stream) {
     HIPCK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking)); HIPCK(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
     for (auto& e : c.tk) HIPCK(hipEventCreate(&e));
+  }
+  if (in_bytes > c.in_cap) {
+    if (c.d_in) HIPCK(hipFree(c.d_in));
+    if (c.h_in) HIPCK(hipHostFree(c.h_in));
+    c.d_in = nullptr; c.h_in = nullptr; c.in_cap = 0;
+    const size_t cap = (in_bytes + 65535) / 65536 * 65536;
+    HIPCK(hipMalloc((void**)&c.d_in, cap));
+    HIPCK(hipHostMalloc((void**)&c.h_in, cap, hipHostMallocDefault));
+    c.in_cap = cap;
   }
   size_t need = n < PLONK_MAX_LAUNCH ? (n + 255) / 256 * 256 : (size_t)PLONK_MAX_LAUNCH;
   if (need <= c.cap) return BN254_OK;
@@ -534,32 +545,42 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
   // BN254_CHUNK_LOG2 (experiment): proofs per workspace chunk, default 2^20
   static const size_t chunk = [] { const char* e = getenv("BN254_CHUNK_LOG2"); int v = e ? atoi(e) : 20; if (v < 12) v = 12; if (v > 20) v = 20; return (size_t)1 << v; }();
   const int profiling = g_profiling.load();
+  // the overlap of the sub-batch streams, measured on an earlier batch: read it once it is there (no waiting)
+  if (d->ov_state == 1 && hipEventQuery(d->ov_ev[1]) == hipSuccess && hipEventQuery(d->ov_ev[3]) == hipSuccess) {
+    float a0 = 0, a1 = 0, s1 = 0, e1 = 0;
+    if (hipEventElapsedTime(&a0, d->ov_ev[0], d->ov_ev[1]) == hipSuccess && hipEventElapsedTime(&a1, d->ov_ev[2], d->ov_ev[3]) == hipSuccess &&
+        hipEventElapsedTime(&s1, d->ov_ev[0], d->ov_ev[2]) == hipSuccess && hipEventElapsedTime(&e1, d->ov_ev[0], d->ov_ev[3]) == hipSuccess) {
+      const float lo_ = s1 < 0 ? s1 : 0, hi_ = e1 > a0 ? e1 : a0;
+      d->ov_ratio = (a0 + a1) / (hi_ - lo_ > 1e-6f ? hi_ - lo_ : 1e-6f);
+      d->ov_state = 2;
+      static const bool fallback = [] { const char* e = getenv("BN254_STREAM_FALLBACK"); return !e || atoi(e) != 0; }();
+      if (d->ov_ratio < 1.15f) {
+        d->single_stream = fallback;
+        g_diag = "the two sub-batch streams of a Groth16 batch ran one after the other on this device (overlap " + std::to_string(d->ov_ratio) +
+                 "): the process's streams share a hardware queue -- set GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises (INTEGRATION.md)" +
+                 (fallback ? "; using one sub-batch per launch" : "");
+      }
+    } else d->ov_state = 2;
+  }
   for (size_t off = 0; off < n; off += chunk) {
     size_t m = n - off < chunk ? n - off : chunk;
-    // sub-batches on concurrent streams: the tail of one sub-batch's kernel overlaps the head of the other's
-    // keys with many public inputs (config 5): the MSM runs as (proof, chunk) lanes through a partial-sum buffer that is shared
-    // by the launches of a batch, so they stay on the caller's stream and cover at most G16_WIDE_MSM_MAX_PROOFS proofs each
-    const bool wide = n_public + 1 == pvk->host.n_k && n_public > (size_t)G16_WIDE_MSM_MIN_INPUTS;
-    const size_t max_launch = wide ? (size_t)G16_WIDE_MSM_MAX_PROOFS : (size_t)G16_MAX_LAUNCH;
-    if (wide) {
-      // the partial-sum buffer was sized by ensure_dev (bn254_groth16_reserve or the entry point itself): this path only enqueues
-      const size_t need = m < max_launch ? (m + 255) / 256 * 256 : max_launch;
-      if (need > d->msm_part_cap) return set_err(BN254_E_BAD_ARG, "workspace of a key with many public inputs is smaller than the batch: bn254_groth16_reserve first");
-    }
-    // Up to 65 536 proofs are one wavefront per SIMD at most: one sub-batch (13.4 against 16.9 ms at 49 152, 14.2 against 16.2 ms at 65 536 for two side by side;
-    // profiles/r03_mid_batch_sweep.txt), and up to COOP12_MAX_PROOFS the cooperative kernels take the batch whole.  Above that, n_streams sub-batches.
-    int parts = (!wide && n_streams > 1 && m > 65536) ? n_streams : 1;
-    while ((m + parts - 1) / parts > max_launch) parts++;      // 32-bit workspace offsets per launch
-    const bool concurrent = !wide && n_streams > 1 && parts > 1;
-    const bool split_small = m <= (size_t)G16_SPLIT_MAX_PROOFS;   // latency mode of bn254_launch_g16
+    G16ChunkPlan plan;
+    if (!g16_plan_chunk(plan, m, pvk->host.n_k - 1, n_public, n_streams, d->single_stream)) return set_err(BN254_E_BAD_ARG, "batch cannot be planned");
+    const bool wide = plan.wide, concurrent = plan.concurrent, split_small = plan.split_small;
+    const int parts = plan.parts;
+    // the buffers were sized by ensure_dev (bn254_groth16_reserve or the entry point itself): this path only enqueues, after checking the plan against them
+    if (m > d->ws_cap) return set_err(BN254_E_BAD_ARG, "workspace smaller than the batch: bn254_groth16_reserve first");
+    if (wide) for (int pi = 0; pi < parts; pi++)
+      if (plan.part[pi].count > d->msm_part_cap) return set_err(BN254_E_BAD_ARG, "workspace of a key with many public inputs is smaller than the batch: bn254_groth16_reserve first");
     if (concurrent || split_small) { int rc = ensure_aux(*d, concurrent ? parts - 1 : 2); if (rc) return rc; }
     if (concurrent) HIPCK(hipEventRecord(d->fork_ev, user));
-    size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
+    const bool measure_overlap = concurrent && parts == 2 && d->ov_state == 0;
+    if (measure_overlap) for (auto& e : d->ov_ev) if (!e) HIPCK(hipEventCreate(&e));
     for (int pi = 0; pi < parts; pi++) {
-      size_t lo = (size_t)pi * per, hi = lo + per < m ? lo + per : m;
-      if (lo >= hi) break;
+      const size_t lo = plan.part[pi].first, hi = lo + plan.part[pi].count;
       hipStream_t st = concurrent ? part_stream(*d, user, pi) : user;
       if (concurrent && pi < 4 && st != user) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
+      if (measure_overlap) HIPCK(hipEventRecord(d->ov_ev[2 * pi], st));
       G16LaunchArgs a;
       a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
       a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
@@ -590,8 +611,10 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : (prof_second ? &d->prof2 : nullptr));
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));
+      if (measure_overlap) HIPCK(hipEventRecord(d->ov_ev[2 * pi + 1], st));
       if (concurrent && (pi + 4 >= parts) && st != user) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
     }
+    if (measure_overlap) d->ov_state = 1;
   }
   d->ev_recorded = profiling && d->ev_ready;
   return BN254_OK;
@@ -615,7 +638,7 @@ static int rlc_ensure(const bn254_g16_pvk* pvk, DevState* d, size_t n, size_t n_
     if (r.h_status) HIPCK(hipHostFree(r.h_status));
     if (r.h_idx) HIPCK(hipHostFree(r.h_idx));
     r.grp_status = nullptr; r.idx = nullptr; r.h_status = nullptr; r.h_idx = nullptr; r.grp_cap = r.idx_cap = r.h_cap = 0;
-    const size_t cap = (n + 255) / 256 * 256 + 1024;   // group status regions of the launch parts are rounded up to 256 each
+    const size_t cap = g16_rlc_alloc(n);               // group status regions of the launch parts are rounded up to 256 each (bn254_g16_plan.h)
     HIPCK(hipMalloc((void**)&r.grp_status, cap));
     HIPCK(hipMalloc((void**)&r.idx, cap * sizeof(uint32_t)));
     HIPCK(hipHostMalloc((void**)&r.h_status, cap, hipHostMallocDefault));
@@ -641,8 +664,11 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
     int rc = rlc_ensure(pvk, d, m, n_public);
     if (rc) return rc;
     RlcDev& r = d->rlc;
-    int parts = (n_streams > 1 && m >= (size_t)n_streams * 16384) ? n_streams : 1;
-    while ((m + parts - 1) / parts > (size_t)G16_MAX_LAUNCH) parts++;
+    const int parts = g16_rlc_parts(m, n_streams);
+    {
+      const long ml0 = g_rlc_share_min_lanes.load();
+      if (g16_rlc_need(m, n_streams, log2_group, log2_share_env, ml0 < 1 ? 1 : (size_t)ml0) > g16_rlc_alloc(r.grp_cap)) return set_err(BN254_E_HIP, "RLC group buffer smaller than the batch (internal sizing error)");
+    }
     const bool concurrent = parts > 1;
     if (concurrent) { rc = ensure_aux(*d, parts - 1); if (rc) return rc; HIPCK(hipEventRecord(d->fork_ev, user)); }
     const size_t per = ((m + parts - 1) / parts + 255) / 256 * 256;
@@ -664,10 +690,8 @@ static int g16_enqueue_rlc(const bn254_g16_pvk* pvk, DevState* d, int device, co
       memcpy(ra.key, key, sizeof key);
       ra.counter_base = (uint32_t)(off + lo);
       // sharing needs enough lanes to fill the GPU; small parts keep one proof per lane
-      int log2_share = log2_share_env < log2_group ? log2_share_env : log2_group;
       const long ml = g_rlc_share_min_lanes.load();
-      const size_t min_lanes = ml < 1 ? 1 : (size_t)ml;
-      while (log2_share > 0 && (a.n >> log2_share) < min_lanes) log2_share--;
+      const int log2_share = g16_rlc_share(a.n, log2_group, log2_share_env, ml < 1 ? 1 : (size_t)ml);
       ra.plan = rlc_plan((uint32_t)a.n, log2_group, log2_share);
       ra.grp_status = r.grp_status + grp_off; grp_off += ((size_t)ra.plan.groups + 255) / 256 * 256;
       ra.btab = r.btab; ra.rlc_tab = r.tab; ra.one = r.one;
@@ -772,6 +796,58 @@ int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallbac
   std::lock_guard<std::mutex> lk(d->mu);
   if (fallback_share) *fallback_share = d->rlc.have_obs ? d->rlc.fb_share : -1.f;
   if (bypassed_calls) *bypassed_calls = d->rlc.bypassed_total;
+  return BN254_OK;
+}
+
+const char* bn254_last_diagnostic(void) { return g_diag.c_str(); }
+
+// How the two sub-batch streams of this (key, device) ran on the first batch that used two: sum of their durations / their union (about 2: side by side; about
+// 1: one after the other, i.e. they share a hardware queue -- see GPU_MAX_HW_QUEUES in INTEGRATION.md); -1 while no such batch has been measured.
+int bn254_groth16_stream_overlap(const bn254_g16_pvk* pvk, int device, float* overlap, int* single_stream) {
+  if (!pvk || !overlap) return set_err(BN254_E_BAD_ARG, "bad argument");
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  *overlap = d->ov_state == 2 ? d->ov_ratio : -1.f;
+  if (single_stream) *single_stream = d->single_stream ? 1 : 0;
+  return BN254_OK;
+}
+
+// Host-only probe of the Groth16 plan (bn254_g16_plan.h): for a key with key_inputs public inputs (comb: its MSM tables are in comb form), a context RESERVED for
+// `reserved` proofs and a batch of n proofs with n_public inputs each -- what the context allocates, and every launch the batch makes: out[] receives, per launch,
+// 8 values {chunk, first proof of the chunk, proofs, stream slot (-1: caller's stream, not concurrent), form (0 lanes, 1 cooperative, 2 latency mode), Miller steps
+// per launch, workspace bytes it addresses (first byte offset, one past the last)}; alloc[] = {workspace bytes, partial-sum bytes, digit bytes, proofs per wide launch}.
+// Returns the number of launches through *n_launches (at most max_launches are written).
+int bn254_dbg_g16_plan(size_t key_inputs, int comb, size_t reserved, size_t n, size_t n_public, int n_streams, int single_stream, uint64_t alloc[4], uint64_t* out,
+                       int max_launches, int* n_launches) {
+  if (!alloc || !out || !n_launches || n_streams < 1 || n_streams > 4) return set_err(BN254_E_BAD_ARG, "bad argument");
+  const G16Alloc a = g16_alloc_for(reserved, key_inputs, comb != 0);
+  alloc[0] = (uint64_t)a.ws_proofs * G16_WS_BYTES_PER_PROOF; alloc[1] = a.msm_part_bytes; alloc[2] = a.msm_digit_bytes; alloc[3] = a.msm_part_proofs;
+  int k = 0;
+  const size_t chunk = G16_MAX_BATCH;
+  int ci = 0;
+  for (size_t off = 0; off < n; off += chunk, ci++) {
+    const size_t m = n - off < chunk ? n - off : chunk;
+    G16ChunkPlan p;
+    if (!g16_plan_chunk(p, m, key_inputs, n_public, n_streams, single_stream != 0)) return set_err(BN254_E_BAD_ARG, "batch cannot be planned");
+    for (int pi = 0; pi < p.parts; pi++) {
+      const G16Part& q = p.part[pi];
+      const G16Form f = g16_launch_form(q.count, n_public, n_public == key_inputs, p.wide, p.parts > 1, p.split_small && p.parts == 1, true, -1);
+      if (k < max_launches) {
+        uint64_t* o = out + 8 * (size_t)k;
+        o[0] = (uint64_t)ci; o[1] = q.first; o[2] = q.count; o[3] = (uint64_t)(int64_t)q.stream_slot; o[4] = (uint64_t)f.form; o[5] = (uint64_t)f.run_steps;
+        o[6] = (uint64_t)q.first * G16_WS_BYTES_PER_PROOF; o[7] = (uint64_t)(q.first + q.count) * G16_WS_BYTES_PER_PROOF;
+      }
+      k++;
+    }
+  }
+  *n_launches = k;
+  return BN254_OK;
+}
+
+// ... and of the group status bytes of the RLC mode for a chunk of m proofs: what the launch parts address against what a context reserved for `reserved` proofs holds
+int bn254_dbg_g16_rlc_plan(size_t reserved, size_t m, int n_streams, int log2_group, int log2_share, size_t min_lanes, uint64_t* need, uint64_t* alloc) {
+  if (!need || !alloc || m == 0 || n_streams < 1 || n_streams > 4 || log2_group < 1 || log2_group > 16 || log2_share < 0 || log2_share > 3) return set_err(BN254_E_BAD_ARG, "bad argument");
+  *need = g16_rlc_need(m, n_streams, log2_group, log2_share, min_lanes); *alloc = g16_rlc_alloc(reserved);
   return BN254_OK;
 }
 
@@ -934,7 +1010,12 @@ int bn254_groth16_verify_batch(const bn254_g16_pvk* pvk, const uint8_t* proofs, 
     auto td = now();
     rc = g16_enqueue(pvk, d, device, d->st_proofs + computed * proof_stride, proof_stride, d->st_inputs + computed * in_row, n_public, c_end - computed,
                      d->st_status + computed, d->host_stream, flags, use_rlc);
-    if (rc) return rc;
+    if (rc) {   // pieces of the pinned ring and earlier chunks may still be in flight: the ring and the staging buffers must be quiescent when the lock is released
+      const std::string keep = g_err;
+      (void)hipStreamSynchronize(d->copy_stream); (void)hipStreamSynchronize(d->host_stream);
+      g_err = keep;
+      return rc;
+    }
     t_enq += ms(td, now());
     computed = c_end;
     c_end = n - c_end < hchunk ? n : c_end + hchunk;
@@ -1247,15 +1328,7 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto t0 = now();
   const size_t pb = m * proof_stride, ib = m * n_public * 32, need = pb + ib;
-  if (need > c.in_cap) {
-    if (c.d_in) HIPCK(hipFree(c.d_in));
-    if (c.h_in) HIPCK(hipHostFree(c.h_in));
-    c.d_in = nullptr; c.h_in = nullptr; c.in_cap = 0;
-    const size_t cap = (need + 65535) / 65536 * 65536;
-    HIPCK(hipMalloc((void**)&c.d_in, cap));
-    HIPCK(hipHostMalloc((void**)&c.h_in, cap, hipHostMallocDefault));
-    c.in_cap = cap;
-  }
+  if (need > c.in_cap) return set_err(BN254_E_HIP, "PlonK context staging smaller than the pass (internal sizing error)");   // sized by plonk_ensure_ctx
   uint32_t lam_key[11];
   for (size_t got = 0; got < sizeof lam_key;) {   // fresh per call, secret until the proofs are fixed (plonk_run has the reasoning)
     ssize_t k = getrandom((uint8_t*)lam_key + got, sizeof lam_key - got, 0);
@@ -1336,7 +1409,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   int workers; size_t per, pass_cap;                                  // sub-batches, proofs per sub-batch, proofs per (equal-sized) pass of a sub-batch
   plonk_plan(n, piece, max_workers, &workers, &per, &pass_cap);
   PlonkLease lease(d, workers);   // waits until that many contexts are free
-  for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap))) return rc;
+  for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap, dev_stages ? pass_cap * (proof_stride + n_public * 32) : 0))) return rc;
   std::vector<int> rcs(workers, BN254_OK); std::vector<std::string> errs(workers);
   auto body = [&](int w) {
     const size_t lo = (size_t)w * per, hi = lo + per < n ? lo + per : n;
@@ -1345,7 +1418,13 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
       int r = dev_stages ? plonk_run_device(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off)
                          : plonk_run(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
                                      (hw + workers - 1) / workers);
-      if (r) { rcs[w] = r; errs[w] = g_err; return; }
+      if (r) {
+        // work of this pass may still be enqueued on the context's streams: drain them before the lease hands the context (its staging, its term and status
+        // buffers) to the next call
+        rcs[w] = r; errs[w] = g_err;
+        (void)hipStreamSynchronize(lease.ctx(w).stream); (void)hipStreamSynchronize(lease.ctx(w).aux);
+        return;
+      }
     }
   };
   if (workers == 1) body(0);
@@ -1491,7 +1570,7 @@ int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, si
   }
   PlonkLease lease(d, 1);
   PlonkCtx& c = lease.ctx(0);
-  if ((rc = plonk_ensure_ctx(pvk, c, n))) return rc;
+  if ((rc = plonk_ensure_ctx(pvk, c, n, 0))) return rc;
   const size_t pb = n * proof_stride, ib = n * n_public * 32;
   DevBuf in, zo, so;
   HIPCK(hipMalloc((void**)&in.p, pb + ib + 4)); HIPCK(hipMalloc((void**)&zo.p, 32 * n)); HIPCK(hipMalloc((void**)&so.p, n));
@@ -1548,6 +1627,20 @@ int bn254_dbg_g2_subgroup(const uint8_t* g2, uint8_t* out_flags, size_t n, int d
   return run_probe(128, 0, 1, g2, nullptr, out_flags, n, device, [](const uint8_t* x, const uint8_t*, uint8_t* o, size_t m) { return bn254_launch_dbg_g2_subgroup(x, o, m, nullptr); });
 }
 
+#if defined(BN254_PLONK_MARKS)
+// diagnostics build: stage 1 of ONE proof on the host, and the intermediate values it dumped (bn254_plonk.hpp::PL_DUMP): the reference the device's dump is held to
+int bn254_dbg_plonk_dump_host(const bn254_plonk_pvk* pvk, const uint8_t* proof, size_t proof_len, const uint8_t* inputs, size_t n_public, uint8_t out[64 * 32], int* status) {
+  if (!pvk || !proof || !out || !status) return set_err(BN254_E_BAD_ARG, "bad argument");
+  PlonkWork wk; std::vector<MsmTerm> terms(plonk_stage1_terms(pvk->key)); std::vector<uint8_t> fl(terms.size());
+  memset(g_plonk_dump_host, 0, sizeof g_plonk_dump_host);
+  g_plonk_sha_n_host = 0;
+  wk.lambda = fr_ctx().one;
+  *status = plonk_stage1(pvk->key, proof, proof_len, inputs, n_public, wk, terms.data(), fl.data());
+  memcpy(out, g_plonk_dump_host, 64 * 32);
+  return BN254_OK;
+}
+int bn254_dbg_plonk_sha_dump_host(uint32_t out[32 * 24], uint32_t* n) { memcpy(out, g_plonk_sha_dump_host, sizeof g_plonk_sha_dump_host); *n = g_plonk_sha_n_host; return BN254_OK; }
+#endif
 // GLV decomposition probe (host only): k (32 bytes big-endian, any value: reduced mod r) -> |k1|, |k2| (16 bytes big-endian each) and signs
 int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2) {
   if (!k32 || !k1_16 || !k2_16 || !neg1 || !neg2) return set_err(BN254_E_BAD_ARG, "bad argument");

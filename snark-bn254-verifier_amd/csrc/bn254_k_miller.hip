@@ -60,9 +60,24 @@ __global__ void __launch_bounds__(256, 2) k_miller_run(int32_t* ws, uint32_t n, 
                 e_p1, (st & inf_mask1) != 0);
 }
 
+// the loop of two table-driven pairs without a variable pair (bn254_vm.h::vm_miller_run_fixed2): the pairing check of a large PlonK batch
+__global__ void __launch_bounds__(256, 2) k_miller_run_fixed2(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, MillerKinds kinds, int s_begin, int s_end, int e,
+                                                              const int32_t* __restrict__ tab0, int e_p0, int inf_mask0, const int32_t* __restrict__ tab1, int e_p1, int inf_mask1) {
+  __shared__ int32_t park_lds[72 * 256];
+  VM_KERNEL_PROLOGUE();
+  w.lds = park_lds;
+  DevLines lines{uni_ptr(tab0), uni_ptr(tab1)};
+  DevKinds dk{kinds};
+  vm_miller_run_fixed2(w, lines, dk, __builtin_amdgcn_readfirstlane(s_begin), __builtin_amdgcn_readfirstlane(s_end), e, e_p0, (st & inf_mask0) != 0, e_p1, (st & inf_mask1) != 0);
+}
+
 }  // namespace bn254
 
 using namespace bn254;
+void bn254_launch_miller_run_fixed2(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int e,
+                                    const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1) {
+  hipLaunchKernelGGL(k_miller_run_fixed2, dim3(grid), dim3(256), 0, s, ws, n, status, kinds, s_begin, s_end, e, tab0, ep0, inf0, tab1, ep1, inf1);
+}
 void bn254_launch_miller_run(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
                              int e, int epa, const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1) {
   hipLaunchKernelGGL(k_miller_run, dim3(grid), dim3(256), 0, s, ws, n, status, kinds, s_begin, s_end, et, eb, e, epa, tab0, ep0, inf0, tab1, ep1, inf1);

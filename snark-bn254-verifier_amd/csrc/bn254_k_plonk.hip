@@ -27,6 +27,10 @@ namespace bn254 {
 __device__ __forceinline__ const uint8_t* pl_stage_lds(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs, size_t n_public, uint32_t n,
                                                      uint32_t lane_stride, const uint8_t** lane_inputs) {
   extern __shared__ uint8_t pl_dyn_lds[];
+  // bn254_plonk.hpp::pl_lane_lds addresses the lanes' slots by LDS OFFSET (it may be compiled out of line, where the array has no name): that is only right while
+  // this array starts at offset 0, i.e. while neither the kernels nor anything the compiler places (a promoted alloca, a static __shared__ of an inlined callee)
+  // owns LDS in front of it.  If that ever changes the transcripts would hash foreign bytes: stop the launch instead.
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)pl_dyn_lds != 0u) __builtin_trap();
   if (threadIdx.x == 0) *(uint32_t*)pl_dyn_lds = lane_stride;
   const size_t pbytes = stride < PL_STAGE_MAX_PROOF ? stride : PL_STAGE_MAX_PROOF;
   const size_t ibytes = n_public * 32 <= PL_STAGE_MAX_INPUT ? n_public * 32 : 0;
@@ -70,6 +74,9 @@ __global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict_
   const FrCtx& F = fr_ctx();
   PlonkWork& wk = work[i];
   PL_MARK(0);
+#if defined(BN254_PLONK_MARKS)
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_plonk_sha_n = 0;
+#endif
   {
     // the KZG batching scalar: 384 bits of the call's ChaCha20 stream (blocks 3i .. 3i+2) reduced mod r, as the host path draws it
     uint32_t lw[12];
@@ -138,6 +145,7 @@ hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs,
   for (int i = 0; i < 8; i++) key.k[i] = lam_key[i];
   for (int i = 0; i < 3; i++) key.nonce[i] = lam_key[8 + i];
   const uint32_t ls = pl_lane_stride(stride, n_public);
+  if (16 + 64 * (size_t)ls > 65536) { hipError_t ae = hipFuncSetAttribute((const void*)k_plonk_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 + 64 * (size_t)ls)); if (ae != hipSuccess) return ae; }
   hipLaunchKernelGGL(k_plonk_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, d_inputs, n_public, (uint32_t)n, key,
                      (PlonkWork*)d_work, (MsmTerm*)d_terms, d_flags, T1, ls);
   return hipGetLastError();
@@ -145,6 +153,7 @@ hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs,
 hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
                                      void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s) {
   const uint32_t ls = pl_lane_stride(stride, 0);
+  if (16 + 64 * (size_t)ls > 65536) { hipError_t ae = hipFuncSetAttribute((const void*)k_plonk_stage2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 + 64 * (size_t)ls)); if (ae != hipSuccess) return ae; }
   hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words,
                      d_lin_inf, (MsmTerm*)d_terms, d_flags, d_status, TT, T2, ls);
   return hipGetLastError();
@@ -165,6 +174,13 @@ __global__ void k_plonk_dbg_zeta(const PlonkWork* __restrict__ work, uint32_t n,
 #if defined(BN254_PLONK_MARKS)
 // diagnostics build: the clock stamps of the last stage launches (100 MHz ticks; bn254_plonk.hpp::PL_MARK)
 extern "C" int bn254_dbg_plonk_marks(unsigned long long out[32]) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plonk_marks), 32 * sizeof(unsigned long long)); }
+// ... and the dumped intermediate values of the first lane (64 x 32 bytes, little-endian limbs; bn254_plonk.hpp::PL_DUMP)
+extern "C" int bn254_dbg_plonk_sha_dump_device(uint32_t out[32 * 24], uint32_t* n) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plonk_sha_dump), 32 * 24 * 4);
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_plonk_sha_n), 4);
+  return (int)e;
+}
+extern "C" int bn254_dbg_plonk_dump_device(uint8_t out[64 * 32]) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plonk_dump), 64 * 32); }
 #endif
 hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_zeta, uint8_t* d_status, hipStream_t s) {
   hipLaunchKernelGGL(k_plonk_dbg_zeta, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const PlonkWork*)d_work, (uint32_t)n, d_zeta, d_status);

@@ -94,6 +94,9 @@ void bn254_launch_miller_step(bool do_sqr, int kind, int32_t* ws, uint32_t n, co
 struct MillerKinds { uint8_t nib[44]; };
 void bn254_launch_miller_run(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int et, int eb,
                              int e, int epa, const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1);
+// the same for two table-driven pairs and no variable pair (bn254_vm.h::vm_miller_run_fixed2)
+void bn254_launch_miller_run_fixed2(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int e,
+                                    const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1);
 // RLC batch mode (bn254_rlc.h): one launch part = n <= G16_MAX_LAUNCH proofs forming plan.groups groups
 #include "bn254_rlc_plan.h"
 struct RlcLaunchArgs {

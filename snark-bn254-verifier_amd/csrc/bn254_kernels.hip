@@ -24,6 +24,7 @@
 #include <cstring>
 #include "bn254_devws.h"
 #include "bn254_rlc.h"
+#include "bn254_g16_plan.h"
 
 namespace bn254 {
 
@@ -677,6 +678,11 @@ struct LaunchOps {
     ProfScope ps_(prof, KID_MILLER_RUN, s);
     bn254_launch_miller_run(kinds, s_begin, s_end, ws, n, status, grid, s, et, eb, e, epa, tab[0], ep0, inf_mask[0], tab[1], ep1, inf_mask[1]);
   }
+  void miller_run_fixed2(int s_begin, int s_end, int e, int ep0, int ep1) {
+    static const MillerKinds kinds = [] { MillerKinds k; memset(&k, 0, sizeof k); for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) k.nib[st_ >> 1] |= (uint8_t)(miller_step_kind(st_) << ((st_ & 1) * 4)); return k; }();
+    ProfScope ps_(prof, KID_MILLER_RUN, s);
+    bn254_launch_miller_run_fixed2(kinds, s_begin, s_end, ws, n, status, grid, s, e, tab[0], ep0, inf_mask[0], tab[1], ep1, inf_mask[1]);
+  }
   void miller_sqr_dbl_var(int et, int e, int ep) { BN_LAUNCH(KID_MILLER_SQR_DBL_VAR, k_miller_sqr_dbl_var, ws, n, status, et, e, ep); }
   void miller_add_var(int et, int eb, int which, int e, int ep) { BN_LAUNCH(KID_MILLER_ADD_VAR, k_miller_add_var, ws, n, status, et, eb, which, e, ep); }
   void f12_mul_line_fixed(int e, int t, int st_, int ep) {
@@ -705,12 +711,15 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   unsigned grid = grid_for(a.n);
   uint32_t n = (uint32_t)a.n;
   if (ev) (void)hipEventRecord(ev[0], s);
-  const bool wide = a.msm_part != nullptr && a.inputs_match_key && a.n_public > G16_WIDE_MSM_MIN_INPUTS;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
-  // cooperative path (small batches): the public-input MSM moves into the cooperative kernel (twelve lanes per proof, L kept projective), so
-  // k_g16_prepare stops after C; keys with many inputs keep their wide MSM kernels and hand L over through the workspace.  A key with more
-  // than G16_WIDE_MSM_MIN_INPUTS inputs but no partial-sum buffer (wrong input count) takes the one-proof-per-lane path.
-  const bool coop = coop_on && !a.part_of_larger && a.n <= bn254_coop_max_proofs() && (wide || a.n_public <= G16_WIDE_MSM_MIN_INPUTS);
+  // BN254_MILLER_RUN_STEPS overrides the steps per k_miller_run launch (0: the one-launch-per-step kernels k_miller_step_dbl / _add)
+  static const int run_steps_env = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : -1; return v < -1 ? -1 : v; }();
+  // the form of this launch -- cooperative kernels (small batches: the public-input MSM moves into the cooperative kernel, twelve lanes per proof, L kept
+  // projective, so k_g16_prepare stops after C; keys with many inputs keep their wide MSM kernels and hand L over through the workspace), lane kernels, or
+  // their latency mode -- is a pure function of the sizes (bn254_g16_plan.h), shared with the plan probe
+  const G16Form form = g16_launch_form(a.n, (size_t)a.n_public, a.inputs_match_key != 0, a.msm_part != nullptr, a.part_of_larger != 0,
+                                       a.split_streams[0] && a.split_streams[1], coop_on, run_steps_env);
+  const bool wide = form.wide, coop = form.form == G16_FORM_COOP;
   BN_LAUNCH(KID_PREPARE, k_g16_prepare, a.proofs, a.stride, a.inputs, a.n_public, n, a.ws, a.status, a.msm_tab, a.k0, a.inputs_match_key, (wide || coop) ? 1 : 0);
   if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
   if (wide) {
@@ -749,7 +758,7 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   }
   LaunchOps ops{a.ws, n, a.status, grid, s, {a.gtab, a.dtab, nullptr}, prof};
   BN_LAUNCH(KID_VM_INIT, k_vm_init, a.ws, n, (const uint8_t*)a.status);
-  if (a.split_streams[0] && a.split_streams[1] && a.n <= G16_SPLIT_MAX_PROOFS) {
+  if (form.form == G16_FORM_LATENCY) {
     // latency mode: Miller(A, B) on the launch stream, the two table-driven pairs as their own chains (accumulators in the free
     // slots VE_S1 / VE_S2) on two more streams; f = f_A f_B f_C afterwards.  Three times the squarings, 40 % less time at 4096.
     ops.f12_copy(VE_S1, VE_F); ops.f12_copy(VE_S2, VE_F);
@@ -772,11 +781,9 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   } else {
     // Steps of the Miller loop per launch (k_miller_run: f never leaves LDS + registers inside a launch).  Large sub-batches take the whole loop in ONE
     // launch; sub-batches that are a single generation of workgroups run measurably better in a few shorter launches (batch 2^17 = two sub-batches of
-    // 2^16: 11 steps per launch 5.75 M proofs/s, 22: 5.71, 44: 5.60, 88: 5.49; batch 2^19: 44 best; 2^20: 88 best by 0.7 %; profiles/r03_run_steps_sweep.txt).
-    // BN254_MILLER_RUN_STEPS overrides (0: the one-launch-per-step kernels k_miller_step_dbl / _add).
-    static const int run_steps_env = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : -1; return v < -1 ? -1 : v; }();
-    // A batch that is ONE sub-batch (up to 65 536 proofs, see g16_enqueue) takes the whole loop in one launch: 14.23 ms against 14.29 ms with 11 steps at 65 536.
-    const int run_steps = run_steps_env >= 0 ? run_steps_env : !a.part_of_larger ? BN_ATE_STEPS : (a.n <= 65536 ? 11 : a.n <= 131072 ? 22 : a.n <= 262144 ? 44 : BN_ATE_STEPS);
+    // 2^16: 11 steps per launch 5.75 M proofs/s, 22: 5.71, 44: 5.60, 88: 5.49; batch 2^19: 44 best; 2^20: 88 best by 0.7 %; profiles/r03_run_steps_sweep.txt);
+    // a batch that is ONE sub-batch (up to 65 536 proofs) takes the whole loop in one launch: 14.23 ms against 14.29 ms with 11 steps at 65 536 (g16_launch_form)
+    const int run_steps = form.run_steps;
     if (run_steps) vm_miller_program_runs(ops, run_steps);
     else vm_miller_program(ops, step_kinds_host(), true);
   }
@@ -914,7 +921,8 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
   LaunchOps ops{ws, nn, status, grid, s, {tab0, tab1, nullptr}, nullptr};
   ops.inf_mask[0] = BN254_ST_LINF; ops.inf_mask[1] = BN254_ST_LINF2;
   static const bool coop_on = [] { const char* e = getenv("BN254_COOP"); return !e || atoi(e) != 0; }();
-  if (coop_on && n <= bn254_coop_max_proofs_fixed()) {
+  static const size_t coop_fixed_max = [] { const char* e = getenv("BN254_COOP_FIXED_MAX"); return e ? (size_t)atol(e) : bn254_coop_max_proofs_fixed(); }();
+  if (coop_on && n <= coop_fixed_max) {
     // small batch: the cooperative layout (bn254_coop12.hip), Miller loop of the two pairs and final exponentiation in ONE launch
     hipError_t e = bn254_coop12_miller_fixed(ws, status, n, 2, tab0, tab1, tab0, VE_LX, VE_CX, VE_LX, BN254_ST_LINF, BN254_ST_LINF2, 0, 1, s);
     if (e != hipSuccess) return e;
@@ -938,9 +946,16 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
     (void)hipStreamWaitEvent(s, ev_join, 0);
     ops.f12_mul(VE_F, VE_F, VE_S1);
   } else {
-    for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
-      if (kinds[st_] == 0 && st_ != 0) ops.f12_sqr(VE_F);
-      ops.f12_mul_line_fixed2(VE_F, st_, VE_LX, VE_CX);
+    // a large batch (throughput): the whole loop of the two pairs in one launch, the accumulator in flight (k_miller_run_fixed2); BN254_MILLER_RUN_STEPS=0 keeps
+    // the one-launch-per-operation form
+    static const int run_steps = [] { const char* e = getenv("BN254_MILLER_RUN_STEPS"); int v = e ? atoi(e) : BN_ATE_STEPS; return v < 0 ? BN_ATE_STEPS : v; }();
+    if (run_steps > 0) {
+      for (int s0 = 0; s0 < BN_ATE_STEPS; s0 += run_steps) ops.miller_run_fixed2(s0, s0 + run_steps < BN_ATE_STEPS ? s0 + run_steps : BN_ATE_STEPS, VE_F, VE_LX, VE_CX);
+    } else {
+      for (int st_ = 0; st_ < BN_ATE_STEPS; st_++) {
+        if (kinds[st_] == 0 && st_ != 0) ops.f12_sqr(VE_F);
+        ops.f12_mul_line_fixed2(VE_F, st_, VE_LX, VE_CX);
+      }
     }
   }
   vm_final_exp_program(ops);

@@ -41,6 +41,16 @@ __device__ unsigned long long g_plonk_marks[32];
 #define PL_MARK(k) ((void)0)
 #endif
 
+#if defined(BN254_PLONK_MARKS)
+// ... and every SHA-256 compression of the first lane (device) / of the last proof (host): the 16 message words as read and the 8 state words after
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIPCC__)
+__device__ uint32_t g_plonk_sha_dump[32][24];
+__device__ uint32_t g_plonk_sha_n;
+#endif
+inline uint32_t g_plonk_sha_dump_host[32][24];
+inline uint32_t g_plonk_sha_n_host;
+#endif
+
 #if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
 // Device side: a lane's pending SHA-256 block lives in LDS, not in its private memory (a byte buffer indexed by a run-time fill level would be
 // scratch: a vector-memory round trip per byte, with one wavefront per SIMD to hide it).  The kernels of bn254_k_plonk.hip lay their dynamic LDS out as
@@ -155,6 +165,21 @@ struct Sha256 {
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+#if defined(BN254_PLONK_MARKS) && defined(BN254_PLONK_SHA_DUMP)
+    {
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t j = g_plonk_sha_n;
+        if (j < 32) { for (int i = 0; i < 16; i++) g_plonk_sha_dump[j][i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3]; for (int i = 0; i < 8; i++) g_plonk_sha_dump[j][16 + i] = h[i]; }
+        g_plonk_sha_n = j + 1;
+      }
+#else
+      const uint32_t j = g_plonk_sha_n_host;
+      if (j < 32) { for (int i = 0; i < 16; i++) g_plonk_sha_dump_host[j][i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3]; for (int i = 0; i < 8; i++) g_plonk_sha_dump_host[j][16 + i] = h[i]; }
+      g_plonk_sha_n_host = j + 1;
+#endif
+    }
+#endif
   }
   PL_HD void update(const void* data, size_t n) {
     const uint8_t* p = (const uint8_t*)data; len += n;
@@ -209,37 +234,55 @@ struct FrCtx {
     FrM r; uint64_t br = 0; for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)m[i] - a.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return r;
   }
   PL_HD FrM sub(const FrM& a, const FrM& b) const { return add(a, neg(b)); }
-  PL_HD FrM mul(const FrM& a, const FrM& b) const {  // CIOS Montgomery product
-#if defined(BN254_FR_MUL32)
-    // EXPERIMENT (not compiled by default): the same product on 8 x 32-bit words, the shape of gfx950's widest multiply (v_mad_u64_u32).  690 instructions
-    // on the device against 890 for the 64-bit-limb form below through __int128; bit-exact on the host and in isolation on the device
-    // (tools/exp/tmul.hip), no measurable change of the stage-1 kernel (0.97 ms either way) -- and with the inlining left to the compiler that kernel
-    // computed a wrong opening check (fine with the function pinned out of line), so the 64-bit form, which every test has run through, stays.
+  // CIOS Montgomery product.  Two forms of the same function: 4 x 64-bit limbs through unsigned __int128 (what a CPU wants), and 8 x 32-bit words (what
+  // gfx950 has: its widest multiply is v_mad_u64_u32, 32 x 32 + 64 -> 64; the 64-bit form compiles to ~890 instructions there, this one to about a third).
+  // The device stages use the 32-bit form, the host the 64-bit one; BN254_FR_MUL_FORM=32 / 64 forces either everywhere (tests/cpp, tools/fr_mul_probe.hip:
+  // bit-exact against each other on both sides, any a < 2^256 and b < m).
+  PL_HD FrM mul(const FrM& a, const FrM& b) const {
+#if (defined(__HIP_DEVICE_COMPILE__) && !(defined(BN254_FR_MUL_FORM) && BN254_FR_MUL_FORM == 64)) || (defined(BN254_FR_MUL_FORM) && BN254_FR_MUL_FORM == 32)
+    return mul_w32(a, b);
+#else
+    return mul_w64(a, b);
+#endif
+  }
+  // On the device the product is ONE out-of-line function (BN254_FR_MUL_INLINE=0 leaves the choice to the compiler, 1 forces inlining: diagnostics): the stages
+  // call it ~250 times, inlined copies make k_plonk_stage1 0.6 MB of code, and the one build in which the compiler inlined it next to the byte shuffles of a
+  // freshly written digest computed a wrong challenge (from_be32 below carries the second half of the workaround).
+#if defined(BN254_FR_MUL_INLINE) && BN254_FR_MUL_INLINE == 1
+  __attribute__((always_inline))
+#elif defined(__HIP_DEVICE_COMPILE__) && !(defined(BN254_FR_MUL_INLINE) && BN254_FR_MUL_INLINE == 0)
+  __attribute__((noinline))
+#endif
+  PL_HD FrM mul_w32(const FrM& a, const FrM& b) const {
     uint32_t aw[8], bw[8], mw[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { aw[2 * i] = (uint32_t)a.l[i]; aw[2 * i + 1] = (uint32_t)(a.l[i] >> 32); bw[2 * i] = (uint32_t)b.l[i]; bw[2 * i + 1] = (uint32_t)(b.l[i] >> 32);
-                                  mw[2 * i] = (uint32_t)m[i]; mw[2 * i + 1] = (uint32_t)(m[i] >> 32); }
-    const uint32_t inv32 = (uint32_t)inv;
-    uint32_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t top = 0;                                        // t[9]: at most one bit
+    for (int i = 0; i < 4; i++) {
+      aw[2 * i] = (uint32_t)a.l[i]; aw[2 * i + 1] = (uint32_t)(a.l[i] >> 32); bw[2 * i] = (uint32_t)b.l[i]; bw[2 * i + 1] = (uint32_t)(b.l[i] >> 32);
+      mw[2 * i] = (uint32_t)m[i]; mw[2 * i + 1] = (uint32_t)(m[i] >> 32);
+    }
+    const uint32_t ninv = (uint32_t)inv;                     // -1 / m mod 2^32
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       uint64_t c = 0;
 #pragma unroll
-      for (int j = 0; j < 8; j++) { c = (uint64_t)aw[j] * bw[i] + ((uint64_t)t[j] + c); t[j] = (uint32_t)c; c >>= 32; }
-      c += t[8]; t[8] = (uint32_t)c; top = (uint32_t)(c >> 32);
-      const uint32_t q = t[0] * inv32;
+      for (int j = 0; j < 8; j++) { const uint64_t s = (uint64_t)aw[j] * bw[i] + t[j] + c; t[j] = (uint32_t)s; c = s >> 32; }   // <= (2^32 - 1)^2 + 2 (2^32 - 1) = 2^64 - 1
+      const uint64_t s8 = (uint64_t)t[8] + c; t[8] = (uint32_t)s8; t[9] = (uint32_t)(s8 >> 32);
+      const uint32_t q = t[0] * ninv;
       c = ((uint64_t)q * mw[0] + t[0]) >> 32;
 #pragma unroll
-      for (int j = 1; j < 8; j++) { c = (uint64_t)q * mw[j] + ((uint64_t)t[j] + c); t[j - 1] = (uint32_t)c; c >>= 32; }
-      c += t[8]; t[7] = (uint32_t)c; t[8] = top + (uint32_t)(c >> 32);
+      for (int j = 1; j < 8; j++) { const uint64_t s = (uint64_t)q * mw[j] + t[j] + c; t[j - 1] = (uint32_t)s; c = s >> 32; }
+      const uint64_t s9 = (uint64_t)t[8] + c; t[7] = (uint32_t)s9; t[8] = t[9] + (uint32_t)(s9 >> 32);
     }
     FrM r;
 #pragma unroll
     for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)t[2 * i] | ((uint64_t)t[2 * i + 1] << 32);
     if (t[8] || geq_m(r)) r = sub_m(r);
     return r;
-#else
+  }
+  PL_HD FrM mul_w64(const FrM& a, const FrM& b) const {
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
       unsigned __int128 c = 0;
@@ -253,7 +296,6 @@ struct FrCtx {
     FrM r = {{t[0], t[1], t[2], t[3]}};
     if (t[4] || geq_m(r)) r = sub_m(r);
     return r;
-#endif
   }
   PL_HD FrM from_u64(uint64_t v) const { FrM t = {{v, 0, 0, 0}}; return mul(t, r2); }
   PL_HD FrM from_canon(const FrM& a) const { return mul(a, r2); }          // a < r
@@ -425,6 +467,11 @@ struct FrCtx {
   PL_HD FrM from_be32(const uint8_t* b) const {
     FrM raw;
     for (int i = 0; i < 4; i++) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = v << 8 | b[(3 - i) * 8 + j]; raw.l[i] = v; }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BN254_FR_NO_BARRIER)
+    // the limbs as plain register values before the product: keeps the byte shuffles of a digest that was just written out (Sha256::finish) from being fused
+    // with the multiplication's word splitting ("a wrong challenge on the device")
+    for (int i = 0; i < 4; i++) asm volatile("" : "+v"(raw.l[i]));
+#endif
     return mul(raw, r2);
   }
   PL_HD FrM from_be_reduce(const uint8_t* b, size_t n) const {
@@ -476,6 +523,22 @@ PL_HD const Fp64Ctx& fp64_ctx() {
   static const Fp64Ctx c; return c;
 #endif
 }
+
+// Diagnostics build only (BN254_PLONK_MARKS): intermediate values of the stages, of the first lane on the device and of the last proof on the host, so that
+// tools/plonk_stage_dump.py can say at which value the two sides part.
+#if defined(BN254_PLONK_MARKS)
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIPCC__)
+__device__ FrM g_plonk_dump[64];
+#endif
+inline FrM g_plonk_dump_host[64];
+#if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
+#define PL_DUMP(k, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_plonk_dump[k] = (v); } while (0)
+#else
+#define PL_DUMP(k, v) do { g_plonk_dump_host[k] = (v); } while (0)
+#endif
+#else
+#define PL_DUMP(k, v) ((void)0)
+#endif
 
 // ---------------------------------------------------------------- key and proof (plonk/converter.rs:18-178, proof.rs)
 enum { PLONK_MAX_QCP = 8, PLONK_MAX_CLAIMED = 16 };
@@ -755,6 +818,10 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   cz.bind(proof + 256, 192);                                              // h0, h1, h2
   zeta = cz.finish(dz);
   PL_MARK(4);
+  PL_DUMP(0, gamma); PL_DUMP(1, beta); PL_DUMP(2, alpha); PL_DUMP(3, zeta);
+#if defined(BN254_PLONK_MARKS)
+  { FrM t; memcpy(&t, dg, 32); PL_DUMP(27, t); memcpy(&t, db, 32); PL_DUMP(28, t); memcpy(&t, da, 32); PL_DUMP(29, t); memcpy(&t, dz, 32); PL_DUMP(30, t); }
+#endif
   wk.zeta = zeta;
   // verify.rs:97-107
   zeta_n = F.pow_u64(zeta, vk.size);
@@ -775,6 +842,7 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   acc = one;
   for (int i = 0; i < nden; i++) { zero[i] = F.is_zero(den[i]); pre[i] = acc; if (!zero[i]) acc = F.mul(acc, den[i]); }
   PL_MARK(5);
+  PL_DUMP(4, zeta_n); PL_DUMP(5, zh_zeta); PL_DUMP(6, acc); PL_DUMP(7, den[0]); PL_DUMP(8, den[1]); PL_DUMP(9, den[2]); PL_DUMP(10, den[3]); PL_DUMP(11, pre[3]);
   return PL_OK;
 }
 PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
@@ -790,7 +858,9 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
       inv[i] = F.mul(ai, pre[i]); ai = F.mul(ai, den[i]);
     }
   }
+  PL_DUMP(12, acc_inv); PL_DUMP(13, inv[0]); PL_DUMP(14, inv[1]); PL_DUMP(15, inv[2]); PL_DUMP(16, inv[3]);
   FrM lagrange_one = F.mul(F.mul(inv[0], zh_zeta), vk.size_inv);
+  PL_DUMP(17, lagrange_one);
   // verify.rs:109-137: PI = sum_i L_i(zeta) w_i
   FrM pi = {{0, 0, 0, 0}}, accw = one;
   const FrM zs = F.mul(zh_zeta, vk.size_inv);
@@ -802,6 +872,7 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   }
   // verify.rs:139-163: BSB22 commitments enter the public-input polynomial through hash_to_field
   PL_MARK(7);
+  PL_DUMP(18, pi);
   for (uint64_t i = 0; i < vk.n_cci; i++) {
     FrM hashed = bsb22_hash_to_field(proof + pr.off_bsb + 64 * i);
     FrM lag = F.mul(F.mul(F.mul(zs, vk.wpow[i]), inv[1 + n_in + i]), hashed);
@@ -809,13 +880,16 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   }
   // verify.rs:165-214: the constant term of the linearised polynomial must equal the claimed opening
   PL_MARK(8);
+  PL_DUMP(19, pi);
   const FrM &l = pr.claimed[1], &r = pr.claimed[2], &o = pr.claimed[3], &s1 = pr.claimed[4], &s2 = pr.claimed[5], &zu = pr.zs_value;
   FrM a2l1 = F.mul(F.mul(lagrange_one, alpha), alpha);
   FrM cl = F.add(F.add(F.mul(beta, s1), gamma), l);
   cl = F.mul(cl, F.add(F.add(F.mul(beta, s2), gamma), r));
   cl = F.mul(cl, F.add(o, gamma));
   cl = F.mul(F.mul(cl, alpha), zu);
+  PL_DUMP(20, a2l1); PL_DUMP(21, cl);
   cl = F.neg(F.add(F.sub(cl, a2l1), pi));
+  PL_DUMP(22, cl); PL_DUMP(23, pr.claimed[0]); PL_DUMP(24, pr.claimed[1]); PL_DUMP(25, pr.claimed[5]); PL_DUMP(26, pr.zs_value);
   {
     // Fr == compares stored words: a claimed value that is not reduced (>= r) can never equal the reduced left-hand side
     FrM raw;

@@ -348,6 +348,21 @@ BN_HD void vm_miller_run(W& w, const LINES& lines, const KINDS& kinds, int s_beg
   mf_store(w, e, f4, f5);
 }
 
+// The same run for TWO table-driven pairs and no variable pair (PlonK's KZG check e(P0, g2[0]) e(P1, g2[1]), plonk/kzg.rs:175-187): f <- [f^2] l0(P0) l1(P1)
+// per step, no G2 arithmetic at all -- the accumulator in flight from the first step to the last.
+template <class W, class LINES, class KINDS>
+BN_HD void vm_miller_run_fixed2(W& w, const LINES& lines, const KINDS& kinds, int s_begin, int s_end, int e, int e_p0, bool inf0, int e_p1, bool inf1) {
+  Fp2 f4, f5;
+  mf_load(w, e, f4, f5);
+  for (int s = s_begin; s < s_end; s++) {
+    if (kinds.get(s) == 0 && s != 0) mf_sqr(w, f4, f5);
+    BN_SCHED_FENCE();
+    mf_line_fixed(w, lines.get(0, s), e_p0, inf0, f4, f5);
+    mf_line_fixed_k(w, lines.get(1, s), e_p1, inf1, f4, f5);
+  }
+  mf_store(w, e, f4, f5);
+}
+
 // ---- r-torsion test of B from the point the Miller loop has already computed ----------------------------------------------------------
 // After vm_miller_program the running point is T = [6u+2]B + psi(B) - psi^2(B).  For B on the twist E'(Fp2):
 //     B in G2  <=>  T == -psi^3(B)          (T finite)

@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# a deployment setting of the host process: the HIP runtime maps the streams of a process onto this many hardware queues (default 4), read when it
+# initialises; the library itself no longer touches the environment
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

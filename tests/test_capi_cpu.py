@@ -281,3 +281,86 @@ def test_plonk_plan(pkg):
             assert w == 1 or n > piece                         # one sub-batch while a single pass holds the batch
             passes = -(-per // ps)
             assert passes * ps >= per and (passes - 1) * ps < per and passes == -(-per // piece)   # no more passes than the piece size forces, all of one size
+
+
+def _g16_plan(L, key_inputs, comb, reserved, n, n_public, n_streams, single):
+    import ctypes as C
+    L.bn254_dbg_g16_plan.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]
+    alloc = (C.c_uint64 * 4)(); out = (C.c_uint64 * (8 * 64))(); k = C.c_int()
+    assert L.bn254_dbg_g16_plan(key_inputs, comb, reserved, n, n_public, n_streams, single, alloc, out, 64, C.byref(k)) == 0
+    assert k.value <= 64
+    rows = [[int(out[8 * i + j]) for j in range(8)] for i in range(k.value)]
+    for r in rows:
+        if r[3] >= 1 << 63:
+            r[3] -= 1 << 64
+    return [int(x) for x in alloc], rows
+
+
+def test_groth16_plan_fits_every_reservation(pkg):
+    """no Groth16 launch can outrun its buffers.  The library allocates (ensure_dev) and enqueues (g16_enqueue_exact, bn254_launch_g16) by the
+    pure functions of csrc/bn254_g16_plan.h; bn254_dbg_g16_plan exposes them.  For keys with 2 / 16 / 17 / 40 / 1024 inputs, reservations from 1 proof to beyond one
+    workspace chunk, batches at and below the reservation (a context an earlier, larger call has grown), matching and wrong input counts, 1 / 2 / 4 sub-batch streams
+    and the serialised-streams fallback: the launches cover the batch exactly once; every launch addresses workspace inside the allocation and at most
+    G16_MAX_LAUNCH proofs (32-bit buffer offsets); launches that run side by side use disjoint workspace; a wide-MSM launch fits the partial-sum and digit buffers;
+    the cooperative form only takes a whole small batch."""
+    import random
+    L = pkg.lib()
+    rng = random.Random(77)
+    WS, MAXL, MAXB, COOP, WIDE = 4680, 786432, 1 << 20, 30720, 65536
+    sizes = [1, 2, 255, 256, 257, 4096, 16384, 16385, 30720, 30721, 65536, 65537, 65552, 131072, 262144, 524288, 786432, 786433, (1 << 20) - 1, 1 << 20, (1 << 20) + 777, 2500000]
+    for key_inputs, comb in ((2, 0), (16, 0), (17, 1), (17, 0), (40, 1), (1024, 1)):
+        for reserved in sizes + [rng.randrange(1, 1 << 21) for _ in range(6)]:
+            for n in {reserved, max(1, reserved // 2), max(1, reserved - 1), 1, min(reserved, 70000), min(reserved, 65537)}:
+                if key_inputs == 1024 and n > 200000:
+                    continue
+                for n_public in (key_inputs, key_inputs - 1):
+                    for n_streams, single in ((2, 0), (1, 0), (4, 0), (2, 1)):
+                        alloc, rows = _g16_plan(L, key_inputs, comb, reserved, n, n_public, n_streams, single)
+                        assert alloc[0] == min((reserved + 255) // 256 * 256, MAXB) * WS
+                        covered = 0
+                        by_chunk = {}
+                        for chunk, first, count, slot, form, steps, lo, hi in rows:
+                            assert count >= 1 and count <= MAXL and hi <= alloc[0] and lo == first * WS and hi == (first + count) * WS, (key_inputs, reserved, n, rows)
+                            assert hi - lo < 0xfffffffc      # a launch addresses its own part of the workspace with 32-bit buffer offsets
+                            by_chunk.setdefault(chunk, []).append((first, count, slot, form))
+                            covered += count
+                            wide = n_public == key_inputs and key_inputs > 16
+                            if wide:
+                                assert slot == -1 and count <= alloc[3] and count <= WIDE
+                                chunks = (key_inputs + 15) // 16
+                                assert chunks * 27 * 4 * count <= alloc[1] and (not comb or 20 * key_inputs * 2 * count <= alloc[2])
+                            if form == 1:
+                                assert count <= COOP and (wide or n_public <= 16)
+                            if form == 2:
+                                assert count <= 16384
+                            assert steps in (11, 22, 44, 88)
+                        assert covered == n
+                        for chunk, parts in by_chunk.items():
+                            parts.sort()
+                            pos = 0
+                            for first, count, slot, form in parts:
+                                assert first == pos            # contiguous, disjoint: parts that run side by side never share workspace
+                                pos += count
+                            assert pos == min(MAXB, n - chunk * MAXB)
+                            assert all(f == 0 for _, _, _, f in parts) or len(parts) == 1      # the cooperative form and the latency mode only take a whole chunk
+                            slots = [s for _, _, s, _ in parts]
+                            if len(parts) > 1 and slots[0] >= 0:
+                                assert len(set(slots)) == min(len(parts), 4) and single == 0 and n_streams > 1
+
+
+def test_groth16_rlc_group_buffer_fits(pkg):
+    """The same for BN254_FLAG_RLC's group status bytes: what the launch parts of a chunk address against what rlc_ensure allocated for the reservation, over
+    group sizes 2 .. 2^10, sharing 1 .. 8 proofs per lane, 1 .. 4 streams."""
+    import ctypes as C
+    import random
+    L = pkg.lib()
+    L.bn254_dbg_g16_rlc_plan.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    rng = random.Random(78)
+    need, alloc = C.c_uint64(), C.c_uint64()
+    for m in [64, 65, 255, 256, 257, 4096, 32767, 32768, 65536, 65537, 200000, 262144, 786432, 786433, (1 << 20) - 1, 1 << 20] + [rng.randrange(64, 1 << 20) for _ in range(30)]:
+        for n_streams in (1, 2, 3, 4):
+            for lg in (1, 2, 5, 10):
+                for ls in (0, 1, 3):
+                    for min_lanes in (1, 65536):
+                        assert L.bn254_dbg_g16_rlc_plan(m, m, n_streams, lg, ls, min_lanes, C.byref(need), C.byref(alloc)) == 0
+                        assert need.value <= alloc.value, (m, n_streams, lg, ls, min_lanes, need.value, alloc.value)

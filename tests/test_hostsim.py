@@ -248,3 +248,31 @@ def test_latency_mode_program_matches(hostsim, O):
             o3 = (C.c_uint8 * 384)()
             assert hs.hs_vm_pairing3(o3, pa, qb, pl, qg, pc, qd, l_inf | 2 | (per_run << 2)) == 1
             assert bytes(o3) == exp, per_run
+
+
+def test_two_fixed_pair_run_on_reference_plonk_fixtures(hostsim, O, fixtures):
+    """The lane path of PlonK's KZG check (bn254_vm.h::vm_miller_run_fixed2: both pairs table-driven, the accumulator in flight through the whole loop, then the final
+    exponentiation program) under the bound tracker: exactly 1 on the operands of the reference's four fixtures, the oracle's pairing on random points, identity
+    flags, and the same value whatever the number of steps per operation."""
+    hs = hostsim
+    fx, vk = fixtures
+    one = (1).to_bytes(32, "big") + bytes(352)
+    o = (C.c_uint8 * 384)()
+    n = 0
+    for name, f in fx.items():
+        if f["variant"] != "plonk":
+            continue
+        st, ps, qs = O.plonk_pairing_inputs(bytes.fromhex(f["raw_proof"]), vk, [int(x) for x in f["public_inputs"]])
+        assert st == O.ACCEPT
+        assert hs.hs_vm_pairing2_fixed(o, ps[0], qs[0], ps[1], qs[1], 0, 0) == 1 and bytes(o) == one, name
+        n += 1
+    assert n == 4
+    rng = random.Random(43)
+    g1, g2 = O.g1_gen(), O.g2_gen()
+    p0, p1 = (O.g1_mul(g1, rng.randrange(1, R)) for _ in range(2))
+    q0, q1 = (O.g2_mul(g2, rng.randrange(1, R)) for _ in range(2))
+    for per_run in (0, 1, 11, 44):
+        assert hs.hs_vm_pairing2_fixed(o, p0, q0, p1, q1, 0, per_run) == 1 and bytes(o) == O.pairing(p0 + p1, q0 + q1), per_run
+    assert hs.hs_vm_pairing2_fixed(o, p0, q0, p1, q1, 1, 0) == 1 and bytes(o) == O.pairing(p1, q1)
+    assert hs.hs_vm_pairing2_fixed(o, p0, q0, p1, q1, 2, 0) == 1 and bytes(o) == O.pairing(p0, q0)
+    assert hs.hs_vm_pairing2_fixed(o, p0, q0, p1, q1, 3, 0) == 1 and bytes(o) == one
