@@ -165,6 +165,10 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
                              size_t n_public, size_t n, uint8_t* status, int device);
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                        size_t n_public, uint8_t* status);
+/* Knobs of the PlonK batch plan (process-wide, atomic; -1 leaves a knob alone; initial values from BN254_PLONK_PIECE / _WORKERS / _BIG_FROM / _BIG_PIECE, read once at
+ * load time): below big_from proofs a batch is up to `workers` chains of passes of at most `piece` proofs side by side (latency-bound launches), from big_from on
+ * few passes of up to big_piece <= 65536 proofs (throughput-bound launches).  Same status bytes either way. */
+void bn254_set_plonk_params(long piece, int workers, long big_from, long big_piece);
 /* Durations (ms) of the first sub-batch of the bn254_plonk_verify_batch that finished last on `device`, from HIP events on the sub-batch's stream:
  *   [0] host: staging copy into pinned memory (with BN254_PLONK_HOST=1: stage 1 on host threads)      [1] k_plonk_stage1
  *   [2] k_g1_msm_rows of the linearised-polynomial digest   [3] its k_g1_sum_affine                   [4] k_plonk_stage2 (BN254_PLONK_HOST=1: host stage 2)

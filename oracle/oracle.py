@@ -5,7 +5,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle.so")
+# BN254_ORACLE_LIB: another build of the same sources (tests/test_sanitizers.py: liboracle_san.so, AddressSanitizer + UBSan)
+LIB_PATH = os.environ.get("BN254_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")
 
 REJECT, ACCEPT, ERR_NOT_MEMBER, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP, ERR_INPUT_LEN, ERR_MALFORMED = range(7)
 ERR_OPENING_MISMATCH, ERR_PAIRING_FAILED, ERR_BSB22_MISMATCH, ERR_INVERSE = 7, 8, 9, 10
@@ -16,7 +17,7 @@ R = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", HERE])
+    subprocess.check_call(["make", "-s", "-C", HERE, os.path.basename(LIB_PATH)])
 
 
 _lib = None

@@ -7,5 +7,5 @@ implementation of verification here: if the library or a GPU is missing, calls r
 from .binding import (  # noqa: F401
     ACCEPT, REJECT, ERR_NOT_MEMBER, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP, ERR_INPUT_LEN, ERR_MALFORMED,
     VK_REFERENCE, VK_GNARK, Bn254Error, Groth16Verifier, PreparedVk, build, lib, lib_path, synth_groth16, kernel_kinds,
-    set_profile_kernels, PreparedPlonkVk, PlonkVerifier, FLAG_STRICT_SCALARS, FLAG_RLC, RAW_PROOF_LEN, proof_write_raw, shard_plan, set_rlc_params,
+    set_profile_kernels, PreparedPlonkVk, PlonkVerifier, FLAG_STRICT_SCALARS, FLAG_RLC, RAW_PROOF_LEN, proof_write_raw, shard_plan, set_rlc_params, set_plonk_params,
 )

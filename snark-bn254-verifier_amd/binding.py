@@ -117,6 +117,14 @@ def set_rlc_params(min_batch=-1, adaptive=-1, share_min_lanes=-1):
     lib().bn254_set_rlc_params(min_batch, adaptive, share_min_lanes)
 
 
+def set_plonk_params(piece=-1, workers=-1, big_from=-1, big_piece=-1):
+    """Knobs of the PlonK batch plan (bn254_set_plonk_params; -1 leaves a knob alone)."""
+    L = lib()
+    L.bn254_set_plonk_params.argtypes = [C.c_long, C.c_int, C.c_long, C.c_long]
+    L.bn254_set_plonk_params.restype = None
+    L.bn254_set_plonk_params(piece, workers, big_from, big_piece)
+
+
 def _check(rc):
     if rc != 0:
         raise Bn254Error("bn254 error %d: %s" % (rc, lib().bn254_last_error().decode()))

@@ -319,6 +319,17 @@ static size_t plonk_scratch_lanes(size_t need, int n_var) {
   return split > full ? split : full;
 }
 static int shape_var(const MsmShape& sh) { int v = 0; for (int s = 0; s < sh.n_sums; s++) v += sh.n_var[s]; return v; }
+// Knobs of the PlonK batch plan (bn254_set_plonk_params; the environment gives their initial values once, at load time):
+//   piece      proofs per pass while a batch is a set of latency-bound chains side by side (5040: every launch of a pass is one wavefront generation and the
+//              MSM launches keep their split form)
+//   workers    sub-batches in flight (contexts), at most PLONK_WORKERS
+//   big_from   from this many proofs a batch runs as FEW LARGE passes instead (throughput: one row per variable term, fixed windows packed, the pairing check on
+//              the lane kernels with the whole Miller loop in one launch): 65 536 proofs in one pass 2.28 M proofs/s against 1.54 M as eight chains of 5040-proof passes
+//   big_piece  proofs per pass of that form (at most PLONK_MAX_LAUNCH)
+static std::atomic<long> g_plonk_piece{[] { long v = env_long("BN254_PLONK_PIECE", 5040); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
+static std::atomic<int> g_plonk_workers{[] { long v = env_long("BN254_PLONK_WORKERS", PLONK_WORKERS); return (int)(v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v)); }()};
+static std::atomic<long> g_plonk_big_from{[] { long v = env_long("BN254_PLONK_BIG_FROM", 24576); return v < 1 ? 1 : v; }()};
+static std::atomic<long> g_plonk_big_piece{[] { long v = env_long("BN254_PLONK_BIG_PIECE", PLONK_MAX_LAUNCH); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
 // the plan of a batch (bn254_plonk_verify_batch): sub-batches side by side, proofs per sub-batch, proofs per pass of a sub-batch
 static void plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per, size_t* pass) {
   int w = (int)((n + piece - 1) / piece); if (w > max_workers) w = max_workers; if (w < 1) w = 1;
@@ -1396,16 +1407,15 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     if ((rc = plonk_ensure_dev(pvk, device, &d))) return rc;
   }
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
-  static const int max_workers = [] { const char* e = getenv("BN254_PLONK_WORKERS"); int v = e ? atoi(e) : PLONK_WORKERS; return v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v); }();
   // BN254_PLONK_HOST=1: the transcripts and the Fr arithmetic on host threads (rounds 1-2) instead of the device kernels of bn254_k_plonk.hip
   static const bool dev_stages = [] { const char* e = getenv("BN254_PLONK_HOST"); return !(e && atoi(e) != 0); }();
-  // Plan (round 3): the batch is cut into up to PLONK_WORKERS contiguous sub-batches, one context and one host thread each, and every sub-batch runs in passes of
-  // at most `piece` = 5040 proofs (balanced: a sub-batch of 6144 is two passes of 3072).  5040 because up to there every launch of a pass is ONE wavefront
-  // generation and the 13-term scalar-multiplication launch (65 520 lanes) keeps its two-bit-window form; several such chains of latency-bound launches side
-  // by side fill the GPU where one chain of larger launches does not.  Measured against rounds 1-3a's plan (one sub-batch per 8192 proofs, at most four, one pass
-  // each): 8192 proofs 9.9 -> 8.3 ms, 16 384 15.7 -> 13.1 ms, 32 768 1.18 -> 1.39 M proofs/s, 131 072 1.28 -> 1.53 M proofs/s (profiles/r03_batch_sweep_fine.txt).
-  // BN254_PLONK_PIECE / BN254_PLONK_WORKERS override.  (PLONK_HOST=1 keeps the plan; its host stages then share the thread pool.)
-  static const size_t piece = [] { const char* e = getenv("BN254_PLONK_PIECE"); long v = e ? atol(e) : 5040; return (size_t)(v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? PLONK_MAX_LAUNCH : v)); }();
+  // Plan.  Up to `big_from` proofs the batch is cut into up to PLONK_WORKERS contiguous sub-batches, one context and one host thread each, and every sub-batch runs in
+  // balanced passes of at most `piece` = 5040 proofs (a sub-batch of 6144 is two passes of 3072): up to there every launch of a pass is ONE wavefront generation and the
+  // MSM launches keep their split form, and several such chains of latency-bound launches side by side fill the GPU where one chain of larger launches does not
+  // (round 3: 8192 proofs 9.9 -> 8.3 ms, 16 384 15.7 -> 13.1 ms).  From `big_from` proofs the launches are large enough to be throughput-bound on their own and the
+  // batch runs as few passes of up to 65 536 proofs (round 4; bn254_set_plonk_params has the numbers).
+  const int max_workers = g_plonk_workers.load();
+  const size_t piece = n >= (size_t)g_plonk_big_from.load() ? (size_t)g_plonk_big_piece.load() : (size_t)g_plonk_piece.load();
   int workers; size_t per, pass_cap;                                  // sub-batches, proofs per sub-batch, proofs per (equal-sized) pass of a sub-batch
   plonk_plan(n, piece, max_workers, &workers, &per, &pass_cap);
   PlonkLease lease(d, workers);   // waits until that many contexts are free
@@ -1435,6 +1445,13 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   }
   for (int w = 0; w < workers; w++) if (rcs[w]) return set_err(rcs[w], errs[w]);
   return BN254_OK;
+}
+
+void bn254_set_plonk_params(long piece, int workers, long big_from, long big_piece) {
+  if (piece >= 0) g_plonk_piece.store(piece < 256 ? 256 : (piece > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : piece));
+  if (workers >= 0) g_plonk_workers.store(workers < 1 ? 1 : (workers > PLONK_WORKERS ? PLONK_WORKERS : workers));
+  if (big_from >= 0) g_plonk_big_from.store(big_from < 1 ? 1 : big_from);
+  if (big_piece >= 0) g_plonk_big_piece.store(big_piece < 256 ? 256 : (big_piece > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : big_piece));
 }
 
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,

@@ -44,7 +44,7 @@
 #define BN_HD_DEVINLINE __host__ __device__ inline __attribute__((noinline))
 #endif
 #else
-#if defined(BN_TRACK_BOUNDS)
+#if defined(BN_TRACK_BOUNDS) || defined(BN_HOST_PLAIN_INLINE)   // (sanitizer builds of the host half, tests/hostsan: forced inlining makes them take an hour)
 #define BN_HD inline
 #else
 #define BN_HD inline __attribute__((always_inline))
@@ -512,7 +512,7 @@ BN_HD Fp fp_inv(const Fp& x) {
       const int32_t tf0 = swap ? f1 : f0, tg0 = swap ? g1 : g0, tf1 = swap ? f0 : f1, tg1 = swap ? g0 : g1;
       A = (tA - (odd ? tB : 0)) >> 1; B = tB;
       f0 = tf0 - (odd ? tf1 : 0); g0 = tg0 - (odd ? tg1 : 0);
-      f1 = tf1 << 1; g1 = tg1 << 1;
+      f1 = (int32_t)((uint32_t)tf1 << 1); g1 = (int32_t)((uint32_t)tg1 << 1);   // (as unsigned: shifting a negative value left is undefined before C++20)
     }
     // (a, b) <- (a f0 + b g0, a f1 + b g1) / 2^29, made non-negative by negating the number together with its factors
     int32_t na[BN_NL], nb[BN_NL];

@@ -366,7 +366,7 @@ struct FrCtx {
         const int32_t tf0 = swap ? f1 : f0, tg0 = swap ? g1 : g0, tf1 = swap ? f0 : f1, tg1 = swap ? g0 : g1;
         A = (tA - (odd ? tB : 0)) >> 1; B = tB;
         f0 = tf0 - (odd ? tf1 : 0); g0 = tg0 - (odd ? tg1 : 0);
-        f1 = tf1 << 1; g1 = tg1 << 1;
+        f1 = (int32_t)((uint32_t)tf1 << 1); g1 = (int32_t)((uint32_t)tg1 << 1);   // (as unsigned: shifting a negative value left is undefined before C++20)
       }
       int32_t na[9], nb[9];
       {

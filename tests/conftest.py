@@ -51,5 +51,6 @@ def hostsim():
     import subprocess
 
     d = os.path.join(ROOT, "tests", "hostsim")
-    subprocess.check_call(["make", "-s", "-C", d, "HSFLAGS=-DHS_WITH_CURVE"])
-    return ctypes.CDLL(os.path.join(d, "libhostsim.so"))
+    name = os.environ.get("BN254_HOSTSIM_LIB") or "libhostsim.so"      # tests/test_sanitizers.py: libhostsim_san.so
+    subprocess.check_call(["make", "-s", "-C", d, "HSFLAGS=-DHS_WITH_CURVE", name])
+    return ctypes.CDLL(os.path.join(d, name))

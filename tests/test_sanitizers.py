@@ -1,0 +1,43 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer over everything of this repository that runs on a CPU --
+sanitizers on the CPU builds only, the GPU pool has none:
+  * the oracle (oracle/*.c) and the host build of the product's arithmetic headers with the bound tracker (tests/hostsim) rebuilt with -fsanitize=address,undefined
+    and run through their own test files in a child interpreter that preloads the sanitizer runtimes;
+  * the HOST HALF OF THE PRODUCT -- csrc/bn254_capi.hip with its parsers, key preparation, plans, pinned ring, context pools and thread pool -- compiled with g++
+    against a host-memory stand-in for the HIP runtime (tests/hostsan) and driven through the C ABI: malformed-bytes fuzz of the three parsers that take
+    attacker-shaped lengths (groth16/converter.rs:28-65, plonk/converter.rs:18-119, the SP1 fixture reader), batches around every plan boundary on the fake
+    device, the RLC fallback, wide keys, PlonK calls in flight, an allocation failure at every allocation of a call.
+A report aborts (-fno-sanitize-recover).  First run: one real finding, a left shift of a negative int in the inner loop of the constant-time inversion
+(bn254_fp.h, bn254_plonk.hpp: undefined before C++20), fixed."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _runtime(name):
+    p = subprocess.check_output(["gcc", "-print-file-name=" + name], text=True).strip()
+    assert os.path.isabs(p) and os.path.exists(p), "sanitizer runtime %s not found" % name
+    return p
+
+
+def test_oracle_and_hostsim_under_asan_ubsan():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_san.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "HSFLAGS=-DHS_WITH_CURVE", "libhostsim_san.so"])
+    env = dict(os.environ, LD_PRELOAD=_runtime("libasan.so") + ":" + _runtime("libubsan.so"), ASAN_OPTIONS="detect_leaks=0",
+               BN254_ORACLE_LIB=os.path.join(ROOT, "oracle", "liboracle_san.so"), BN254_HOSTSIM_LIB="libhostsim_san.so")
+    files = ["tests/test_oracle_golden.py", "tests/test_oracle_arith.py", "tests/test_hostsim.py", "tests/test_rlc_hostsim.py", "tests/test_msm_rows.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_host_half_of_the_library_under_asan_ubsan():
+    d = os.path.join(ROOT, "tests", "hostsan")
+    exe = os.path.join(d, "hostsan")
+    src = [os.path.join(d, "hostsan_main.cpp"), os.path.join(d, "hip", "hip_runtime.h")] + [os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", f)
+                                                                                            for f in os.listdir(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc")) if f.endswith((".h", ".hpp", ".hip"))]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in src):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-DBN_HOST_PLAIN_INLINE", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                               "-x", "c++", "-I", d, "-I", os.path.join(ROOT, "include"), os.path.join(d, "hostsan_main.cpp"), "-o", exe, "-lpthread", "-ldl"], cwd=d)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden"), "100"], cwd=ROOT, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "hostsan ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
