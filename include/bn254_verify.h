@@ -167,7 +167,9 @@ int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk
                        size_t n_public, uint8_t* status);
 /* Knobs of the PlonK batch plan (process-wide, atomic; -1 leaves a knob alone; initial values from BN254_PLONK_PIECE / _WORKERS / _BIG_FROM / _BIG_PIECE, read once at
  * load time): below big_from proofs a batch is up to `workers` chains of passes of at most `piece` proofs side by side (latency-bound launches), from big_from on
- * few passes of up to big_piece <= 65536 proofs (throughput-bound launches).  Same status bytes either way. */
+ * few passes of up to big_piece <= 65536 proofs (throughput-bound launches).  big_from = 0 (the default) selects the plan measured on the MI355X: chains up to
+ * ~9000 proofs, one pass up to ~20 000, two passes side by side up to ~40 000, one pass up to 65 536, passes of 65 536 on up to eight contexts beyond.  Same status
+ * bytes whatever the plan. */
 void bn254_set_plonk_params(long piece, int workers, long big_from, long big_piece);
 /* Durations (ms) of the first sub-batch of the bn254_plonk_verify_batch that finished last on `device`, from HIP events on the sub-batch's stream:
  *   [0] host: staging copy into pinned memory (with BN254_PLONK_HOST=1: stage 1 on host threads)      [1] k_plonk_stage1

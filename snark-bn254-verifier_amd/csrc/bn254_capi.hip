@@ -324,13 +324,24 @@ static int shape_var(const MsmShape& sh) { int v = 0; for (int s = 0; s < sh.n_s
 //              MSM launches keep their split form)
 //   workers    sub-batches in flight (contexts), at most PLONK_WORKERS
 //   big_from   from this many proofs a batch runs as FEW LARGE passes instead (throughput: one row per variable term, fixed windows packed, the pairing check on
-//              the lane kernels with the whole Miller loop in one launch): 65 536 proofs in one pass 2.28 M proofs/s against 1.54 M as eight chains of 5040-proof passes
+//              the lane kernels with the whole Miller loop in one launch): 65 536 proofs in one pass 2.28 M proofs/s against 1.48 M as eight chains of 5040-proof passes.
+//              0 (default): the plan measured on the MI355X (plonk_auto_plan, profiles/r04_plonk_plan_sweep.txt)
 //   big_piece  proofs per pass of that form (at most PLONK_MAX_LAUNCH)
 static std::atomic<long> g_plonk_piece{[] { long v = env_long("BN254_PLONK_PIECE", 5040); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
 static std::atomic<int> g_plonk_workers{[] { long v = env_long("BN254_PLONK_WORKERS", PLONK_WORKERS); return (int)(v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v)); }()};
-static std::atomic<long> g_plonk_big_from{[] { long v = env_long("BN254_PLONK_BIG_FROM", 24576); return v < 1 ? 1 : v; }()};
+static std::atomic<long> g_plonk_big_from{[] { long v = env_long("BN254_PLONK_BIG_FROM", 0); return v < 0 ? 0 : v; }()};      // 0: the measured plan of plonk_auto_plan
 static std::atomic<long> g_plonk_big_piece{[] { long v = env_long("BN254_PLONK_BIG_PIECE", PLONK_MAX_LAUNCH); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
 // the plan of a batch (bn254_plonk_verify_batch): sub-batches side by side, proofs per sub-batch, proofs per pass of a sub-batch
+// The default plan by batch size (profiles/r04_plonk_plan_sweep.txt, one MI355X): chains of 5040-proof passes side by side up to ~9000 proofs (8192: 7.06 ms against
+// 7.27 ms as one pass); ONE pass of the whole batch up to ~20 000 (16 384: 12.2 against 12.7 ms); TWO passes side by side up to ~40 000 (32 768: 18.3 ms against 20.2 ms
+// as one pass and 22.3 ms as chains); one pass again up to 65 536 (49 152: 25.1 ms = 1.96 M proofs/s, 65 536: 28.8 ms = 2.28 M, chains 1.48 M); beyond, passes of up to
+// 65 536 proofs on up to eight contexts (262 144: 2.62 M proofs/s).
+static void plonk_auto_plan(size_t n, size_t chain_piece, int max_workers, size_t* piece, int* workers_cap) {
+  if (n <= 9000) { *piece = chain_piece; *workers_cap = max_workers; }
+  else if (n <= 20000) { *piece = n; *workers_cap = 1; }
+  else if (n <= 40000) { *piece = (n + 1) / 2; *workers_cap = max_workers < 2 ? max_workers : 2; }
+  else { *piece = n < (size_t)PLONK_MAX_LAUNCH ? n : (size_t)PLONK_MAX_LAUNCH; *workers_cap = max_workers; }
+}
 static void plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per, size_t* pass) {
   int w = (int)((n + piece - 1) / piece); if (w > max_workers) w = max_workers; if (w < 1) w = 1;
   const size_t p = (n + (size_t)w - 1) / (size_t)w;
@@ -1414,8 +1425,11 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
   // MSM launches keep their split form, and several such chains of latency-bound launches side by side fill the GPU where one chain of larger launches does not
   // (round 3: 8192 proofs 9.9 -> 8.3 ms, 16 384 15.7 -> 13.1 ms).  From `big_from` proofs the launches are large enough to be throughput-bound on their own and the
   // batch runs as few passes of up to 65 536 proofs (round 4; bn254_set_plonk_params has the numbers).
-  const int max_workers = g_plonk_workers.load();
-  const size_t piece = n >= (size_t)g_plonk_big_from.load() ? (size_t)g_plonk_big_piece.load() : (size_t)g_plonk_piece.load();
+  int max_workers = g_plonk_workers.load();
+  size_t piece;
+  const long big_from = g_plonk_big_from.load();
+  if (big_from == 0) plonk_auto_plan(n, (size_t)g_plonk_piece.load(), max_workers, &piece, &max_workers);
+  else piece = n >= (size_t)big_from ? (size_t)g_plonk_big_piece.load() : (size_t)g_plonk_piece.load();
   int workers; size_t per, pass_cap;                                  // sub-batches, proofs per sub-batch, proofs per (equal-sized) pass of a sub-batch
   plonk_plan(n, piece, max_workers, &workers, &per, &pass_cap);
   PlonkLease lease(d, workers);   // waits until that many contexts are free
@@ -1450,7 +1464,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
 void bn254_set_plonk_params(long piece, int workers, long big_from, long big_piece) {
   if (piece >= 0) g_plonk_piece.store(piece < 256 ? 256 : (piece > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : piece));
   if (workers >= 0) g_plonk_workers.store(workers < 1 ? 1 : (workers > PLONK_WORKERS ? PLONK_WORKERS : workers));
-  if (big_from >= 0) g_plonk_big_from.store(big_from < 1 ? 1 : big_from);
+  if (big_from >= 0) g_plonk_big_from.store(big_from);      // 0: the measured default plan
   if (big_piece >= 0) g_plonk_big_piece.store(big_piece < 256 ? 256 : (big_piece > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : big_piece));
 }
 
