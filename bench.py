@@ -52,7 +52,27 @@ def algo_bytes_per_proof(n_public):
 
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_MAD_PER_S = 35.1e12   # measured v_mad_u64_u32 lane-rate, profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64)
+VALU_PEAK_REFERENCE = 35.1e12   # v_mad_u64_u32 lane-rate of the box of profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64): the guide has no integer multiply-add peak
+VALU_PEAK_MAD_PER_S = VALU_PEAK_REFERENCE   # replaced at run time by the rate of THIS box (measure_valu_peak: bn254_dbg_valu_peak, ~2 ms); boxes of the pool differ by +-2 %
+VALU_PEAK_MEASURED = None
+
+
+def measure_valu_peak(pkg, device=0):
+    """The multiply-add issue rate of the box the bench runs on (the library's k_valu_peak: 16 independent v_mad_u64_u32 chains per lane, two wavefronts per SIMD, best
+    of five launches); every VALU fraction of the line is taken against it, the round-1 constant stays beside it as `peak_reference`."""
+    global VALU_PEAK_MAD_PER_S, VALU_PEAK_MEASURED
+    import ctypes as C
+    v = C.c_double(0.0)
+    L = pkg.lib()
+    L.bn254_dbg_valu_peak.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    if L.bn254_dbg_valu_peak(device, C.byref(v)) == 0 and v.value > 1e12:
+        VALU_PEAK_MEASURED = v.value
+        VALU_PEAK_MAD_PER_S = v.value
+    return VALU_PEAK_MEASURED
+
+
+def _peak_fields():
+    return {"peak": VALU_PEAK_MAD_PER_S / 1e12, "peak_measured": (VALU_PEAK_MEASURED / 1e12) if VALU_PEAK_MEASURED else None, "peak_reference": VALU_PEAK_REFERENCE / 1e12}
 METRIC = "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X"
 SEED = 0xB2540002
 
@@ -71,6 +91,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-rlc", action="store_true", help="skip the rlc_mode side measurement (all-valid batch, exact against RLC)")
     ap.add_argument("--rlc", action="store_true", help="time the random-linear-combination batch mode instead of the exact path")
     ap.add_argument("--host-buffers", action="store_true", help="also time the host-buffer entry (PCIe-inclusive), reported beside `value`")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="REHEARSAL of --gpus N on ONE GPU: N rank processes, all on cuda:0, gloo for the status gather and the "
+                    "reductions (RCCL refuses two ranks on one device); the line says so and its value is not a scaling number")
     return ap.parse_args(argv)
 
 
@@ -89,6 +111,8 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    if args.rehearse_one_gpu:
+        env["BENCH_REHEARSE_ONE_GPU"] = "1"
     return subprocess.call(cmd, env=env)
 
 
@@ -115,10 +139,17 @@ class GpuVerifier:
         self.stream = torch.cuda.current_stream(self.dev)
         self.side = torch.cuda.Stream(self.dev)     # the status gather runs here, beside the next batch
         self.flags = pkg.FLAG_RLC if args.rlc else 0
+        self.gather_done = [None, None]             # event after the gather that last READ status buffer 0 / 1 (on the side stream)
+        self.cpu_gather = getattr(args, "cpu_gather", False)   # rehearsal: the collective runs under gloo on host copies of the shard
         pkg.lib().bn254_set_profiling(1)
 
     def step(self):
         self.d_status = self.d_st[self.k & 1]
+        # batch k writes the buffer that gather k - 2 read: the gather runs on a side stream (and, with world > 1, may wait for a slow rank), so the
+        # main stream waits for THAT gather before it lets the batch touch the buffer -- transient PENDING bytes must never reach a collective
+        ev = self.gather_done[self.k & 1]
+        if ev is not None:
+            self.stream.wait_event(ev)
         self.k += 1
         self.pvk.verify_batch_device(self.d_proofs.data_ptr(), self.d_inputs.data_ptr(), self.d_status.data_ptr(), self.n, 256,
                                      self.args.n_public, self.local_rank, self.stream.cuda_stream, flags=self.flags)
@@ -134,8 +165,13 @@ class GpuVerifier:
         with torch.cuda.stream(self.side):
             self.side.wait_event(done)
             a = torch.cuda.Event(enable_timing=True); a.record(self.side)
-            full = sharding.gather_status(st, n_total, world)
+            if self.cpu_gather:
+                # rehearsal on one GPU: gloo gathers host copies (the copy waits on the side stream for this batch's last kernel)
+                full = sharding.gather_status(st.cpu(), n_total, world).to(self.dev)
+            else:
+                full = sharding.gather_status(st, n_total, world)
             b = torch.cuda.Event(enable_timing=True); b.record(self.side)
+            self.gather_done[(self.k - 1) & 1] = b
         return full, (a, b)
 
     def accumulate_profile(self, on):
@@ -242,7 +278,7 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
     if hasattr(v, "accumulate_profile"):
         v.accumulate_profile(False)
     if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=full.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if backend == "gloo" else full.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     gather_ms = sum(v.elapsed_ms(a, b) for a, b in gathers) / max(1, len(gathers))
@@ -309,13 +345,13 @@ def _valu_roofline(dom, launches_ms, per_launch, passes=None):
     avg_ms = total_ms / max(1, launches)
     mads = (_load_json("kernel_mads.json") or {}).get("kernels", {}).get(dom, {}).get("mads_per_proof_launch")
     traffic = (_load_json("pmc_traffic.json") or {}).get(dom)
-    r = {"bound": "valu", "kernel": dom, "unit": "T mad/s", "peak": VALU_PEAK_MAD_PER_S / 1e12, "avg_launch_ms": avg_ms,
+    r = {"bound": "valu", "kernel": dom, "unit": "T mad/s", **_peak_fields(), "avg_launch_ms": avg_ms,
          "launches_timed": launches, "proofs_per_launch": per_launch, "union_ms": union_ms, "overlap": total_ms / union_ms if union_ms else None,
          "traffic": (traffic["read_bytes_per_proof"] + traffic["write_bytes_per_proof"]) * per_launch * (passes / max(1, launches) if traffic and traffic.get("per_pass") and passes else 1) if traffic else None,
          "note": "achieved = v_mad_[iu]64_[iu]32 per proof and launch (counted in the gfx950 code object: tools/count_mads.py -> profiles/kernel_mads.json) x proofs per "
                  "launch x launches / union of the launch intervals (HIP events around every launch of the kind on BOTH sub-batch streams inside the timed region, one time "
                  "base); `overlap` = summed launch durations / union (2 = the two streams ran the kernel side by side the whole time); avg_launch_ms is what rocprofv3's "
-                 "kernel trace averages; peak = measured issue rate (profiles/r01_ubench_valu.txt).  Cooperative kernels: 12 lanes per proof, count from the call-graph "
+                 "kernel trace averages; peak = the multiply-add issue rate measured on THIS box at the start of the run (peak_measured; peak_reference = profiles/r01_ubench_valu.txt).  Cooperative kernels: 12 lanes per proof, count from the call-graph "
                  "model checked against SQ_INSTS_VALU_INT64"}
     entry = (_load_json("kernel_mads.json") or {}).get("kernels", {}).get(dom, {})
     if mads and union_ms:
@@ -345,7 +381,7 @@ def _valu_whole_path(breakdown, proofs_per_s_per_gpu):
             continue
         mads += e.get("mads_per_proof_batch", cnt * e["mads_per_proof_launch"])
     ach = mads * proofs_per_s_per_gpu
-    return {"mads_per_proof": mads, "achieved": ach / 1e12, "peak": VALU_PEAK_MAD_PER_S / 1e12, "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S,
+    return {"mads_per_proof": mads, "achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S,
             "kernels_without_count": missing}
 
 
@@ -549,7 +585,75 @@ def plonk_workload(batch):
     return vk, b"".join(proofs), b"".join(inputs), proofs, inputs
 
 
-def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
+def _plonk_accounting(pkg, km, batch, stage_ms):
+    """Executed multiply-adds of a PlonK batch's launches from its plans.  Returns the roofline of the dominant kernel (the row kernel of the KZG check), the pairing
+    stage's, and the whole path's multiply-adds per proof."""
+    import ctypes as C
+    L = pkg.lib()
+    comp = km.get("k_g1_msm_rows", {}).get("components")
+    sumc = km.get("k_g1_sum_affine", {}).get("components")
+    out = {"roofline": None, "pairing": None, "whole": None, "plan": None}
+    if not comp or not sumc:
+        return out
+    # the batch plan (sub-batches in flight, proofs per pass): the library's default, reproduced through its probe
+    w, per, ps = C.c_int(), C.c_size_t(), C.c_size_t()
+    L.bn254_dbg_plonk_plan.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    if batch <= 9000: piece, mw = 5040, 8
+    elif batch <= 20000: piece, mw = batch, 1
+    elif batch <= 40000: piece, mw = (batch + 1) // 2, 2
+    else: piece, mw = min(batch, 65536), 8
+    assert L.bn254_dbg_plonk_plan(batch, piece, mw, C.byref(w), C.byref(per), C.byref(ps)) == 0
+    pass_n = min(ps.value, batch)
+    L.bn254_dbg_plonk_msm_plan.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def rows(stage):
+        nr, nv = C.c_int(), C.c_int(); sc = C.c_size_t(); ch = C.c_int(); sums, fixed = (C.c_int * 2)(), (C.c_int * 2)(); desc = (C.c_int * 256)()
+        assert L.bn254_dbg_plonk_msm_plan(1, stage, pass_n, 0, C.byref(nr), C.byref(nv), C.byref(sc), C.byref(ch), sums, fixed, desc) == 0
+        per_row = []
+        for r in range(nr.value):
+            vt, lo, hi, ut, _s, _slot, flo, fhi = desc[8 * r:8 * r + 8]
+            m = 0.0
+            if vt >= 0:
+                m += comp["table_head"] + 9 * comp["table_add"] + (hi - lo) / 2 * comp["step"] + lo * comp["dbl"]
+            if ut >= 0:
+                m += comp["unit"]
+            m += (fhi - flo) * comp["mixed"] * 255.0 / 256.0       # a zero byte skips its table addition
+            per_row.append(m)
+        return per_row, list(sums)
+
+    r1, s1 = rows(1)
+    r2, s2 = rows(2)
+    msm = sum(r1) + sum(r2)
+    sums = 2 * sumc["tail"] + sumc["add"] * (s1[0] + s2[0] + s2[1]) + sumc["tail"]
+    coop = pass_n <= 40960
+    if coop:
+        pair = km.get("k_coop12_miller_fixed", {}).get("mads_per_proof_launch")
+    else:
+        fe = sum(km[k].get("mads_per_proof_batch", c * km[k]["mads_per_proof_launch"]) for k, c in
+                 (("k_f12_inv", 1), ("k_f12_conj", 5), ("k_f12_frob", 4), ("k_f12_cyclo_sqr", 6), ("k_f12_cyclo_sqr_n", 39), ("k_f12_mul", 60)) if k in km)
+        pair = km.get("k_miller_run_fixed2", {}).get("mads_per_proof_launch", 0) + fe
+    out["plan"] = {"sub_batches_in_flight": w.value, "proofs_per_pass": pass_n, "digest_rows": len(r1), "kzg_rows": len(r2), "pairing": "cooperative kernel (12 lanes per proof)" if coop else "lane kernels (k_miller_run_fixed2 + the final-exponentiation program)"}
+    t2 = stage_ms.get("k_g1_msm_rows_kzg", 0)
+    if t2 > 0:
+        # one launch of the first sub-batch: its pass_n proofs x the rows' multiply-adds / the launch's duration (other sub-batches may run beside it: a per-launch figure)
+        ach = sum(r2) * pass_n / (t2 * 1e-3)
+        n_lanes = len(r2) * ((pass_n + 63) // 64 * 64)
+        out["roofline"] = {"bound": "valu", "kernel": "k_g1_msm_rows (KZG check: P0 and P1)", "unit": "T mad/s", **_peak_fields(), "achieved": ach / 1e12, "frac": ach / VALU_PEAK_MAD_PER_S,
+                           "avg_launch_ms": t2, "rows_per_proof": len(r2), "lanes_per_launch": n_lanes, "executed_mads_per_proof": sum(r2), "longest_row_mads": max(r2), "traffic": None,
+                           "note": "achieved = multiply-adds the launched rows EXECUTE (plan rows x loop bodies of the code object) x proofs of the launch / its HIP-event duration; "
+                                   "%d lanes = %.2f wavefronts per SIMD, so up to one wavefront per SIMD the launch lasts as long as its longest row (%d multiply-adds)" % (n_lanes, n_lanes / 65536.0, int(max(r2)))}
+    tp = stage_ms.get("pairing_check", 0)
+    if pair and tp > 0:
+        a2 = pair * pass_n / (tp * 1e-3)
+        out["pairing"] = {"kernel": "k_coop12_miller_fixed" if coop else "k_miller_run_fixed2 + final exponentiation", "ms": tp, "mads_per_proof": pair, "achieved": a2 / 1e12, "frac": a2 / VALU_PEAK_MAD_PER_S}
+    if pair:
+        out["whole"] = {"mads_per_proof": msm + sums + pair, "msm_rows": msm, "sums": sums, "pairing": pair,
+                        "note": "k_plonk_stage1 / k_plonk_stage2 (transcripts, Fr arithmetic on 32-bit words) carry < 1 % of a proof's multiply-adds and are not counted"}
+    return out
+
+
+def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=512, in_flight=True):
     """BASELINE configs[3]: PlonK batch (the reference's 4 fixtures + mutated copies, every 8th proof invalid), host buffers in, status bytes
     out.  Statuses of the first cpu_sample proofs against the oracle; cpu_baseline = the oracle's PlonK verifier on one core."""
     from oracle import oracle as O
@@ -561,30 +665,15 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
     for _ in range(steps):
         st = pvk.verify_batch(pb, ib)
     dt = time.perf_counter() - t
-    # the dominant GPU kernel against the VALU peak: the merged k_g1_scalar_mul launch of stage 2 (one lane per scalar multiplication,
-    # multiply-adds per lane from the code object: tools/count_mads.py), and the pairing check on the cooperative kernel
+    # Accounting.  Multiply-adds EXECUTED by the launched form, from the row plans the library made for this batch size (bn254_dbg_plonk_msm_plan) priced with the
+    # loop bodies of the code object (tools/count_mads.py -> kernel_mads.json `components`), against the HIP-event durations of the first sub-batch's launches.
     stage_ms, lanes = pvk.last_timing()
     km = (_load_json("kernel_mads.json") or {}).get("kernels", {})
-    peak = VALU_PEAK_MAD_PER_S
-    env = os.environ.get
-    roofline = pairing = None
-    if "k_g1_scalar_mul" in km and stage_ms.get("k_g1_scalar_mul_stage2", 0) > 0:
-        split = (lanes[1] * 2 <= 65536 or env("BN254_MSM_SPLIT") == "1") and env("BN254_MSM_SPLIT") != "0"      # bn254_g1_msm_split
-        w2 = lanes[1] * (2 if split else 1) <= 65536 and env("BN254_MSM_W2", "1") != "0"                          # bn254_g1_msm_tab_lanes
-        e = km["k_g1_scalar_mul" + ("_split" if split else "") + ("_w2" if w2 else "")]
-        sm = e["mads_per_proof_launch"]                                                            # the longest lane's chain
-        useful = km["k_g1_scalar_mul"]["mads_per_proof_launch"] * lanes[1]                          # the work of the unsplit algorithm
-        ach = useful / (stage_ms["k_g1_scalar_mul_stage2"] * 1e-3)
-        n_lanes = lanes[1] * (2 if split else 1)
-        roofline = {"bound": "valu", "kernel": "k_g1_scalar_mul" + ("<split>" if split else "") + ("<two-bit windows>" if w2 else ""), "unit": "T mad/s", "peak": peak / 1e12, "achieved": ach / 1e12, "frac": ach / peak,
-                    "avg_launch_ms": stage_ms["k_g1_scalar_mul_stage2"], "terms_per_launch": lanes[1], "lanes_per_launch": n_lanes, "mads_per_term_unsplit": km["k_g1_scalar_mul"]["mads_per_proof_launch"],
-                    "longest_lane_chain_mads": sm, "traffic": None,
-                    "note": "%d lanes = %.2f wavefronts per SIMD: the launch lasts as long as its longest lane's chain (%d multiply-adds); achieved = multiply-adds of the "
-                            "one-lane-per-term algorithm / launch time; peak = measured issue rate with full occupancy (profiles/r01_ubench_valu.txt)" % (n_lanes, n_lanes / 64 / 1024.0, int(sm))}
-        pc = km.get("k_coop12_miller_fixed")
-        if pc and batch <= 40960 and stage_ms.get("pairing_check", 0) > 0:
-            a2 = pc["mads_per_proof_launch"] * min(batch, 65536) / (stage_ms["pairing_check"] * 1e-3)
-            pairing = {"kernel": "k_coop12_miller_fixed", "ms": stage_ms["pairing_check"], "mads_per_proof": pc["mads_per_proof_launch"], "achieved": a2 / 1e12, "frac": a2 / peak}
+    acct = _plonk_accounting(pkg, km, batch, stage_ms)
+    roofline, pairing, whole = acct["roofline"], acct["pairing"], acct["whole"]
+    if whole:
+        ach = whole["mads_per_proof"] * batch * steps / dt
+        whole.update({"achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S})
     m = min(cpu_sample, batch)
     t = time.perf_counter()
     ref = bytes(O.plonk_verify(proofs[i], vk, [int.from_bytes(inputs[i][:32], "big"), int.from_bytes(inputs[i][32:], "big")]) for i in range(m))
@@ -594,8 +683,8 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
     # the same batch with several calls in flight on the one prepared key (host threads: what a verifier service with requests pending does);
     # a single batch of this size is a chain of latency-bound launches, so the aggregate rate rises until the launches of different calls share SIMDs
     import threading
-    in_flight = {}
-    for k in (2, 4):
+    run_in_flight, in_flight = in_flight, {}
+    for k in ((2, 4) if run_in_flight else ()):
         outs = [None] * k
         def work(j, rounds):
             for _ in range(rounds):
@@ -615,7 +704,7 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=64):
             "value": batch * steps / dt, "unit": "proofs/s", "ms_per_step": dt * 1e3 / steps, "steps": steps, "batch": batch,
             "status_check": "first %d statuses == oracle; %d ACCEPT of %d" % (m, batch - batch // 8, batch),
             "calls_in_flight": in_flight,
-            "roofline": roofline, "pairing_check": pairing, "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "roofline": roofline, "pairing_check": pairing, "valu_whole_path": whole, "plan": acct["plan"], "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "hbm_roofline": {"algorithmic_bytes_per_proof": 904 + 64 + 1, "achieved": batch * steps / dt * 969 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": batch * steps / dt * 969 / 1e9 / HBM_PEAK_GBPS},
             "cpu_baseline": {"value": m / cdt, "unit": "proofs/s", "cores": 1, "kind": "port", "sample": "first %d proofs, %.1f s" % (m, cdt)}}
 
@@ -655,7 +744,8 @@ def other_configs(args, pkg, local_rank, resident_value, keep):
     """The `configs` block of the bench line."""
     cfg = {}
     cfg["batch4096"] = device_config(pkg, local_rank, "BASELINE configs[1]: batch 4096 Groth16 proofs, 2 public inputs, inputs resident", 2, 4096, 20, 2, 0xB2540001, 64)
-    cfg["plonk4096"] = plonk_config(pkg, 4096, 5, 1, 32)
+    cfg["plonk4096"] = plonk_config(pkg, 4096, 5, 1, 512)
+    cfg["plonk65536"] = plonk_config(pkg, 65536, 3, 1, 16, in_flight=False)
     cfg["groth16_1024x4096"] = device_config(pkg, local_rank, "BASELINE configs[4]: batch 4096 Groth16 proofs, 1024 public inputs, inputs resident", 1024, 4096, 5, 1, 0xB2540004, 16)
     hb = _host_buffer_line(args, pkg, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"], local_rank)
     hb["workload"] = "the headline batch through bn254_groth16_verify_batch on pageable host buffers (PCIe-inclusive; never `value`)"
@@ -676,6 +766,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearse = os.environ.get("BENCH_REHEARSE_ONE_GPU") == "1" or (args.rehearse_one_gpu and world > 1)
+    if rehearse:
+        local_rank = 0                      # every rank drives the ONE device of the box
+        args.cpu_gather = True
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     torch.cuda.set_device(local_rank)
@@ -684,8 +778,12 @@ def main(argv=None):
     use_dist = world > 1 or "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     pkg = importlib.import_module("snark-bn254-verifier_amd")
+    measure_valu_peak(pkg, local_rank)
     keep = {}
 
     def make(vk, proofs, inputs, lr):
@@ -698,8 +796,13 @@ def main(argv=None):
         return r
 
     lines = []
-    out = run_rank(args, make, "nccl", rank, world, local_rank, synth, emit=lines.append)
+    out = run_rank(args, make, "gloo" if rehearse else "nccl", rank, world, local_rank, synth, emit=lines.append)
     if rank == 0:
+        if rehearse:
+            out["rehearsal"] = ("REHEARSAL: %d rank processes on ONE GPU (cuda:0), gloo for the status gather and the reductions -- exercises run_rank end to end with the real "
+                                "kernels (range generation, two processes' streams on one device, gathered order against the expected statuses); NOT a scaling number: the "
+                                "ranks share one GPU and the collective is not RCCL" % world)
+            out["config"]["parallelism"] += " [rehearsal on one GPU]"
         if world == 1:
             headline = (args.n_public, args.batch_log2, bool(args.rlc), bool(args.weak)) == (2, 20, False, False)
             if not args.no_cpu_baseline:

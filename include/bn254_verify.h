@@ -251,6 +251,8 @@ int bn254_synth_groth16_range(uint64_t seed, size_t n_public, size_t first, size
 /* ---- probes of the device arithmetic, used by the GPU parity tests (tests/test_gpu_*.py) ---------------------------
  * Each runs one lane per item on `device` and copies the result back.  Fp12 layout: 12 x 32 bytes in tower order
  * c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1; G1: x | y; G2: x.c1 | x.c0 | y.c1 | y.c0 (gnark order). */
+/* measurement probe: lane-level v_mad_u64_u32 per second of `device` (two wavefronts per SIMD, 16 independent chains per lane): the VALU peak of THIS box */
+int bn254_dbg_valu_peak(int device, double* mads_per_s);
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);                 /* n x 32 B each */
 int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);        /* 0 mul 1 sqr 2 inv 3 cyclo_sqr(after easy part) 4 frob1 */
 int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, size_t n, int device);          /* e(P_i, Q_i), n x 384 B */

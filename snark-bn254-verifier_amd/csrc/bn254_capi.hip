@@ -1617,6 +1617,15 @@ int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, si
   return BN254_OK;
 }
 
+// the multiply-add issue rate of THIS device (lane-level v_mad_u64_u32 per second, sixteen independent chains per lane, two wavefronts per SIMD, best of five
+// launches of ~0.25 ms): what bench.py divides its VALU rooflines by (the constant of profiles/r01_ubench_valu.txt, 35.1e12, stays as the reference)
+int bn254_dbg_valu_peak(int device, double* mads_per_s) {
+  if (!mads_per_s) return set_err(BN254_E_BAD_ARG, "bad argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  *mads_per_s = bn254_measure_valu_peak(5);
+  return *mads_per_s > 0 ? BN254_OK : set_err(BN254_E_HIP, "peak measurement failed");
+}
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {
   return run_probe(32, 32, 32, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp_mul(x, y, o, m, nullptr); });
 }

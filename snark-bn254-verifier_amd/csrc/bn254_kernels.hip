@@ -591,6 +591,28 @@ __global__ void k_scatter_status(uint8_t* __restrict__ status, const uint8_t* __
 }
 
 // =====================================================================================================================
+// the issue rate of the instruction every field product is made of, measured on THIS device: sixteen independent v_mad_u64_u32 chains per lane, two
+// wavefronts per SIMD (tools/ubench_valu.hip: 1.92 ns per wavefront-instruction and SIMD on the box of profiles/r01_ubench_valu.txt = 35.1 T lane-mads/s;
+// boxes of one pool differ by a few percent, so bench.py prices its rooflines with the rate of the box it runs on)
+// =====================================================================================================================
+#define VALU_PEAK_ITERS 2048
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed) {
+  const uint32_t tid = threadIdx.x + blockIdx.x * blockDim.x;
+  const uint32_t a = seed * 2654435761u + tid, b = (seed ^ 0x9e3779b9u) + tid * 7u;
+  uint64_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = (uint64_t)(a + i) << 7 | (uint32_t)i;
+  for (int it = 0; it < VALU_PEAK_ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+  }
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) x ^= (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32);
+  out[tid] = x;
+}
+
+// =====================================================================================================================
 // probes for the GPU parity tests
 // =====================================================================================================================
 __device__ __forceinline__ Fp probe_ld_fp(const uint8_t* p) {
@@ -860,6 +882,30 @@ hipError_t bn254_launch_gather_rows(uint8_t* dst, const uint8_t* src, size_t src
 hipError_t bn254_launch_scatter_status(uint8_t* status, const uint8_t* fb_status, const uint32_t* idx, uint32_t m, hipStream_t s) {
   if (m) hipLaunchKernelGGL(k_scatter_status, dim3(grid_for(m)), dim3(256), 0, s, status, fb_status, idx, m);
   return hipGetLastError();
+}
+// lane-level multiply-adds per second of the current device (best of `reps` launches of k_valu_peak at two wavefronts per SIMD); 0 on failure
+double bn254_measure_valu_peak(int reps) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0.0;
+  const int grid = p.multiProcessorCount * 2;             // 256 threads = one wavefront on each SIMD of a CU; two blocks per CU
+  uint32_t* out = nullptr;
+  if (hipMalloc((void**)&out, (size_t)grid * 256 * 4) != hipSuccess) return 0.0;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_valu_peak, dim3(grid), dim3(256), 0, nullptr, out, 1u);
+  float best = 1e30f;
+  for (int r = 0; r < reps; r++) {
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_valu_peak, dim3(grid), dim3(256), 0, nullptr, out, (uint32_t)(r + 2));
+    (void)hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess) { best = 1e30f; break; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+  if (best > 1e29f) return 0.0;
+  return (double)grid * 256.0 * (double)VALU_PEAK_ITERS * 16.0 / ((double)best * 1e-3);
 }
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_dbg_fp_mul, dim3(grid_for(n)), dim3(256), 0, s, a, b, o, n);

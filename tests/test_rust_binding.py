@@ -6,9 +6,9 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-C_KIND = {"int": "i32", "unsigned": "u32", "size_t": "usize", "uint64_t": "u64", "long": "long", "float": "f32", "uint8_t": "u8", "void": "void", "char": "char",
+C_KIND = {"int": "i32", "unsigned": "u32", "size_t": "usize", "uint64_t": "u64", "long": "long", "float": "f32", "double": "f64", "uint8_t": "u8", "void": "void", "char": "char",
           "bn254_g16_pvk": "opaque:g16", "bn254_plonk_pvk": "opaque:plonk"}
-R_KIND = {"c_int": "i32", "c_uint": "u32", "usize": "usize", "u64": "u64", "c_long": "long", "f32": "f32", "u8": "u8", "c_void": "void", "c_char": "char",
+R_KIND = {"c_int": "i32", "c_uint": "u32", "usize": "usize", "u64": "u64", "c_long": "long", "f32": "f32", "f64": "f64", "u8": "u8", "c_void": "void", "c_char": "char",
           "Bn254G16Pvk": "opaque:g16", "Bn254PlonkPvk": "opaque:plonk", "()": "void"}
 
 

@@ -117,6 +117,51 @@ def count_in(mads, lo, hi):
     return sum(1 for a in mads if lo <= a <= hi)
 
 
+def model_components(name, ins):
+    """Kernels whose loops run a launch-dependent number of times (the row kernels of the PlonK MSMs, the two-pair Miller loop): the multiply-adds of each loop
+    BODY, recognised by size -- a complete addition ~2000, a mixed addition ~1800, a doubling ~1240, a two-bit step (2 doublings + 1 addition) ~4460 -- so that
+    bench.py prices a launch from its plan (bn254_dbg_plonk_msm_plan): rows x (table + steps x step + doublings x dbl + windows x mixed)."""
+    mads = [a for a, t, _ in ins if MAD.match(t)]
+    groups = [(h, l, count_in(mads, h, l[-1])) for h, l in loop_groups(ins, mads)]
+    groups = [g for g in groups if g[2] > 0]
+    comp, in_loops = {}, 0
+    if name == "k_g1_msm_rows":
+        for h, l, c in groups:
+            key = "step" if 4300 <= c <= 4600 else "table_add" if 1950 <= c <= 2050 else "dbl" if 1150 <= c <= 1350 else "mixed" if 1700 <= c <= 1900 else None
+            if key == "table_add" and comp.get(key) == c:
+                continue                                  # the 3 x 3 table loop: the outer loop holds nothing but the inner one
+            assert key and key not in comp, ("k_g1_msm_rows: loop layout changed", c, comp)
+            comp[key] = c; in_loops += c
+        assert set(comp) == {"step", "table_add", "dbl", "mixed"}, comp
+        rest = len(mads) - in_loops
+        comp["unit"] = comp["mixed"]                      # the unit term: one mixed addition outside the loops
+        comp["table_head"] = rest - comp["unit"]          # multiples of P and phi(P): 2 doublings, 2 mixed additions, beta x
+        full = comp["table_head"] + 9 * comp["table_add"] + 64 * comp["step"]
+        return {"static_mads": len(mads), "components": comp, "mads_per_proof_launch": float(full), "unmodelled": [],
+                "model": "row kernel: multiply-adds per loop body (complete addition %(table_add)d x9 for the window table, two-bit step %(step)d, doubling %(dbl)d, mixed addition "
+                         "%(mixed)d per fixed-base byte window / unit term; table head %(table_head)d); mads_per_proof_launch = ONE unsplit variable row (table + 64 steps); a "
+                         "launch is priced from its plan" % comp}
+    if name == "k_g1_sum_affine":
+        add = [c for h, l, c in groups if 1900 <= c <= 2050]
+        assert len(add) == 1, ("k_g1_sum_affine: loop layout changed", groups)
+        e = model_kernel("k_g1_sum_affine_inv", ins)      # the inversion's rounds
+        base = e["mads_per_proof_launch"] - add[0]
+        return {"static_mads": len(mads), "components": {"add": add[0], "tail": base}, "mads_per_proof_launch": float(base + 14 * add[0]), "unmodelled": [],
+                "model": "sum of a plan's rows: complete addition %d per row + %d (to affine: binary-GCD inversion, two products); mads_per_proof_launch = 14 rows" % (add[0], base)}
+    if name == "k_miller_run_fixed2":
+        assert len(groups) == 1, ("k_miller_run_fixed2: one step loop expected", groups)
+        h, l, c = groups[0]
+        # the compiler peels the steps without a squaring (the first step and the 23 additions) into a second copy of the two line products behind the loop:
+        # the loop body is squaring + two lines, the code behind it two lines
+        lines = len(mads) - c
+        sq = [(0, 0, c - lines)]
+        assert 3500 <= sq[0][2] <= 4500 and 7000 <= lines <= 8000, ("k_miller_run_fixed2: layout changed", c, lines)
+        total = 64 * sq[0][2] + 88 * lines
+        return {"static_mads": len(mads), "components": {"sqr": sq[0][2], "two_lines": lines}, "mads_per_proof_launch": float(total), "mads_per_proof_batch": float(total), "per_pass": True,
+                "unmodelled": [], "model": "Miller loop of two table-driven pairs in one launch: squaring of f (%d multiply-adds) x64 + two line products (%d) x88" % (sq[0][2], lines)}
+    return None
+
+
 def model_kernel(name, ins):
     mads = [a for a, t, _ in ins if MAD.match(t)]
     valu = sum(1 for _, t, _ in ins if VALU.match(t))
@@ -376,8 +421,10 @@ def main():
             continue
         if name.startswith("k_coop"):
             continue                          # cooperative kernels: model_coop12 (call graph + step program)
-        e = model_kernel(name, ins)
-        e.pop("weights")
+        if name in ("k_valu_peak", "k_plonk_stage1", "k_plonk_stage2", "k_plonk_dbg_zeta"):
+            continue                          # the measurement kernel; the PlonK stages (transcripts + Fr arithmetic on 32-bit words: < 1 % of a proof's multiply-adds, counted by PMC only)
+        e = model_components(name, ins) or model_kernel(name, ins)
+        e.pop("weights", None)
         e["symbol"] = sym
         inst.setdefault(name, []).append(e)
     for name, es in inst.items():
