@@ -53,12 +53,12 @@ def algo_bytes_per_proof(n_public):
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_REFERENCE = 35.1e12   # v_mad_u64_u32 lane-rate of the box of profiles/r01_ubench_valu.txt (548 G wave-instr/s x 64): the guide has no integer multiply-add peak
-VALU_PEAK_MAD_PER_S = VALU_PEAK_REFERENCE   # replaced at run time by the rate of THIS box (measure_valu_peak: bn254_dbg_valu_peak, ~2 ms); boxes of the pool differ by +-2 %
+VALU_PEAK_MAD_PER_S = VALU_PEAK_REFERENCE   # replaced at run time by the rate of THIS box (measure_valu_peak: bn254_dbg_valu_peak, right after the timed region)
 VALU_PEAK_MEASURED = None
 
 
 def measure_valu_peak(pkg, device=0):
-    """The multiply-add issue rate of the box the bench runs on (the library's k_valu_peak: 16 independent v_mad_u64_u32 chains per lane, two wavefronts per SIMD, best
+    """The multiply-add issue rate of the box the bench runs on (the library's k_valu_peak: 16 independent v_mad_u64_u32 chains per lane, four wavefronts per SIMD, launches of about 2 ms, best
     of five launches); every VALU fraction of the line is taken against it, the round-1 constant stays beside it as `peak_reference`."""
     global VALU_PEAK_MAD_PER_S, VALU_PEAK_MEASURED
     import ctypes as C
@@ -269,6 +269,10 @@ def run_rank(args, make_verifier, backend, rank, world, local_rank, synth, emit=
             v.sync()                              # experiment: the host waits for every batch (what rounds 1-3a did through the per-step profile read)
     fence()
     elapsed = time.perf_counter() - t_start
+    if rank == 0 and getattr(v, "pkg", None) is not None:
+        # the multiply-add peak of THIS box, measured while the GPU is as warm as it was in the timed region (an idle GPU reads 10 % low: its clocks take tens of
+        # milliseconds of load to settle; at the start of the run the measurement said 29.7 .. 33.0 T, after the timed region it agrees with tools/ubench_valu)
+        measure_valu_peak(v.pkg, v.local_rank)
     # HIP-event durations of the dominant kernel's launches over ALL timed steps (both sub-batch streams), phase durations of the last step
     kp, per_launch = v.kernel_profile_all()
     for k, (cnt, ms, un) in kp.items():
@@ -351,7 +355,7 @@ def _valu_roofline(dom, launches_ms, per_launch, passes=None):
          "note": "achieved = v_mad_[iu]64_[iu]32 per proof and launch (counted in the gfx950 code object: tools/count_mads.py -> profiles/kernel_mads.json) x proofs per "
                  "launch x launches / union of the launch intervals (HIP events around every launch of the kind on BOTH sub-batch streams inside the timed region, one time "
                  "base); `overlap` = summed launch durations / union (2 = the two streams ran the kernel side by side the whole time); avg_launch_ms is what rocprofv3's "
-                 "kernel trace averages; peak = the multiply-add issue rate measured on THIS box at the start of the run (peak_measured; peak_reference = profiles/r01_ubench_valu.txt).  Cooperative kernels: 12 lanes per proof, count from the call-graph "
+                 "kernel trace averages; peak = the multiply-add issue rate measured on THIS box right after the timed region, GPU warm (peak_measured; peak_reference = profiles/r01_ubench_valu.txt).  Cooperative kernels: 12 lanes per proof, count from the call-graph "
                  "model checked against SQ_INSTS_VALU_INT64"}
     entry = (_load_json("kernel_mads.json") or {}).get("kernels", {}).get(dom, {})
     if mads and union_ms:
@@ -783,7 +787,6 @@ def main(argv=None):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     pkg = importlib.import_module("snark-bn254-verifier_amd")
-    measure_valu_peak(pkg, local_rank)
     keep = {}
 
     def make(vk, proofs, inputs, lr):

@@ -197,8 +197,9 @@ int bn254_sp1_fixture_parse(const uint8_t* buf, size_t len, int* variant, uint8_
                             uint8_t public_inputs[64], uint8_t vkey_hash[32]);
 
 /* ---- measurement support ------------------------------------------------------------------------------------------
- * A batch runs as ~720 kernel launches: one per Fp12-level operation of the verification program (k_f12_sqr, k_f12_mul,
- * k_f12_mul_line_fixed, ...), each over the whole (sub-)batch.  When profiling is enabled, verify_batch_device records HIP
+ * A sub-batch above COOP12_MAX_PROOFS runs as about 120 kernel launches: k_g16_prepare, k_vm_init, the whole Miller loop as ONE k_miller_run (or a few, g16_launch_form),
+ * k_g16_subgroup, one launch per Fp12-level operation of the final exponentiation (k_f12_mul x 60, k_f12_cyclo_sqr_n x 39, ...) and k_g16_compare; up to
+ * COOP12_MAX_PROOFS as four (k_g16_prepare, the cooperative kernel, k_g16_subgroup, k_g16_compare).  When profiling is enabled, verify_batch_device records HIP
  * events on the launch stream (a) at the four phase boundaries (prepare | subgroup | Miller loop | final exponentiation) and
  * (b) around every launch whose kernel kind is selected by bn254_set_profile_kernels (bit i = kind i, default all).
  * After the stream has been synchronised bn254_groth16_last_kernel_ms returns the phase durations and
@@ -251,7 +252,7 @@ int bn254_synth_groth16_range(uint64_t seed, size_t n_public, size_t first, size
 /* ---- probes of the device arithmetic, used by the GPU parity tests (tests/test_gpu_*.py) ---------------------------
  * Each runs one lane per item on `device` and copies the result back.  Fp12 layout: 12 x 32 bytes in tower order
  * c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1; G1: x | y; G2: x.c1 | x.c0 | y.c1 | y.c0 (gnark order). */
-/* measurement probe: lane-level v_mad_u64_u32 per second of `device` (two wavefronts per SIMD, 16 independent chains per lane): the VALU peak of THIS box */
+/* measurement probe: lane-level v_mad_u64_u32 per second of `device` (four wavefronts per SIMD, launches of about 2 ms, 16 independent chains per lane): the VALU peak of THIS box */
 int bn254_dbg_valu_peak(int device, double* mads_per_s);
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);                 /* n x 32 B each */
 int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);        /* 0 mul 1 sqr 2 inv 3 cyclo_sqr(after easy part) 4 frob1 */

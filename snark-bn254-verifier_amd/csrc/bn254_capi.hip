@@ -1617,13 +1617,13 @@ int bn254_dbg_plonk_stage1(const bn254_plonk_pvk* pvk, const uint8_t* proofs, si
   return BN254_OK;
 }
 
-// the multiply-add issue rate of THIS device (lane-level v_mad_u64_u32 per second, sixteen independent chains per lane, two wavefronts per SIMD, best of five
+// the multiply-add issue rate of THIS device (lane-level v_mad_u64_u32 per second, sixteen independent chains per lane, four wavefronts per SIMD, best of five
 // launches of ~0.25 ms): what bench.py divides its VALU rooflines by (the constant of profiles/r01_ubench_valu.txt, 35.1e12, stays as the reference)
 int bn254_dbg_valu_peak(int device, double* mads_per_s) {
   if (!mads_per_s) return set_err(BN254_E_BAD_ARG, "bad argument");
   int rc = check_device(device);
   if (rc) return rc;
-  *mads_per_s = bn254_measure_valu_peak(5);
+  *mads_per_s = bn254_measure_valu_peak(12);
   return *mads_per_s > 0 ? BN254_OK : set_err(BN254_E_HIP, "peak measurement failed");
 }
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {

@@ -222,6 +222,16 @@ __device__ __forceinline__ void c12_store_f12(const Coop12& co, int32_t* ws, uin
   if (pending) c12_ws_st(ws, n, p, e + 2 * (int)co.c + (int)co.h, r);
 }
 
+// the value in `slot` against a constant (12 Fp in k-order): every lane compares its own Fp number, the twelve lanes of a proof vote
+__device__ __forceinline__ bool c12_eq_const(const Coop12& co, int slot, const int32_t* __restrict__ target, uint32_t pl) {
+  Fp t;
+#pragma unroll
+  for (int l = 0; l < BN_NL; l++) t.v[l] = target[(2 * (int)co.c + (int)co.h) * BN_NL + l];
+  BN_SETB(t, 1.0, 0.5);
+  const uint64_t m = __builtin_amdgcn_ballot_w64(fp_eq(co.own(slot), t));
+  return ((m >> (pl * 12u)) & 0xfffull) == 0xfffull;
+}
+
 #define C12_PROLOGUE()                                                                                        \
   extern __shared__ __attribute__((aligned(16))) int32_t c12_lds[];                                           \
   const uint32_t lane = threadIdx.x & 63;                                                                     \
@@ -247,9 +257,9 @@ __global__ void __launch_bounds__(64) k_coop12_final_exp(int32_t* ws, uint32_t n
 
 // ---- Miller loop of the table-driven pairs only (PlonK's two-pair check): f = prod_t Miller(P_t, Q_t), then (optionally) the final exponentiation -------------
 __global__ void __launch_bounds__(64)
-k_coop12_miller_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ kinds, int n_pairs,
+k_coop12_miller_fixed(int32_t* ws, uint32_t n, uint8_t* status, const uint8_t* __restrict__ kinds, int n_pairs,
                       const int32_t* __restrict__ tab0, const int32_t* __restrict__ tab1, const int32_t* __restrict__ tab2,
-                      int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp) {
+                      int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, const int32_t* __restrict__ target, int reject_code) {
   C12_PROLOGUE();
   const int F = C12_SLOT(VE_F);
   co.put(F, (c == 0 && h == 0) ? fp_one() : fp_zero());
@@ -271,7 +281,11 @@ k_coop12_miller_fixed(int32_t* ws, uint32_t n, const uint8_t* __restrict__ statu
   if (fuse_final_exp) {
     Coop12Ops ops{co};
     vm_final_exp_program(ops);
-    c12_store_f12(co, ws, n, p, C12_SLOT(VE_S0), VE_S0, pending);
+    if (target) {
+      // the verdict in the same launch (k_g16_compare's rule): the result never reaches the workspace
+      const bool acc = c12_eq_const(co, C12_SLOT(VE_S0), target, pl);
+      if (pending && c == 0 && h == 0) status[p] = acc ? BN254_ST_ACCEPT : (uint8_t)reject_code;
+    } else c12_store_f12(co, ws, n, p, C12_SLOT(VE_S0), VE_S0, pending);
   } else c12_store_f12(co, ws, n, p, F, VE_F, pending);
 }
 
@@ -377,9 +391,9 @@ __device__ __noinline__ G1Proj c12_public_input_msm(const Coop12 co, const uint8
   return fetch(0);
 }
 __global__ void __launch_bounds__(64)
-k_coop12_miller_g16(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ kinds, const int32_t* __restrict__ tab0,
+k_coop12_miller_g16(int32_t* ws, uint32_t n, uint8_t* status, const uint8_t* __restrict__ kinds, const int32_t* __restrict__ tab0,
                     const int32_t* __restrict__ tab1, const uint8_t* __restrict__ inputs, int n_public, int inputs_match_key,
-                    const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0, int l_from_ws, int fuse_final_exp) {
+                    const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0, int l_from_ws, int fuse_final_exp, const int32_t* __restrict__ target) {
   C12_PROLOGUE();
   const int F = C12_SLOT(VE_F);
   // keys with many public inputs: L was computed by the wide MSM kernels (affine, in the workspace, identity flag in the status byte)
@@ -410,6 +424,24 @@ k_coop12_miller_g16(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status,
     c12_mul_line_fp2(co, F, c12_halves(ln.d0, h), c12_halves(ln.d3, h), c12_halves(ln.d4, h));
     c12_mul_line_fp(co, F, yl, c12_halves(ln.s1, h), c12_halves(ln.cz, h), l_inf);      // (Y_L + m X_L w + c Z_L w^3): the line at L scaled by Z_L
     c12_mul_line_fp(co, F, yc, c12_halves(ln.s2, h), c12_halves(l1.c, h), false);
+  }
+  if (fuse_final_exp && target) {
+    // The whole verdict in this launch (what k_g16_subgroup and k_g16_compare do for the lane kernels).  The r-torsion test of B from the loop's final
+    // point (bn254_vm.h::vm_g2_ate_check: T == -psi^3(B) projectively) costs four Fp2 products: every lane holds T and B whole and computes it for itself.
+    const Fp2 sx = fp2_mul(fp2_conj(q.x), frob_coeff(3, 2)), sy = fp2_neg(fp2_mul(fp2_conj(q.y), frob_coeff(3, 3)));
+    const bool in_g2 = !fp2_is_zero(t.z) & fp2_eq(t.x, fp2_mul(sx, t.z)) & fp2_eq(t.y, fp2_mul(sy, t.z));
+    Coop12Ops ops{co};
+    vm_final_exp_program(ops);
+    const bool acc = c12_eq_const(co, C12_SLOT(VE_S0), target, pl);
+    if (pending && c == 0 && h == 0) {
+      uint8_t out;
+      if (!in_g2) out = BN254_ST_NOT_IN_SUBGROUP;
+      else if (st & 0x3f) out = st & 0x3f;                      // deferred error of C
+      else if (!inputs_match_key) out = BN254_ST_INPUT_LEN;     // PrepareInputsFailed comes after every loader error
+      else out = acc ? BN254_ST_ACCEPT : BN254_ST_REJECT;
+      status[p] = out;
+    }
+    return;
   }
   // the running point goes back to the workspace for the r-torsion test (k_g16_subgroup): lanes of coefficients 0..2 store X, Y, Z.  Not at
   // VE_T, which the result slot VE_S0 overlays: at COOP_T_ELEM
@@ -450,22 +482,22 @@ hipError_t bn254_coop12_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStr
   return hipGetLastError();
 }
 hipError_t bn254_coop12_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
-                                     int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s) {
+                                     int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, const int32_t* target, int reject_code, hipStream_t s) {
   const uint8_t* kinds = c12_kinds_dev();
   if (!kinds) return hipErrorOutOfMemory;
   const size_t lds = (size_t)C12_WAVE_DWORDS * 4;
   (void)hipFuncSetAttribute((const void*)k_coop12_miller_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_coop12_miller_fixed, dim3(c12_grid(n)), dim3(64), lds, s, ws, (uint32_t)n, (const uint8_t*)status, kinds, n_pairs, tab0, tab1, tab2,
-                     e_p0, e_p1, e_p2, inf0, inf1, inf2, fuse_final_exp);
+  hipLaunchKernelGGL(k_coop12_miller_fixed, dim3(c12_grid(n)), dim3(64), lds, s, ws, (uint32_t)n, status, kinds, n_pairs, tab0, tab1, tab2,
+                     e_p0, e_p1, e_p2, inf0, inf1, inf2, fuse_final_exp, target, reject_code);
   return hipGetLastError();
 }
 hipError_t bn254_coop12_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
-                                   int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s) {
+                                   int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, const int32_t* target, hipStream_t s) {
   const uint8_t* kinds = c12_kinds_dev();
   if (!kinds) return hipErrorOutOfMemory;
   const size_t lds = (size_t)C12_WAVE_DWORDS * 4;
   (void)hipFuncSetAttribute((const void*)k_coop12_miller_g16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_coop12_miller_g16, dim3(c12_grid(n)), dim3(64), lds, s, ws, (uint32_t)n, (const uint8_t*)status, kinds, tab0, tab1, inputs, n_public,
-                     inputs_match_key, msm_tab, k0, l_from_ws, fuse_final_exp);
+  hipLaunchKernelGGL(k_coop12_miller_g16, dim3(c12_grid(n)), dim3(64), lds, s, ws, (uint32_t)n, status, kinds, tab0, tab1, inputs, n_public,
+                     inputs_match_key, msm_tab, k0, l_from_ws, fuse_final_exp, target);
   return hipGetLastError();
 }

@@ -131,13 +131,13 @@ hipError_t bn254_launch_pairing2_fixed(int32_t* ws, uint8_t* status, size_t n, c
 // two-pair check of the PlonK path: its lane form is still one launch per operation, the cooperative kernel keeps the range it had
 #define COOP12_MAX_PROOFS_FIXED 40960
 hipError_t bn254_coop12_miller_g16(int32_t* ws, uint8_t* status, size_t n, const int32_t* tab0, const int32_t* tab1, const uint8_t* inputs, int n_public,
-                                   int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, hipStream_t s);
+                                   int inputs_match_key, const int32_t* msm_tab, const int32_t* k0, int l_from_ws, int fuse_final_exp, const int32_t* target, hipStream_t s);
 hipError_t bn254_coop12_final_exp(int32_t* ws, uint8_t* status, size_t n, hipStream_t s);
 hipError_t bn254_coop12_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int n_pairs, const int32_t* tab0, const int32_t* tab1, const int32_t* tab2,
-                                     int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, hipStream_t s);
+                                     int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, const int32_t* target, int reject_code, hipStream_t s);
 static inline size_t bn254_coop_max_proofs() { return COOP12_MAX_PROOFS; }
 static inline size_t bn254_coop_max_proofs_fixed() { return COOP12_MAX_PROOFS_FIXED; }
-double bn254_measure_valu_peak(int reps);   // lane-level v_mad_u64_u32 per second of the current device at two wavefronts per SIMD
+double bn254_measure_valu_peak(int reps);   // lane-level v_mad_u64_u32 per second of the current device at four wavefronts per SIMD
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);
 // e(P_i, Q_i): needs a workspace of G16_WS_BYTES_PER_PROOF * n bytes and the step program

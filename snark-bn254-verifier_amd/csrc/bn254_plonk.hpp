@@ -2,12 +2,13 @@
 // converter,proof}.rs, transcript.rs, hash_to_field.rs).
 //
 // Split of the work per proof:
-//   host   parsing, the Fiat-Shamir transcripts (5 SHA-256 chains of ~1 KB), BSB22 hash-to-field, the Fr arithmetic of the
-//          linearisation (3 pow, 4 inversions, ~100 products): control-heavy, a few hundred microseconds in total per proof
-//   GPU    every group operation: the 11-term G1 MSM of the linearised polynomial digest, the folding MSMs of the KZG batch
-//          opening (13 more scalar multiplications) and the two-pair pairing check (bn254_kernels.hip)
-// The second transcript hashes the first MSM's result, so a batch makes one round trip: stage1 (host) -> MSM -> stage2 (host)
-// -> MSMs + pairing.  Nothing here is shared with oracle/: this is product code.
+//   once per key (host)   the loader, the 80 KB byte-window tables of the key's points (plonk_table_point), the transcript prefix
+//   per proof, DEVICE     everything: parsing, the Fiat-Shamir transcripts (SHA-256), BSB22 hash-to-field, the Fr arithmetic of the linearisation and the GLV
+//                         decomposition (PlonkStage1 / PlonkStage2 below, one proof per lane in csrc/bn254_k_plonk.hip), then every group operation: the two
+//                         multi-scalar multiplications as rows (bn254_msm.h, k_g1_msm_rows) and the two-pair pairing check (bn254_kernels.hip / bn254_coop12.hip)
+// The same stage code compiles for the host: the library runs it there only under BN254_PLONK_HOST=1 (a debugging aid) and the sanitizer harness of
+// tests/hostsan does.  The second transcript hashes the first MSM's result, so a pass is stage 1 -> MSM -> stage 2 -> MSM -> pairing, all on one stream.
+// Nothing here is shared with oracle/: this is product code.
 #pragma once
 #include <cstring>
 #include <string>

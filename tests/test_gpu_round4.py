@@ -143,7 +143,7 @@ def test_plonk_other_key_shapes_vs_oracle(pkg, O, fixtures):
         for total in (1, 257, 5041):
             reps = -(-total // len(cases))
             sel = (cases * reps)[:total]
-            pb = b"".join(p.ljust(stride, b"\\0") for p, _ in sel)
+            pb = b"".join(p.ljust(stride, b"\0") for p, _ in sel)
             ib = b"".join(b"".join(be(x) for x in ins) for _, ins in sel)
             st = pvk.verify_batch(pb, ib, total, proof_stride=stride, n_public=npub)
             assert st == (want * reps)[:total], (n_qcp, nb_public, total)
@@ -162,7 +162,7 @@ def test_plonk_large_proof_stride_lds(pkg, O, fixtures):
     exp = bytes(O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) for c in cases)
     pvk = pkg.PreparedPlonkVk(vk)
     for stride in (1700, 1664, 905):
-        pb = b"".join(c[0].ljust(stride, b"\\xa5") for c in cases) * 9
+        pb = b"".join(c[0].ljust(stride, b"\xa5") for c in cases) * 9
         ib = b"".join(c[1] for c in cases) * 9
         assert pvk.verify_batch(pb, ib, 9 * len(cases), proof_stride=stride) == exp * 9, stride
     pvk.close()

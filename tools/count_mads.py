@@ -351,10 +351,14 @@ def coop12_kernel(funcs, frag, kind, callees, ops, n_pairs=2):
     ranges = [(lo, hi, steps)]
     notes = []
     if kind == "g16":
-        assert len(latches) == 2 and len(conds) == 2, ("k_coop12_miller_g16: layout changed", latches, conds)
-        (s_lo, s_hi, s_m), (a_lo, a_hi, a_m) = conds
-        d_lo, d_hi = latches[0] + 1, latches[1]
-        d_m = count_in(mads, d_lo, d_hi)
+        # two layouts of the same loop: the doubling rounds as the fall-through between two latches, or as a third forward-branched block
+        assert (len(latches), len(conds)) in ((2, 2), (1, 3)), ("k_coop12_miller_g16: layout changed", latches, conds)
+        if len(conds) == 2:
+            (s_lo, s_hi, s_m), (a_lo, a_hi, a_m) = conds
+            d_lo, d_hi = latches[0] + 1, latches[1]
+            d_m = count_in(mads, d_lo, d_hi)
+        else:
+            (s_lo, s_hi, s_m), (a_lo, a_hi, a_m), (d_lo, d_hi, d_m) = conds
         assert 700 <= s_m <= 800 and 950 <= a_m <= 1000 and 800 <= d_m <= 900, (s_m, a_m, d_m)
         ranges += [(s_lo, s_hi, 64.0 / steps), (a_lo, a_hi, 23.0 / steps), (d_lo, d_hi, 65.0 / steps)]
         notes.append("Miller loop x88: squaring of f (%d multiply-adds) x64, G2 addition rounds (%d) x23, G2 doubling rounds (%d) x65, three line products (%d) x88"

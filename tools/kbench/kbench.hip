@@ -222,6 +222,73 @@ __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
   c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
   sth(ws, e_dst, 0, c0); sth(ws, e_dst, 1, c1);
 }
+#elif defined(V_MUL_STREAM)
+// the STREAMING SCHOOLBOOK form of the general Fp12 product.  a is loaded once and stays in registers (108); for every output coefficient
+// r_j = sum_t (xi if t > j) a_t b_((j - t) mod 6) the six coefficients of b are read again (from the caches: 6 x 432 B per lane) and the six Fp2 products are ONE sum
+// of products (two 12-term fp_dot: 24 x 81 + 2 x 81 = 2106 multiply-adds per coefficient, 12.6 k per product against 8.3 k of the Karatsuba form); no Fp6-sized
+// temporary goes through the workspace: operands read once from HBM (864 B) + result (432 B) = 1296 B against the 2451 B the counters show for k_f12_mul.
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 24;
+  const Fp2 a0 = ld2(ws, e_a), a1 = ld2(ws, e_a + 2), a2 = ld2(ws, e_a + 4), a3 = ld2(ws, e_a + 6), a4 = ld2(ws, e_a + 8), a5 = ld2(ws, e_a + 10);
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    // b_((j - t) mod 6) for t = 0..5, xi-multiplied where t > j
+    Fp2 b0 = ld2(ws, e_b + 2 * ((j + 6 - 0) % 6)), b1 = ld2(ws, e_b + 2 * ((j + 6 - 1) % 6)), b2 = ld2(ws, e_b + 2 * ((j + 6 - 2) % 6));
+    Fp2 b3 = ld2(ws, e_b + 2 * ((j + 6 - 3) % 6)), b4 = ld2(ws, e_b + 2 * ((j + 6 - 4) % 6)), b5 = ld2(ws, e_b + 2 * ((j + 6 - 5) % 6));
+    if (1 > j) b1 = fp2_mul_xi(b1);
+    if (2 > j) b2 = fp2_mul_xi(b2);
+    if (3 > j) b3 = fp2_mul_xi(b3);
+    if (4 > j) b4 = fp2_mul_xi(b4);
+    if (5 > j) b5 = fp2_mul_xi(b5);
+    st2(ws, e_dst + 2 * j, fp2_dotp(pp(a0, b0), pp(a1, b1), pp(a2, b2), pp(a3, b3), pp(a4, b4), pp(a5, b5)));
+    BN_SCHED_FENCE();
+  }
+}
+#elif defined(V_MUL_STREAM2)
+// ... the same with every output coefficient as TWO sums of three products (the twelve-term form keeps 216 operand registers live and spills 1252 bytes per lane):
+// a (108 registers) + three coefficients of b at a time; one more reduction per coefficient (13.6 k multiply-adds per product)
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 24;
+  const Fp2 a0 = ld2(ws, e_a), a1 = ld2(ws, e_a + 2), a2 = ld2(ws, e_a + 4), a3 = ld2(ws, e_a + 6), a4 = ld2(ws, e_a + 8), a5 = ld2(ws, e_a + 10);
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    Fp2 lo;
+    {
+      Fp2 b0 = ld2(ws, e_b + 2 * ((j + 6 - 0) % 6)), b1 = ld2(ws, e_b + 2 * ((j + 6 - 1) % 6)), b2 = ld2(ws, e_b + 2 * ((j + 6 - 2) % 6));
+      if (1 > j) b1 = fp2_mul_xi(b1);
+      if (2 > j) b2 = fp2_mul_xi(b2);
+      lo = fp2_dotp(pp(a0, b0), pp(a1, b1), pp(a2, b2));
+    }
+    BN_SCHED_FENCE();
+    {
+      Fp2 b3 = ld2(ws, e_b + 2 * ((j + 6 - 3) % 6)), b4 = ld2(ws, e_b + 2 * ((j + 6 - 4) % 6)), b5 = ld2(ws, e_b + 2 * ((j + 6 - 5) % 6));
+      if (3 > j) b3 = fp2_mul_xi(b3);
+      if (4 > j) b4 = fp2_mul_xi(b4);
+      if (5 > j) b5 = fp2_mul_xi(b5);
+      st2(ws, e_dst + 2 * j, fp2_add(lo, fp2_dotp(pp(a3, b3), pp(a4, b4), pp(a5, b5))));
+    }
+    BN_SCHED_FENCE();
+  }
+}
+#elif defined(V_MUL_STREAM3)
+// ... and as THREE sums of two products (a + two coefficients of b at a time; 14.6 k multiply-adds per product)
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 24;
+  const Fp2 a0 = ld2(ws, e_a), a1 = ld2(ws, e_a + 2), a2 = ld2(ws, e_a + 4), a3 = ld2(ws, e_a + 6), a4 = ld2(ws, e_a + 8), a5 = ld2(ws, e_a + 10);
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    Fp2 acc;
+    { Fp2 b0 = ld2(ws, e_b + 2 * ((j + 6 - 0) % 6)), b1 = ld2(ws, e_b + 2 * ((j + 6 - 1) % 6)); if (1 > j) b1 = fp2_mul_xi(b1); acc = fp2_dotp(pp(a0, b0), pp(a1, b1)); }
+    BN_SCHED_FENCE();
+    { Fp2 b2 = ld2(ws, e_b + 2 * ((j + 6 - 2) % 6)), b3 = ld2(ws, e_b + 2 * ((j + 6 - 3) % 6)); if (2 > j) b2 = fp2_mul_xi(b2); if (3 > j) b3 = fp2_mul_xi(b3); acc = fp2_add(acc, fp2_dotp(pp(a2, b2), pp(a3, b3))); }
+    BN_SCHED_FENCE();
+    { Fp2 b4 = ld2(ws, e_b + 2 * ((j + 6 - 4) % 6)), b5 = ld2(ws, e_b + 2 * ((j + 6 - 5) % 6)); if (4 > j) b4 = fp2_mul_xi(b4); if (5 > j) b5 = fp2_mul_xi(b5); st2(ws, e_dst + 2 * j, fp2_add(acc, fp2_dotp(pp(a4, b4), pp(a5, b5)))); }
+    BN_SCHED_FENCE();
+  }
+}
 #elif defined(V_COPY)
 __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
   WS_SETUP

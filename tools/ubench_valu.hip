@@ -14,10 +14,11 @@ constexpr int ITERS = 32768;     // loop trips
 constexpr int UNROLL = 16;      // instructions per trip per chain-set
 
 enum Op { MAD64 = 0, MUL_LO, MUL_HI, MAD_U24, MUL_U24, MULHI_U24, ADD_U32, ADDC_PAIR, FMA_F64, LSHL_ADD_U64,
-          MAD64_DEP, MIX_MAD_ADD2, MIX_MAD_ADD4, FMA_F32, MAD64_4CHAIN, NOPS };
+          MAD64_DEP, MIX_MAD_ADD2, MIX_MAD_ADD4, FMA_F32, MAD64_4CHAIN, EMMART_LIMB, ADD_F64, NOPS };
 static const char* op_name[] = { "v_mad_u64_u32 (16 indep)", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_u32_u24",
   "v_mul_hi_u32_u24", "v_add_u32", "v_add_co+v_addc pair", "v_fma_f64", "v_lshl_add_u64", "v_mad_u64_u32 (1 dep chain)",
-  "mix 1 mad64 + 2 add", "mix 1 mad64 + 4 add", "v_fma_f32", "v_mad_u64_u32 (4 chains)" };
+  "mix 1 mad64 + 2 add", "mix 1 mad64 + 4 add", "v_fma_f32", "v_mad_u64_u32 (4 chains)",
+  "52x52 limb product on FMAs (2 fma + f64 sub + 2 u64 add)", "v_add_f64" };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed, unsigned long long* cyc) {
@@ -49,6 +50,17 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed, unsigned 
       else if constexpr (OP == FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(da), "v"(db));
       else if constexpr (OP == FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(fa), "v"(fb));
       else if constexpr (OP == LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[i]) : "v"(acc[(i + 1) & 15]));
+      else if constexpr (OP == ADD_F64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(db));
+      else if constexpr (OP == EMMART_LIMB) {
+        // one 52 x 52 -> 104-bit limb product in double precision (Emmart, Zheng, Weems 2018): hi = fma(a, b, C1) rounds to a multiple of 2^52, sub = C2 - hi,
+        // lo = fma(a, b, sub) is the exact low part; the two halves are then accumulated into their columns as 64-bit integers (the magic constants align the
+        // mantissas).  Five instructions per limb product; a 5 x 5 limb Montgomery product needs 2 x 25 of them.
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d[i]) : "v"(da), "v"(d[(i + 1) & 15]), "v"(db));
+        asm volatile("v_add_f64 %0, %1, -%2" : "=v"(d[(i + 2) & 15]) : "v"(db), "v"(d[i]));
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d[(i + 3) & 15]) : "v"(da), "v"(d[(i + 1) & 15]), "v"(d[(i + 2) & 15]));
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[i]) : "v"(d[i]));
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[(i + 8) & 15]) : "v"(d[(i + 3) & 15]));
+      }
       else if constexpr (OP == MIX_MAD_ADD2) {
         asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
         asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
@@ -82,7 +94,7 @@ template <int OP> void run(int waves_per_simd, uint32_t* dout, unsigned long lon
   }
   std::vector<unsigned long long> cyc(grid); CK(hipMemcpy(cyc.data(), dcyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   double med = 0; { std::vector<unsigned long long> c = cyc; std::sort(c.begin(), c.end()); med = (double)c[c.size() / 2]; }
-  int per_it = (OP == MIX_MAD_ADD2) ? 3 : (OP == MIX_MAD_ADD4) ? 5 : 1;
+  int per_it = (OP == MIX_MAD_ADD2) ? 3 : (OP == MIX_MAD_ADD4 || OP == EMMART_LIMB) ? 5 : 1;
   double winstr = (double)ITERS * UNROLL * per_it;              // wave-instructions per wave
   double total = winstr * grid * 4;                              // over all waves
   // s_memtime ticks at a fixed 100 MHz-derived rate on some parts; report both wall-derived and tick-derived
@@ -104,6 +116,7 @@ int main() {
     run<ADD_U32>(w, dout, dcyc, ncu); run<ADDC_PAIR>(w, dout, dcyc, ncu); run<FMA_F32>(w, dout, dcyc, ncu);
     run<FMA_F64>(w, dout, dcyc, ncu); run<LSHL_ADD_U64>(w, dout, dcyc, ncu);
     run<MIX_MAD_ADD2>(w, dout, dcyc, ncu); run<MIX_MAD_ADD4>(w, dout, dcyc, ncu);
+    run<ADD_F64>(w, dout, dcyc, ncu); run<EMMART_LIMB>(w, dout, dcyc, ncu);
     printf("\n");
   }
   return 0;
