@@ -15,7 +15,9 @@ def main():
     args = ap.parse_args()
     import bench
     pkg = importlib.import_module("snark-bn254-verifier_amd")
-    r = bench.plonk_config(pkg, args.batch, args.steps, args.warmup, args.cpu_sample)
+    bench.plonk_config(pkg, args.batch, 2, 1, 0, in_flight=False)      # warms the GPU: the peak probe reads low on idle clocks
+    bench.measure_valu_peak(pkg)
+    r = bench.plonk_config(pkg, args.batch, args.steps, args.warmup, args.cpu_sample, in_flight=args.batch <= 8192)
     r.update({"metric": "PlonK verifies/sec at batch=%d (host buffers in, status bytes out)" % args.batch, "n_gpus": 1, "warmup": args.warmup,
               "higher_is_better": True, "dtype": "int64", "data": "reference fixtures + mutations", "config": {"workload": r["workload"]}})
     print(json.dumps(r))
