@@ -291,6 +291,9 @@ int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget,
 /* host-only probe of the modular inversion of the PlonK stages (which = 0: the constant-time form the stages use, 1: the Fermat form, 2: the classic
  * shift-and-subtract binary GCD; field 0: Fr, 1: Fp); 32-byte big-endian in / out */
 int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, int field);
+/* host-only probe of the two Montgomery product forms of the PlonK stages (form 32: 8 x 32-bit words, what the device runs; 64: 4 x 64-bit limbs, what the host
+ * runs): n products of 32-byte big-endian values (reduced first), out = canonical big-endian a * b mod m (field 0: Fr, 1: Fp) */
+int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int form, int field);
 
 /* host-only probe of the comb tables used for keys with many public inputs (csrc/bn254_host.hpp::build_comb_table): x * P computed from P's table
  * and the column digits of the 256-bit big-endian x, as the kernels do; out64 = uncompressed point, all zero for the identity */

@@ -1729,6 +1729,18 @@ int bn254_dbg_fr_inverse(const uint8_t in32[32], uint8_t out32[32], int which, i
   F.to_be(out32, which == 1 ? F.inverse_fermat(a) : which == 2 ? F.inverse_bgcd(a) : F.inverse(a));
   return BN254_OK;
 }
+// n products a_i * b_i in the field (operands: any 256-bit values, reduced and converted to Montgomery form first), through the
+// product form the DEVICE stages use (form 32: eight 32-bit words) or the host's (form 64: four 64-bit limbs on __int128); out = canonical big-endian
+int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int form, int field) {
+  if ((!a || !b || !out) && n) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (form != 32 && form != 64) return set_err(BN254_E_BAD_ARG, "form is 32 or 64");
+  const FrCtx& F = field ? fp64_ctx().F : fr_ctx();
+  for (size_t i = 0; i < n; i++) {
+    const FrM x = F.from_be_reduce(a + 32 * i, 32), y = F.from_be_reduce(b + 32 * i, 32);
+    F.to_be(out + 32 * i, form == 32 ? F.mul_w32(x, y) : F.mul_w64(x, y));
+  }
+  return BN254_OK;
+}
 
 // host-only probe of the comb tables of keys with many public inputs: x * P from build_comb_table(P) and the column digits the kernels use
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]) {

@@ -265,6 +265,34 @@ def test_fr_inverse_binary_gcd(pkg):
             assert int.from_bytes(bytes(o1), "big") == want == int.from_bytes(bytes(o2), "big") == int.from_bytes(bytes(o3), "big"), (field, hex(v))
 
 
+def test_fr_product_forms_agree(pkg):
+    """The 8 x 32-bit-word Montgomery product the device stages run and the 4 x 64-bit one of the host, in Fr and in Fp, against Python integers: 20 000 random pairs
+    and every pair of edge values (0, 1, m - 1, m, 2^256 - 1, words of all ones / a single bit) -- the two forms must be the same function."""
+    import random
+    L = pkg.lib()
+    L.bn254_dbg_fr_mul.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int]
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    rng = random.Random(77)
+    for field, mod in ((0, R), (1, P)):
+        edge = [0, 1, 2, mod - 1, mod, mod + 1, (1 << 256) - 1, 1 << 255, (1 << 32) - 1, 1 << 32, (1 << 64) - 1, 1 << 64, (1 << 224) - 1, 0xffffffff << 96,
+                sum(0xffffffff << (64 * i) for i in range(4)), sum(0xffffffff << (64 * i + 32) for i in range(4))] + [1 << (32 * k) for k in range(8)] + [(1 << (32 * k)) - 1 for k in range(1, 8)]
+        pairs = [(x, y) for x in edge for y in edge] + [(rng.randrange(1 << 256), rng.randrange(1 << 256)) for _ in range(20000)]
+        a = b"".join(x.to_bytes(32, "big") for x, _ in pairs)
+        b = b"".join(y.to_bytes(32, "big") for _, y in pairs)
+        outs = []
+        for form in (32, 64):
+            o = (C.c_uint8 * (32 * len(pairs)))()
+            assert L.bn254_dbg_fr_mul(a, b, o, len(pairs), form, field) == 0
+            outs.append(bytes(o))
+        assert outs[0] == outs[1], "the two product forms differ (field %d)" % field
+        # value check (the probe converts to Montgomery form, multiplies in the form under test and converts back)
+        for i in list(range(len(edge) ** 2)) + list(range(len(pairs) - 300, len(pairs))):
+            x, y = pairs[i]
+            got = int.from_bytes(outs[0][32 * i:32 * i + 32], "big")
+            assert got == (x % mod) * (y % mod) % mod, (field, hex(x), hex(y))
+
+
 def test_plonk_plan(pkg):
     """The PlonK batch plan (sub-batches side by side, balanced passes of at most `piece` proofs) covers the batch exactly.  (The sizing of the window-table scratch
     against every launch a context can see -- the round-3 heap overflow -- is tests/test_msm_rows.py::test_plonk_context_scratch_holds_every_launch.)"""
