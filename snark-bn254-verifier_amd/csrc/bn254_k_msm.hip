@@ -79,29 +79,43 @@ k_g1_msm_rows(MsmPlan plan_arg, const int32_t* __restrict__ terms, const uint8_t
 // per item: the sum of rows [first, first + count) of `part`, to affine.  out_words != nullptr: 16 little-endian words (x | y, canonical) and a flag byte
 // (1 = identity) per item.  Otherwise the point goes to workspace elements (e_x, e_x + 1) as (x, y) or (0, 1) for the identity, whose flag bit `inf_bit`
 // is OR-ed into the (pending) status byte.  count_b > 0: TWO sums per item in one launch (PlonK: P0 and P1 of the KZG check): the lanes from
-// round_up(n, 64) on form the second one (a wavefront never mixes the two) -- the launch lasts as long as one lane's chain, whatever the number of sums.
+// round_up(n, 64) items on form the second one (a wavefront never mixes the two) -- the launch lasts as long as one lane's chain, whatever the number of sums.
+// lpi_log2 = 2: FOUR lanes per item and sum (small batches, where the launch is one lane's chain of additions): lane q of a quad adds rows q, q + 4, ...,
+// two butterfly steps over the quad (27 dwords each way through the cross-lane network) leave the total in every lane, lane 0 writes: 14 rows are 4 + 2
+// additions deep instead of 14.
+__device__ __forceinline__ G1Proj g1_shfl_xor(const G1Proj& p, int mask) {
+  G1Proj r;
+#pragma unroll
+  for (int l = 0; l < BN_NL; l++) { r.x.v[l] = __shfl_xor(p.x.v[l], mask); r.y.v[l] = __shfl_xor(p.y.v[l], mask); r.z.v[l] = __shfl_xor(p.z.v[l], mask); }
+  BN_SETB(r.x, BN_VB(p.x), BN_LBD(p.x)); BN_SETB(r.y, BN_VB(p.y), BN_LBD(p.y)); BN_SETB(r.z, BN_VB(p.z), BN_LBD(p.z));
+  return r;
+}
 __global__ void __launch_bounds__(256, 2)
 k_g1_sum_affine(const int32_t* __restrict__ part, int first, int count, uint32_t n, uint32_t* __restrict__ out_words, uint8_t* __restrict__ out_inf, int32_t* ws,
-                uint8_t* __restrict__ status, int e_x, int inf_bit, int first_b, int count_b, int e_x_b, int inf_bit_b) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+                uint8_t* __restrict__ status, int e_x, int inf_bit, int first_b, int count_b, int e_x_b, int inf_bit_b, int lpi_log2) {
+  const uint32_t gl = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t g = gl >> lpi_log2;                       // item-lane
+  const int q = (int)(gl & ((1u << lpi_log2) - 1u)), lpi = 1 << lpi_log2;
   const uint32_t n_pad = (n + 63u) & ~63u;
-  const bool second_sum = count_b > 0 && g >= n_pad;
+  const bool second_sum = count_b > 0 && g >= n_pad;       // n_pad << lpi_log2 is a multiple of 64: uniform over a wavefront
   const uint32_t i = second_sum ? g - n_pad : (g < n ? g : 0xffffffffu);
   if (second_sum) { first = first_b; count = count_b; e_x = e_x_b; inf_bit = inf_bit_b; }
   const uint32_t ii = i < n ? i : n - 1;
   G1Proj L = g1_identity();
-  for (int cc = 0; cc < count; cc++) {
+  for (int cc = q; cc < count; cc += lpi) {
     const int32_t* o = part + (size_t)(first + cc) * 27 * n + ii;
-    G1Proj q;
+    G1Proj t;
 #pragma unroll
-    for (int l = 0; l < BN_NL; l++) { q.x.v[l] = o[(size_t)l * n]; q.y.v[l] = o[(size_t)(9 + l) * n]; q.z.v[l] = o[(size_t)(18 + l) * n]; }
-    BN_SETB(q.x, 3.0, 0.5); BN_SETB(q.y, 3.0, 0.5); BN_SETB(q.z, 3.0, 0.5);
-    L = g1_add(L, q);
+    for (int l = 0; l < BN_NL; l++) { t.x.v[l] = o[(size_t)l * n]; t.y.v[l] = o[(size_t)(9 + l) * n]; t.z.v[l] = o[(size_t)(18 + l) * n]; }
+    BN_SETB(t.x, 3.0, 0.5); BN_SETB(t.y, 3.0, 0.5); BN_SETB(t.z, 3.0, 0.5);
+    L = g1_add(L, t);
   }
+  for (int m = 1; m < lpi; m <<= 1) L = g1_add(L, g1_shfl_xor(L, m));
   bool l_inf = g1_is_identity(L);
   G1Aff La = g1_to_affine(L);
+  const bool writer = i < n && q == 0;
   if (out_words) {
-    if (i < n) {
+    if (writer) {
       uint32_t wx[8], wy[8];
       fp_to_words(wx, La.x); fp_to_words(wy, La.y);
 #pragma unroll
@@ -109,11 +123,11 @@ k_g1_sum_affine(const int32_t* __restrict__ part, int first, int count, uint32_t
       out_inf[i] = l_inf ? 1 : 0;
     }
   } else {
-    DevWs w(ws, n, i < n ? i : DEAD_LANE);
+    DevWs w(ws, n, writer ? i : DEAD_LANE);
     La.y = fp_select(l_inf, fp_one(), La.y);
     w.st(e_x, La.x); w.st(e_x + 1, La.y);
     // the two sums of an item may both flag their point: different bits of the same status byte -> an atomic OR
-    if (i < n && l_inf) { if (status[i] & BN254_ST_PENDING) atomicOr((unsigned int*)(status + (i & ~3u)), (unsigned int)inf_bit << (8 * (i & 3u))); }
+    if (writer && l_inf) { if (status[i] & BN254_ST_PENDING) atomicOr((unsigned int*)(status + (i & ~3u)), (unsigned int)inf_bit << (8 * (i & 3u))); }
   }
 }
 
@@ -134,8 +148,10 @@ hipError_t bn254_launch_g1_msm_rows(const MsmPlan& plan, const int32_t* terms, c
 hipError_t bn254_launch_g1_sum_rows(const MsmPlan& plan, const int32_t* part, size_t n, uint32_t* out_words, uint8_t* out_inf, int32_t* ws, uint8_t* status, int e_x, int inf_bit,
                                     int e_x_b, int inf_bit_b, hipStream_t s) {
   const bool two = plan.count[1] > 0;
-  const size_t lanes = two ? ((n + 63) & ~(size_t)63) + n : n;
+  // four lanes per item while the launch stays within one wavefront per SIMD (there it lasts as long as one lane's chain of additions); one lane per item beyond
+  const int lpi_log2 = ((two ? 2 : 1) * n * 4 <= 65536 && plan.count[0] >= 4) ? 2 : 0;
+  const size_t lanes = (two ? ((n + 63) & ~(size_t)63) + n : n) << lpi_log2;
   hipLaunchKernelGGL(k_g1_sum_affine, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, part, plan.first[0], plan.count[0], (uint32_t)n, out_words, out_inf, ws, status, e_x,
-                     inf_bit, plan.first[1], two ? plan.count[1] : 0, e_x_b, inf_bit_b);
+                     inf_bit, plan.first[1], two ? plan.count[1] : 0, e_x_b, inf_bit_b, lpi_log2);
   return hipGetLastError();
 }

@@ -36,6 +36,7 @@ __device__ __forceinline__ const uint8_t* pl_stage_lds(const uint8_t* __restrict
   const size_t ibytes = n_public * 32 <= PL_STAGE_MAX_INPUT ? n_public * 32 : 0;
   const uint32_t first = blockIdx.x * 64u;
   const bool aligned = (((uintptr_t)proofs | stride | (uintptr_t)inputs) & 3) == 0;
+  const size_t nt = blockDim.x;             // 64 (k_plonk_stage2) or 128 (k_plonk_stage1: chain + helper wavefront, the same 64 proofs)
   for (uint32_t j = 0; j < 64; j++) {
     const uint32_t rec = first + j;
     if (rec >= n) break;
@@ -43,16 +44,17 @@ __device__ __forceinline__ const uint8_t* pl_stage_lds(const uint8_t* __restrict
     const uint8_t* src = proofs + (size_t)rec * stride;
     const uint8_t* isrc = inputs + (size_t)rec * n_public * 32;
     if (aligned) {
-      for (size_t off = 4 * (size_t)threadIdx.x; off < pbytes; off += 256) *(uint32_t*)(dst + off) = *(const uint32_t*)(src + off);
-      for (size_t off = 4 * (size_t)threadIdx.x; off < ibytes; off += 256) *(uint32_t*)(dst + ((pbytes + 3) & ~(size_t)3) + off) = *(const uint32_t*)(isrc + off);
+      for (size_t off = 4 * (size_t)threadIdx.x; off < pbytes; off += 4 * nt) *(uint32_t*)(dst + off) = *(const uint32_t*)(src + off);
+      for (size_t off = 4 * (size_t)threadIdx.x; off < ibytes; off += 4 * nt) *(uint32_t*)(dst + ((pbytes + 3) & ~(size_t)3) + off) = *(const uint32_t*)(isrc + off);
     } else {
-      for (size_t off = threadIdx.x; off < pbytes; off += 64) dst[off] = src[off];
-      for (size_t off = threadIdx.x; off < ibytes; off += 64) dst[((pbytes + 3) & ~(size_t)3) + off] = isrc[off];
+      for (size_t off = threadIdx.x; off < pbytes; off += nt) dst[off] = src[off];
+      for (size_t off = threadIdx.x; off < ibytes; off += nt) dst[((pbytes + 3) & ~(size_t)3) + off] = isrc[off];
     }
   }
   __syncthreads();
-  const uint32_t i = first + threadIdx.x;
-  const uint8_t* mine = pl_dyn_lds + 16 + (size_t)threadIdx.x * lane_stride + 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t i = first + lane;
+  const uint8_t* mine = pl_dyn_lds + 16 + (size_t)lane * lane_stride + 64;
   *lane_inputs = ibytes ? mine + ((pbytes + 3) & ~(size_t)3) : inputs + (size_t)(i < n ? i : 0) * n_public * 32;
   return mine;
 }
@@ -64,33 +66,64 @@ static uint32_t pl_lane_stride(size_t stride, size_t n_public) {
   return (uint32_t)(dw * 4);
 }
 
-__global__ void __launch_bounds__(64) k_plonk_stage1(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs,
-                                                     size_t n_public, uint32_t n, ChaChaKey lam_key, PlonkWork* __restrict__ work, MsmTerm* __restrict__ terms,
-                                                     uint8_t* __restrict__ flags, int T1, uint32_t lane_stride) {
+// Two lanes per proof, in two wavefronts of a 128-thread workgroup (round 4).  A lane's chain was 478 us at 4096 proofs -- one wavefront per SIMD, nothing to
+// hide latency behind -- of which 172 us do not depend on the transcripts: the curve checks and digit conversions of the nine points (parse_plonk_proof), the BSB22
+// hash_to_field, lambda.  Wavefront 1 (lanes 64..127) does those for the same 64 proofs while wavefront 0 runs transcripts -> zeta^n -> denominators -> inversion
+// from the proof's bytes and its layout alone; they meet at ONE barrier (the parsed proof and the hashes travel through work[i], the status precedence is the
+// reference's: a loader error of any point beats everything the chain lane found), then wavefront 0 finishes (public-input sum, opening check, terms).
+__global__ void __launch_bounds__(128) k_plonk_stage1(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* __restrict__ inputs,
+                                                      size_t n_public, uint32_t n, ChaChaKey lam_key, PlonkWork* work, MsmTerm* terms,
+                                                      uint8_t* flags, int T1, uint32_t lane_stride) {
   const uint8_t* my_inputs;
   const uint8_t* my_proof = pl_stage_lds(proofs, stride, inputs, n_public, n, lane_stride, &my_inputs);
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  if (i >= n) return;
+  const bool helper = threadIdx.x >= 64u;
+  const uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u);
+  const bool live = i < n;                      // no early return: every lane reaches the barrier
   const FrCtx& F = fr_ctx();
-  PlonkWork& wk = work[i];
+  PlonkWork& wk = work[live ? i : 0];
+  MsmTerm* t = terms + (size_t)(live ? i : 0) * T1;
+  uint8_t* fl = flags + (size_t)(live ? i : 0) * T1;
+  PlonkStage1 s;
+  FrM acc_inv = {{0, 0, 0, 0}};
+  int st_chain = PL_MALFORMED;
   PL_MARK(0);
 #if defined(BN254_PLONK_MARKS)
   if (blockIdx.x == 0 && threadIdx.x == 0) g_plonk_sha_n = 0;
 #endif
-  {
-    // the KZG batching scalar: 384 bits of the call's ChaCha20 stream (blocks 3i .. 3i+2) reduced mod r, as the host path draws it
-    uint32_t lw[12];
-    for (int j = 0; j < 3; j++) chacha20_block4(lw + 4 * j, lam_key, 3u * i + (uint32_t)j);
-    uint8_t lb[48];
-    for (int j = 0; j < 12; j++) { lb[4 * j] = (uint8_t)lw[j]; lb[4 * j + 1] = (uint8_t)(lw[j] >> 8); lb[4 * j + 2] = (uint8_t)(lw[j] >> 16); lb[4 * j + 3] = (uint8_t)(lw[j] >> 24); }
-    wk.lambda = F.from_be_reduce(lb, 48);
+  if (helper) {
+    if (live) {
+      PL_MARK_H(20);
+      {
+        // the KZG batching scalar: 384 bits of the call's ChaCha20 stream (blocks 3i .. 3i+2) reduced mod r, as the host path draws it
+        uint32_t lw[12];
+        for (int j = 0; j < 3; j++) chacha20_block4(lw + 4 * j, lam_key, 3u * i + (uint32_t)j);
+        uint8_t lb[48];
+        for (int j = 0; j < 12; j++) { lb[4 * j] = (uint8_t)lw[j]; lb[4 * j + 1] = (uint8_t)(lw[j] >> 8); lb[4 * j + 2] = (uint8_t)(lw[j] >> 16); lb[4 * j + 3] = (uint8_t)(lw[j] >> 24); }
+        wk.lambda = F.from_be_reduce(lb, 48);
+      }
+      for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
+      PL_MARK_H(21);
+      const int st = parse_plonk_proof(wk.pr, my_proof, stride);                    // lib.rs:70
+      PL_MARK_H(22);
+      if (st == PL_OK) for (uint32_t k = 0; k < wk.pr.n_bsb; k++) wk.h2f[k] = bsb22_hash_to_field(my_proof + wk.pr.off_bsb + 64 * (size_t)k);
+      wk.parse_status = st;
+      PL_MARK_H(23);
+    }
+  } else if (live) {
+    PlonkLayout lay;
+    if (plonk_proof_layout(lay, my_proof, stride)) {
+      st_chain = PlonkStage1::counts(*key, lay.n_bsb, lay.n_claimed, n_public);
+      if (st_chain == PL_OK) st_chain = s.chain(*key, my_proof, my_inputs, n_public, wk, lay.off_bsb, lay.n_bsb);
+      if (st_chain == PL_OK) acc_inv = F.inverse(s.acc);
+    }
+    PL_MARK(13);
   }
-  MsmTerm* t = terms + (size_t)i * T1;
-  uint8_t* fl = flags + (size_t)i * T1;
-  for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
-  PlonkStage1 s;
-  int st = s.a(*key, my_proof, stride, my_inputs, n_public, wk);
-  if (st == PL_OK) st = s.b(F.inverse(s.acc), t, fl);
+  __syncthreads();
+  if (helper || !live) return;
+  PL_MARK(12);
+  int st = wk.parse_status;                     // a malformed layout fails the parser too, with that or an earlier point error
+  if (st == PL_OK) st = st_chain;
+  if (st == PL_OK) st = s.b(acc_inv, t, fl, wk.h2f);
   PL_MARK(11);
   if (st != PL_OK) for (int k = 0; k < T1; k++) { for (int q = 0; q < 18; q++) t[k].pt[q] = 0; for (int q = 0; q < 8; q++) t[k].k[q] = 0; fl[k] = 0; }
   wk.status = st;
@@ -145,8 +178,9 @@ hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs,
   for (int i = 0; i < 8; i++) key.k[i] = lam_key[i];
   for (int i = 0; i < 3; i++) key.nonce[i] = lam_key[8 + i];
   const uint32_t ls = pl_lane_stride(stride, n_public);
-  if (16 + 64 * (size_t)ls > 65536) { hipError_t ae = hipFuncSetAttribute((const void*)k_plonk_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 + 64 * (size_t)ls)); if (ae != hipSuccess) return ae; }
-  hipLaunchKernelGGL(k_plonk_stage1, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, d_inputs, n_public, (uint32_t)n, key,
+  const size_t lds = 16 + 64 * (size_t)ls + 64 * (size_t)PL_HELPER_SHA_STRIDE;     // + the SHA blocks of the helper wavefront's lanes (bn254_plonk.hpp::pl_lane_lds)
+  if (lds > 65536) { hipError_t ae = hipFuncSetAttribute((const void*)k_plonk_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ae != hipSuccess) return ae; }
+  hipLaunchKernelGGL(k_plonk_stage1, dim3((unsigned)((n + 63) / 64)), dim3(128), lds, s, (const PlonkKey*)d_key, d_proofs, stride, d_inputs, n_public, (uint32_t)n, key,
                      (PlonkWork*)d_work, (MsmTerm*)d_terms, d_flags, T1, ls);
   return hipGetLastError();
 }

@@ -38,8 +38,10 @@ __device__ unsigned long long g_plonk_marks[32];
 #endif
 #if defined(BN254_PLONK_MARKS) && defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
 #define PL_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_plonk_marks[k] = wall_clock64(); } while (0)
+#define PL_MARK_H(k) do { if (blockIdx.x == 0 && threadIdx.x == 64) g_plonk_marks[k] = wall_clock64(); } while (0)   /* first lane of the helper wavefront */
 #else
 #define PL_MARK(k) ((void)0)
+#define PL_MARK_H(k) ((void)0)
 #endif
 
 #if defined(BN254_PLONK_MARKS)
@@ -52,10 +54,11 @@ inline uint32_t g_plonk_sha_dump_host[32][24];
 inline uint32_t g_plonk_sha_n_host;
 #endif
 
+#define PL_HELPER_SHA_STRIDE 68     /* bytes: a 64-byte block + one dword, so that the helper lanes' same-offset accesses fall on different banks */
 #if defined(BN254_PLONK_DEVICE_TU) && defined(__HIP_DEVICE_COMPILE__)
 // Device side: a lane's pending SHA-256 block lives in LDS, not in its private memory (a byte buffer indexed by a run-time fill level would be
 // scratch: a vector-memory round trip per byte, with one wavefront per SIMD to hide it).  The kernels of bn254_k_plonk.hip lay their dynamic LDS out as
-//   [0] u32 lane stride in bytes | 16 + lane * stride: [0, 64) this lane's SHA block, [64, ...) its proof bytes, then its public inputs
+//   [0] u32 lane stride in bytes | 16 + lane * stride: [0, 64) this lane's SHA block, [64, ...) its proof bytes, then its public inputs | 64 SHA blocks of the helper lanes
 // and a lane hashes with ONE Sha256 object at a time (the transcripts are sequential), so the slot needs no owner.
 // The slot is addressed by its LDS offset, not through an `extern __shared__` declaration: the functions below may be compiled out of line, and
 // dynamic LDS is only nameable from the kernel itself.  The two kernels declare no static LDS, so their dynamic LDS starts at offset 0.
@@ -63,7 +66,8 @@ __device__ __forceinline__ uint8_t* pl_lane_lds() {
   typedef __attribute__((address_space(3))) uint8_t lds_u8;
   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
   const uint32_t stride = *(lds_cu32*)(uintptr_t)0;
-  lds_u8* p = (lds_u8*)(uintptr_t)(16u + threadIdx.x * stride);
+  // lanes 64..127 of a workgroup (the helper wavefront of k_plonk_stage1) hash in blocks of their own behind the 64 slots
+  lds_u8* p = threadIdx.x < 64u ? (lds_u8*)(uintptr_t)(16u + threadIdx.x * stride) : (lds_u8*)(uintptr_t)(16u + 64u * stride + (threadIdx.x - 64u) * (uint32_t)PL_HELPER_SHA_STRIDE);
   return (uint8_t*)p;
 }
 #define PL_SHA_BUF() pl_lane_lds()
@@ -634,6 +638,26 @@ PL_HD int parse_plonk_proof(PlonkProof& p, const uint8_t* b, size_t n) {
   return PL_OK;
 }
 
+// The length fields of a proof alone -- where its claimed values, its second opening and its commitments sit -- with parse_plonk_proof's bounds checks and none of its
+// point work: what the transcripts need.  false: the proof is malformed (parse_plonk_proof then fails too, with that or an earlier point error).
+struct PlonkLayout { size_t off_claimed, off_zs_h, off_bsb; uint32_t n_claimed, n_bsb; };
+PL_HD bool plonk_proof_layout(PlonkLayout& l, const uint8_t* b, size_t n) {
+  if (n < 516) return false;
+  l.n_claimed = pl_be32(b + 512);
+  if (l.n_claimed > PLONK_MAX_CLAIMED) return false;
+  size_t off = 516;
+  if (n < off + 32 * (size_t)l.n_claimed + 100) return false;
+  l.off_claimed = off;
+  off += 32 * (size_t)l.n_claimed;
+  l.off_zs_h = off;
+  l.n_bsb = pl_be32(b + off + 96);
+  if (l.n_bsb > PLONK_MAX_QCP) return false;
+  off += 100;
+  if (n < off + 64 * (size_t)l.n_bsb) return false;
+  l.off_bsb = off;
+  return true;
+}
+
 // transcript.rs:15-108: challenge = SHA-256(name | digest of the previous challenge (position > 0) | bindings in order)
 struct Challenge {
   Sha256 h;
@@ -733,6 +757,9 @@ struct PlonkWork {
   PlonkProof pr;
   FrM zeta, zu_coeff_dummy;   // (second member unused; keeps the struct trivially copyable)
   FrM lambda;
+  // k_plonk_stage1 runs a proof on two lanes of two wavefronts: what the helper lane hands to the chain lane (the parsed proof travels in `pr`)
+  int parse_status;
+  FrM h2f[PLONK_MAX_QCP];     // hash_to_field of the BSB22 commitments
 };
 enum { PLONK_STAGE1_TERMS_BASE = 10 };  // + n_bsb
 PL_HD int plonk_stage1_terms(const PlonkKey& vk) { return PLONK_STAGE1_TERMS_BASE + (int)vk.n_qcp; }
@@ -788,20 +815,32 @@ struct PlonkStage1 {
   const PlonkKey* vkp; const uint8_t* proof; const uint8_t* inputs; size_t n_inputs; PlonkWork* wkp;
   FrM alpha, beta, gamma, zeta, zeta_n, zh_zeta, acc;
   FrM den[MAXDEN], pre[MAXDEN]; bool zero[MAXDEN]; int nden; size_t n_in;
+  // a = parse + counts + chain.  The device runs the three on two lanes: parse_plonk_proof (the curve checks of the nine points) beside the chain of transcripts,
+  // which needs the proof's bytes and its layout only (bn254_k_plonk.hip::k_plonk_stage1)
   PL_HD int a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk);
-  PL_HD int b(const FrM& acc_inv, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */);
+  PL_HD static int counts(const PlonkKey& vk, uint32_t n_bsb, uint32_t n_claimed, size_t n_inputs_);
+  PL_HD int chain(const PlonkKey& vk, const uint8_t* proof_, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk, size_t off_bsb, uint32_t n_bsb);
+  // h2f: the hash_to_field values of the commitments when another lane computed them (nullptr: computed here)
+  PL_HD int b(const FrM& acc_inv, MsmTerm* terms /* plonk_stage1_terms(vk) */, uint8_t* tflags /* one per term */, const FrM* h2f = nullptr);
 };
+PL_HD int PlonkStage1::counts(const PlonkKey& vk, uint32_t n_bsb, uint32_t n_claimed, size_t n_inputs_) {
+  if (n_bsb != vk.n_qcp) return PL_BSB22;                                 // verify.rs:52-54
+  if (n_inputs_ != vk.nb_public) return PL_INPUT_LEN;                     // verify.rs:57-59 (InvalidWitness)
+  if (n_claimed != 6 + vk.n_qcp || vk.n_cci != vk.n_qcp) return PL_MALFORMED;     // index panics in the reference
+  return PL_OK;
+}
 PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof_len, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk) {
-  const FrCtx& F = fr_ctx();
-  vkp = &vk; proof = proof_; inputs = inputs_; n_inputs = n_inputs_; wkp = &wk;
   PlonkProof& pr = wk.pr;
   PL_MARK(1);
-  int st = parse_plonk_proof(pr, proof, proof_len);                       // lib.rs:70
+  int st = parse_plonk_proof(pr, proof_, proof_len);                      // lib.rs:70
   PL_MARK(2);
   if (st != PL_OK) return st;
-  if (pr.n_bsb != vk.n_qcp) return PL_BSB22;                              // verify.rs:52-54
-  if (n_inputs != vk.nb_public) return PL_INPUT_LEN;                      // verify.rs:57-59 (InvalidWitness)
-  if (pr.n_claimed != 6 + vk.n_qcp || vk.n_cci != vk.n_qcp) return PL_MALFORMED;  // index panics in the reference
+  if ((st = counts(vk, pr.n_bsb, pr.n_claimed, n_inputs_)) != PL_OK) return st;
+  return chain(vk, proof_, inputs_, n_inputs_, wk, pr.off_bsb, pr.n_bsb);
+}
+PL_HD int PlonkStage1::chain(const PlonkKey& vk, const uint8_t* proof_, const uint8_t* inputs_, size_t n_inputs_, PlonkWork& wk, size_t off_bsb, uint32_t n_bsb) {
+  const FrCtx& F = fr_ctx();
+  vkp = &vk; proof = proof_; inputs = inputs_; n_inputs = n_inputs_; wkp = &wk;
   const FrM one = F.one;
   // Fiat-Shamir (verify.rs:62-95, 319-362)
   uint8_t dg[32], db[32], da[32], dz[32];
@@ -812,7 +851,7 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   PL_MARK(3);
   Challenge cb("beta", 4, dg); beta = cb.finish(db);
   Challenge ca("alpha", 5, db);
-  ca.bind(proof + pr.off_bsb, 64 * (size_t)pr.n_bsb);
+  ca.bind(proof + off_bsb, 64 * (size_t)n_bsb);
   ca.bind(proof + 192, 64);                                               // z
   alpha = ca.finish(da);
   Challenge cz("zeta", 4, da);
@@ -846,7 +885,7 @@ PL_HD int PlonkStage1::a(const PlonkKey& vk, const uint8_t* proof_, size_t proof
   PL_DUMP(4, zeta_n); PL_DUMP(5, zh_zeta); PL_DUMP(6, acc); PL_DUMP(7, den[0]); PL_DUMP(8, den[1]); PL_DUMP(9, den[2]); PL_DUMP(10, den[3]); PL_DUMP(11, pre[3]);
   return PL_OK;
 }
-PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
+PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags, const FrM* h2f) {
   const FrCtx& F = fr_ctx();
   const PlonkKey& vk = *vkp; PlonkWork& wk = *wkp; PlonkProof& pr = wk.pr;
   const FrM one = F.one;
@@ -875,7 +914,7 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags) {
   PL_MARK(7);
   PL_DUMP(18, pi);
   for (uint64_t i = 0; i < vk.n_cci; i++) {
-    FrM hashed = bsb22_hash_to_field(proof + pr.off_bsb + 64 * i);
+    FrM hashed = h2f ? h2f[i] : bsb22_hash_to_field(proof + pr.off_bsb + 64 * i);
     FrM lag = F.mul(F.mul(F.mul(zs, vk.wpow[i]), inv[1 + n_in + i]), hashed);
     pi = F.add(pi, lag);
   }

@@ -142,12 +142,14 @@ def model_components(name, ins):
                          "%(mixed)d per fixed-base byte window / unit term; table head %(table_head)d); mads_per_proof_launch = ONE unsplit variable row (table + 64 steps); a "
                          "launch is priced from its plan" % comp}
     if name == "k_g1_sum_affine":
+        # two loops hold a complete addition each: the rows of a lane, the butterfly steps over a quad of lanes (four lanes per item for small batches)
         add = [c for h, l, c in groups if 1900 <= c <= 2050]
-        assert len(add) == 1, ("k_g1_sum_affine: loop layout changed", groups)
+        assert len(add) == 2 and abs(add[0] - add[1]) <= 2, ("k_g1_sum_affine: loop layout changed", groups)
         e = model_kernel("k_g1_sum_affine_inv", ins)      # the inversion's rounds
-        base = e["mads_per_proof_launch"] - add[0]
+        base = e["mads_per_proof_launch"] - add[0] - add[1]
         return {"static_mads": len(mads), "components": {"add": add[0], "tail": base}, "mads_per_proof_launch": float(base + 14 * add[0]), "unmodelled": [],
-                "model": "sum of a plan's rows: complete addition %d per row + %d (to affine: binary-GCD inversion, two products); mads_per_proof_launch = 14 rows" % (add[0], base)}
+                "model": "sum of a plan's rows: complete addition %d per row + %d (to affine: binary-GCD inversion, two products); mads_per_proof_launch = 14 rows on one lane (with four lanes per item "
+                         "each lane adds a quarter of the rows + two butterfly steps and all four run the tail: the algorithmic count is what is reported)" % (add[0], base)}
     if name == "k_miller_run_fixed2":
         assert len(groups) == 1, ("k_miller_run_fixed2: one step loop expected", groups)
         h, l, c = groups[0]
