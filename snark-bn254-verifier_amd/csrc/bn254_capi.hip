@@ -1211,7 +1211,9 @@ size_t bn254_plonk_vk_num_public(const bn254_plonk_pvk* pvk) { return pvk ? (siz
 static int plonk_msm(const PlonkDev* d, PlonkCtx& c, const MsmShape& shape, size_t m, int n_terms, bool to_words, size_t* lanes_out, hipEvent_t ev_rows) {
   MsmPlan plan;
   const size_t m_pad = (m + 63) & ~(size_t)63;
-  if (!msm_plan_build(plan, shape, m_pad, msm_lane_budget())) return set_err(BN254_E_BAD_ARG, "PlonK key shape needs more MSM rows than the launch supports");
+  // BN254_MSM_SPLIT_AT (experiments): the bit position at which the variable terms' low and high rows meet, instead of the planner's choice
+  static const int force_a = [] { const char* e = getenv("BN254_MSM_SPLIT_AT"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 126 && !(v & 1)) ? v : 0; }();
+  if (!msm_plan_build(plan, shape, m_pad, msm_lane_budget(), force_a)) return set_err(BN254_E_BAD_ARG, "PlonK key shape needs more MSM rows than the launch supports");
   if (m > c.cap || bn254_g1_msm_scratch_lanes(plan, m) > c.glv_lanes || (size_t)plan.n_rows > (size_t)MSM_MAX_ROWS)
     return set_err(BN254_E_HIP, "PlonK context smaller than the launch (internal sizing error)");
   hipError_t e = bn254_launch_g1_msm_rows(plan, (const int32_t*)c.terms, c.flags, m, n_terms, c.part, c.glv_tab, d->fixed_tabs, c.stream);

@@ -44,19 +44,49 @@ struct MsmShape {
   int n_var[2], n_unit[2], n_fixed[2];
   int8_t var_term[2][MSM_MAX_FIXED], unit_term[2][4], fixed_term[2][MSM_MAX_FIXED], fixed_tab[2][MSM_MAX_FIXED];
 };
-// cost model of the planner, in field multiplications of one lane: a two-bit step (2 doublings + 1 addition), a doubling, a mixed addition, the table
-#define MSM_COST_STEP 30
-#define MSM_COST_DBL 8
-#define MSM_COST_MIXED 11
-#define MSM_COST_TABLE 150
+// cost model of the planner: multiply-adds of one lane per loop body of k_g1_msm_rows as counted in the gfx950 code object (tools/count_mads.py `components`): a two-bit
+// step (2 doublings + 1 addition from the lane's table), a doubling, a complete mixed addition (fixed-base byte window / unit term), the lane's 15-entry table
+#define MSM_COST_STEP 4461
+#define MSM_COST_DBL 1243
+#define MSM_COST_MIXED 1815
+#define MSM_COST_TABLE 24149
 // Rows for `n_pad` items (a multiple of 64: a wavefront never straddles two rows) within `lane_budget` lanes (one wavefront per SIMD: 65536).
-//   * While twice the variable terms fit the budget the launch is latency-bound and every variable term is SPLIT over a low and a high row; the high row's 64
-//     extra doublings leave the low row (chain_hi - chain_lo) / MIXED = 46 mixed additions of slack, so the fixed windows of a sum go to its low rows first,
-//     then to rows of their own as far as the budget has rows left (a row of the sum costs k_g1_sum_affine one more addition, so own rows come second), and
-//     whatever is still left is spread over the low rows.
+//   * While twice the variable terms fit the budget the launch is latency-bound -- it lasts as long as its LONGEST row -- and every variable term is SPLIT over a
+//     low row (joint bit positions [0, a)) and a high row ([a, 128), which doubles its result a more times).  Per sum the planner tries every even a and keeps
+//     the one with the shortest longest row: the fixed windows of the sum go to its low rows as far as those stay below the high rows, then to rows of their own
+//     as far as the budget has rows left, and whatever is still left is spread over the low rows.  (a = 64 with the fixed windows riding on the low rows was
+//     round 4's first form; a sum without fixed windows is level at a = 88, one with spare rows for its windows too: 0.82 -> 0.74 ms at 4096 proofs.)
 //   * Otherwise (a large launch: throughput) every variable term is one row and the fixed windows form rows of about a variable row's cost.
 // Unit terms ride on the first rows of their sum.  Returns false if the shape needs more than MSM_MAX_ROWS rows.
-inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t lane_budget) {
+struct MsmSplit { int a, low_each, own_rows, own_each; long worst; };
+// the best split of one sum: L variable terms, wf fixed windows, `spare` rows of the budget not yet taken
+inline MsmSplit msm_best_split(int L, int wf, long spare, int force_a = 0) {
+  MsmSplit best = {64, 0, 0, 0, -1};
+  for (int a = force_a ? force_a : 2; a <= (force_a ? force_a : 126); a += 2) {
+    const long hi = MSM_COST_TABLE + (long)(128 - a) / 2 * MSM_COST_STEP + (long)a * MSM_COST_DBL, lo = MSM_COST_TABLE + (long)a / 2 * MSM_COST_STEP;
+    MsmSplit c = {a, 0, 0, 0, hi > lo ? hi : lo};
+    int rest = wf;
+    if (rest > 0) {
+      const long room = hi > lo ? (hi - lo) / MSM_COST_MIXED : 0;              // windows a low row takes without becoming the longest row
+      c.low_each = (int)((long)(rest + L - 1) / L < room ? (rest + L - 1) / L : room);
+      rest -= c.low_each * L;
+      if (rest > 0) {
+        const long own_cap = c.worst / MSM_COST_MIXED;
+        long want = (rest + own_cap - 1) / own_cap;
+        c.own_rows = (int)(want < spare ? want : (spare > 0 ? spare : 0));
+        if (c.own_rows > 0) { c.own_each = (rest + c.own_rows - 1) / c.own_rows; if (c.own_each > own_cap) c.own_each = (int)own_cap; rest -= c.own_rows * c.own_each; }
+        if (rest > 0) c.low_each += (rest + L - 1) / L;                        // no rows left: the low rows get longer
+      }
+      const long lo_full = lo + (long)c.low_each * MSM_COST_MIXED, own = (long)c.own_each * MSM_COST_MIXED;
+      if (lo_full > c.worst) c.worst = lo_full;
+      if (own > c.worst) c.worst = own;
+    }
+    // fewer rows of their own on a tie (a row of the sum costs k_g1_sum_affine one more addition)
+    if (best.worst < 0 || c.worst < best.worst || (c.worst == best.worst && c.own_rows < best.own_rows)) best = c;
+  }
+  return best;
+}
+inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t lane_budget, int force_a = 0 /* experiments: the split position, even, 2..126 */) {
   std::memset(&p, 0, sizeof p);
   if (sh.n_sums < 1 || sh.n_sums > 2 || n_pad == 0) return false;
   int total_var = 0;
@@ -65,10 +95,7 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
     total_var += sh.n_var[s];
   }
   const bool split = total_var > 0 && (size_t)(2 * total_var) * n_pad <= lane_budget;
-  const int chain_hi = MSM_COST_TABLE + 32 * MSM_COST_STEP + 64 * MSM_COST_DBL, chain_lo = MSM_COST_TABLE + 32 * MSM_COST_STEP;
-  const int chain_full = MSM_COST_TABLE + 64 * MSM_COST_STEP;
-  const int free_cap = (chain_hi - chain_lo) / MSM_COST_MIXED;                                 // windows a low row takes without becoming the longest row
-  const int own_cap = (split ? chain_hi : chain_full) / MSM_COST_MIXED;                        // windows of a row that has nothing else to do
+  const long chain_full = MSM_COST_TABLE + 64L * MSM_COST_STEP;
   long spare = split ? (long)(lane_budget / n_pad) - 2 * total_var : MSM_MAX_ROWS;             // rows the budget still has
   int r = 0, slot = 0;
   for (int s = 0; s < sh.n_sums; s++) {
@@ -76,26 +103,18 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
     p.n_fixed[s] = sh.n_fixed[s];
     for (int f = 0; f < sh.n_fixed[s]; f++) { p.fixed_term[s][f] = sh.fixed_term[s][f]; p.fixed_tab[s][f] = sh.fixed_tab[s][f]; }
     const int wf = 32 * sh.n_fixed[s], L = sh.n_var[s];
-    int low_each = 0, own_rows = 0, own_each = 0;
-    if (wf > 0) {
-      if (split && L > 0) {
-        low_each = (wf + L - 1) / L;
-        if (low_each > free_cap) low_each = free_cap;
-        int rest = wf - low_each * L;
-        if (rest > 0) {
-          long want = (rest + own_cap - 1) / own_cap;
-          own_rows = (int)(want < spare ? want : (spare > 0 ? spare : 0));
-          if (own_rows > 0) { own_each = (rest + own_rows - 1) / own_rows; if (own_each > own_cap) own_each = own_cap; }
-          rest -= own_rows * own_each;
-          if (rest > 0) low_each += (rest + L - 1) / L;                                        // no rows left: the low rows get longer
-        }
-      } else {
-        own_rows = (wf + own_cap - 1) / own_cap;
-        if (split && own_rows > spare) own_rows = spare > 0 ? (int)spare : 1;                  // (a sum without variable terms in a split launch)
-        own_each = (wf + own_rows - 1) / own_rows;
-      }
-      spare -= own_rows;
+    int low_each = 0, own_rows = 0, own_each = 0, a = 64;
+    if (split && L > 0) {
+      // rows left for THIS sum's windows: what the budget has, minus nothing -- later sums take what remains (PlonK: only the first sum of a launch has fixed terms)
+      const MsmSplit b = msm_best_split(L, wf, spare > MSM_MAX_ROWS - r - 2 * L ? MSM_MAX_ROWS - r - 2 * L : spare, force_a);
+      a = b.a; low_each = b.low_each; own_rows = b.own_rows; own_each = b.own_each;
+    } else if (wf > 0) {
+      const int own_cap = (int)((split ? MSM_COST_TABLE + 32L * MSM_COST_STEP + 64L * MSM_COST_DBL : chain_full) / MSM_COST_MIXED);   // windows of a row that has nothing else to do
+      own_rows = (wf + own_cap - 1) / own_cap;
+      if (split && own_rows > spare) own_rows = spare > 0 ? (int)spare : 1;                    // (a sum without variable terms in a split launch)
+      own_each = (wf + own_rows - 1) / own_rows;
     }
+    spare -= own_rows;
     int q = 0, unit_i = 0;                                                                      // next fixed window / unit term to hand out
     auto fixed_slice = [&](MsmRow& w, int want) { w.fw_lo = (uint16_t)q; q = q + want < wf ? q + want : wf; w.fw_hi = (uint16_t)q; };
     auto blank = [&](MsmRow& w) { w.var_term = -1; w.unit_term = -1; w.pos_lo = w.pos_hi = 0; w.sum = (uint8_t)s; w.glv_slot = 0; w.fw_lo = w.fw_hi = 0; };
@@ -103,13 +122,13 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
       if (r + 2 > MSM_MAX_ROWS) return false;
       MsmRow& lo = p.row[r++];
       blank(lo);
-      lo.var_term = sh.var_term[s][t]; lo.pos_lo = 0; lo.pos_hi = split ? 64 : 128; lo.glv_slot = (uint8_t)slot++;
+      lo.var_term = sh.var_term[s][t]; lo.pos_lo = 0; lo.pos_hi = (uint8_t)(split ? a : 128); lo.glv_slot = (uint8_t)slot++;
       if (unit_i < sh.n_unit[s]) lo.unit_term = sh.unit_term[s][unit_i++];
       fixed_slice(lo, low_each);
       if (split) {
         MsmRow& hi = p.row[r++];
         blank(hi);
-        hi.var_term = sh.var_term[s][t]; hi.pos_lo = 64; hi.pos_hi = 128; hi.glv_slot = (uint8_t)slot++;
+        hi.var_term = sh.var_term[s][t]; hi.pos_lo = (uint8_t)a; hi.pos_hi = 128; hi.glv_slot = (uint8_t)slot++;
       }
     }
     for (int k = 0; k < own_rows || q < wf || unit_i < sh.n_unit[s]; k++) {
@@ -128,7 +147,7 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
   p.n_rows = r; p.n_var_rows = slot;
   return true;
 }
-// the longest row of a plan, in the planner's cost units (tests; the roofline of the bench line)
+// the longest row of a plan, in the planner's cost units = multiply-adds of a lane (tests; the roofline of the bench line)
 inline int msm_plan_chain(const MsmPlan& p) {
   int worst = 0;
   for (int r = 0; r < p.n_rows; r++) {

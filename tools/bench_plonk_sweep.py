@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sizes", default="4096,8192,12288,16384,24576,32768,49152,65536,131072,262144")
+    ap.add_argument("--sizes", default="4096,5040,6144,8192,10240,12288,16384,20480,24576,32768,40960,49152,65536,131072,262144")
     ap.add_argument("--steps", type=int, default=4)
     args = ap.parse_args()
     import bench
@@ -21,6 +21,8 @@ def main():
         p, q = pb[:904 * n], ib[:64 * n]
         ref = None
         plans = [("chains5040_w8", dict(piece=5040, workers=8, big_from=1 << 30))]
+        # chains of smaller passes: up to 4096 proofs the KZG launch keeps its split rows (2 x 8 variable terms x 4096 lanes = one wavefront per SIMD)
+        plans += [("chains%d_w8" % pc, dict(piece=pc, workers=8, big_from=1 << 30)) for pc in (4096, 2560) if n > pc]
         for w in (1, 2, 8):
             for bp in (16384, 32768, 65536):
                 if bp >= n and w > 1:
