@@ -596,13 +596,13 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       if (plan.part[pi].count > d->msm_part_cap) return set_err(BN254_E_BAD_ARG, "workspace of a key with many public inputs is smaller than the batch: bn254_groth16_reserve first");
     if (concurrent || split_small) { int rc = ensure_aux(*d, concurrent ? parts - 1 : 2); if (rc) return rc; }
     if (concurrent) HIPCK(hipEventRecord(d->fork_ev, user));
-    const bool measure_overlap = concurrent && parts == 2 && d->ov_state == 0;
+    const bool measure_overlap = concurrent && parts >= 2 && d->ov_state == 0;        // the first two sub-batches of the first batch that runs several
     if (measure_overlap) for (auto& e : d->ov_ev) if (!e) HIPCK(hipEventCreate(&e));
     for (int pi = 0; pi < parts; pi++) {
       const size_t lo = plan.part[pi].first, hi = lo + plan.part[pi].count;
       hipStream_t st = concurrent ? part_stream(*d, user, pi) : user;
       if (concurrent && pi < 4 && st != user) HIPCK(hipStreamWaitEvent(st, d->fork_ev, 0));
-      if (measure_overlap) HIPCK(hipEventRecord(d->ov_ev[2 * pi], st));
+      if (measure_overlap && pi < 2) HIPCK(hipEventRecord(d->ov_ev[2 * pi], st));
       G16LaunchArgs a;
       a.proofs = (const uint8_t*)d_proofs + (off + lo) * proof_stride; a.stride = proof_stride;
       a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
@@ -633,7 +633,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       hipError_t e = bn254_launch_g16(a, st, prof_this ? d->ev : nullptr, prof_this ? &d->prof : (prof_second ? &d->prof2 : nullptr));
       if (e != hipSuccess) return set_err(e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ? BN254_E_NO_DEVICE : BN254_E_HIP,
                                            std::string("kernel launch: ") + hipGetErrorString(e));
-      if (measure_overlap) HIPCK(hipEventRecord(d->ov_ev[2 * pi + 1], st));
+      if (measure_overlap && pi < 2) HIPCK(hipEventRecord(d->ov_ev[2 * pi + 1], st));
       if (concurrent && (pi + 4 >= parts) && st != user) { HIPCK(hipEventRecord(d->join_ev[pi % 4], st)); HIPCK(hipStreamWaitEvent(user, d->join_ev[pi % 4], 0)); }
     }
     if (measure_overlap) d->ov_state = 1;

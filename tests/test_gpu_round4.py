@@ -2,6 +2,7 @@
 multi-device entry on every visible device, PlonK batch plans against each other (chains of passes, one large pass, the lane kernels of the two-pair pairing check),
 PlonK key shapes other than the SP1 circuit's, a proof stride that needs 115 KB of LDS per workgroup, the stream-overlap report."""
 import ctypes as C
+import os
 import random
 
 import pytest
@@ -183,6 +184,10 @@ def test_stream_overlap_is_measured_not_assumed(pkg, L):
     for _ in range(3):
         assert pvk.verify_batch(proofs, inputs) == exp
     assert L.bn254_groth16_stream_overlap(pvk.handle, 0, C.byref(ov), C.byref(single)) == 0
+    if os.environ.get("BN254_STREAMS") == "1":      # tools/gpu_variants.sh: one sub-batch per launch by configuration, nothing to measure
+        assert ov.value == -1.0 and single.value == 0
+        pvk.close()
+        return
     assert 0.9 <= ov.value <= 2.1, ov.value
     if ov.value < 1.15:
         assert single.value == 1 and b"hardware queue" in L.bn254_last_diagnostic()

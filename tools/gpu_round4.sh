@@ -20,13 +20,13 @@ python tools/bench_plonk.py --batch 4096 --steps 20 --warmup 3 --cpu-sample 512 
 python tools/bench_plonk.py --batch 65536 --steps 5 --warmup 1 --cpu-sample 0 > $O/plonk65536.json 2> $O/plonk65536.err || fail plonk65536 $O/plonk65536.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rlc --no-configs > $O/prof_bench.json 2> $O/prof.err || fail rocprof $O/prof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk -o run -- python3 $R/tools/bench_plonk.py --batch 4096 --steps 10 --warmup 2 --cpu-sample 0 > $O/prof_plonk.json 2> $O/prof_plonk.err || fail "rocprof plonk" $O/prof_plonk.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk -o run -- python3 $R/tools/bench_plonk.py --batch 4096 --steps 10 --warmup 2 --cpu-sample 0 --no-in-flight > $O/prof_plonk.json 2> $O/prof_plonk.err || fail "rocprof plonk" $O/prof_plonk.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk64k -o run -- python3 $R/tools/bench_plonk.py --batch 65536 --steps 3 --warmup 1 --cpu-sample 0 > $O/prof_plonk64k.json 2> $O/prof_plonk64k.err || fail "rocprof plonk 64k" $O/prof_plonk64k.err
 echo "kernel traces done"
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_INT64" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $c | cut -d' ' -f1)
   BN254_STREAMS=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-rlc --no-configs --batch-log2 18 > $O/pmc_$tag.json 2> $O/pmc_$tag.err || fail "pmc $tag" $O/pmc_$tag.err
-  rocprofv3 --pmc $c --output-format csv -d $O/pmcp_$tag -o run -- python3 $R/tools/bench_plonk.py --batch 4096 --steps 2 --warmup 1 --cpu-sample 0 > $O/pmcp_$tag.json 2> $O/pmcp_$tag.err || fail "pmc plonk $tag" $O/pmcp_$tag.err
+  rocprofv3 --pmc $c --output-format csv -d $O/pmcp_$tag -o run -- python3 $R/tools/bench_plonk.py --batch 4096 --steps 2 --warmup 1 --cpu-sample 0 --no-in-flight > $O/pmcp_$tag.json 2> $O/pmcp_$tag.err || fail "pmc plonk $tag" $O/pmcp_$tag.err
   echo "pmc $tag done"
 done
 cd $R

@@ -5,7 +5,9 @@
 # Run on the GPU box: gpurun -- bash tools/gpu_variants.sh      (ONLY_RLC=1: the two RLC shapes only; ONLY_LIBS=1: the library variants only)
 set -o pipefail
 mkdir -p gpurun_out
-run() { tag=$1; shift; env "$@" timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/variants_pytest_$tag.txt 2>&1; rc=$?; echo "$tag rc=$rc $(tail -1 gpurun_out/variants_pytest_$tag.txt)"; grep -q -i "access fault" gpurun_out/variants_pytest_$tag.txt && exit 1; [ $rc -eq 0 ] || exit $rc; }
+FAILED=0
+# a failing variant is recorded and the next one runs (a GPU fault or a timeout ends the script: no further GPU step after one)
+run() { tag=$1; shift; env "$@" timeout -k 10 900 python -m pytest tests -q -m gpu > gpurun_out/variants_pytest_$tag.txt 2>&1; rc=$?; echo "$tag rc=$rc $(tail -1 gpurun_out/variants_pytest_$tag.txt)"; grep -q -i "access fault" gpurun_out/variants_pytest_$tag.txt && exit 1; [ $rc -ge 124 ] && exit $rc; [ $rc -eq 0 ] || FAILED=1; }
 if [ -z "$ONLY_RLC" ] && [ -z "$ONLY_LIBS" ]; then
 run nocoop BN254_COOP=0
 run streams1 BN254_STREAMS=1
@@ -28,10 +30,11 @@ for v in frmul64 frmul_inline_barrier frmul_outofline_nobarrier; do
   [ -f $lib ] || { echo "$v: not built (tools/build_variants.sh)"; continue; }
   tag=lib_$v
   BN254_LIB_PATH=$lib timeout -k 10 900 python -m pytest tests -x -q -m gpu -k plonk > gpurun_out/variants_pytest_$tag.txt 2>&1; rc=$?
-  echo "$tag rc=$rc $(tail -1 gpurun_out/variants_pytest_$tag.txt)"; [ $rc -eq 0 ] || exit $rc
+  echo "$tag rc=$rc $(tail -1 gpurun_out/variants_pytest_$tag.txt)"; [ $rc -ge 124 ] && exit $rc; [ $rc -eq 0 ] || FAILED=1
 done
 fi
 if [ -z "$ONLY_LIBS" ]; then
 timeout -k 10 900 python tools/gpu_fuzz.py --cases 200 > gpurun_out/variants_fuzz.txt 2>&1 || { tail -5 gpurun_out/variants_fuzz.txt; exit 1; }
 tail -2 gpurun_out/variants_fuzz.txt
 fi
+exit $FAILED

@@ -61,8 +61,8 @@ with open(os.path.join(out, tag + "_miller_run_timeline.txt"), "w") as f:
             f.write("%-16s queue %s  %9.3f -> %9.3f  (%8.3f ms)\n" % (n, r["Queue_Id"], (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6,
                                                                       (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
 kernel_stats("prof_plonk/**/*kernel_trace.csv", tag + "_plonk4096_kernel_stats.csv",
-             "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_plonk.py --batch 4096 --steps 10 --warmup 2 --cpu-sample 0 (PlonK batches of 4096 proofs: one pass, the MSMs as rows,\n"
-             "# the pairing check on the cooperative kernel; includes the warm-up batches and the peak probe k_valu_peak)\n")
+             "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_plonk.py --batch 4096 --steps 10 --warmup 2 --cpu-sample 0 --no-in-flight (PlonK batches of 4096 proofs, one call at a time:\n"
+             "# one pass, the MSMs as rows, the pairing check on the cooperative kernel; includes the warm-up batches and the peak probe k_valu_peak)\n")
 kernel_stats("prof_plonk64k/**/*kernel_trace.csv", tag + "_plonk65536_kernel_stats.csv",
              "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_plonk.py --batch 65536 --steps 3 --warmup 1 --cpu-sample 0 (PlonK batches of 65 536 proofs: one pass, unsplit rows,\n"
              "# the pairing check on the lane kernels: k_miller_run_fixed2 + the final-exponentiation program)\n")
@@ -144,5 +144,5 @@ if "k_miller_run" in sq:
               open(os.path.join(out, "miller_run_pmc_counts.json"), "w"), indent=1)
 # PlonK, 4096 proofs per batch (the warm-up batches of bench_plonk.py included: per-launch averages)
 pmc_table("pmcp", 4096, tag + "_plonk4096_pmc_summary.csv",
-          "# rocprofv3 --pmc passes (SQ activity | FETCH_SIZE | WRITE_SIZE), each its own run of: python3 tools/bench_plonk.py --batch 4096 --steps 2 --warmup 1 --cpu-sample 0 "
+          "# rocprofv3 --pmc passes (SQ activity | FETCH_SIZE | WRITE_SIZE), each its own run of: python3 tools/bench_plonk.py --batch 4096 --steps 2 --warmup 1 --cpu-sample 0 --no-in-flight "
           "(PlonK batches of 4096 proofs; per-launch averages; bytes per PROOF of the batch)\n")
