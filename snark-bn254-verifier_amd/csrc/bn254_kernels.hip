@@ -309,11 +309,31 @@ k_g16_msm_partial_comb(const uint16_t* __restrict__ digits, int n_public, uint32
   G1Proj acc = g1_identity();
   if (status[i] & BN254_ST_PENDING) {
     const int s_begin = (int)(c * per), s_end = (int)min((uint32_t)n_public, (c + 1) * (uint32_t)per);
-    for (int col = G16_COMB_COLS - 1; col >= 0; col--) {
-      if (col != G16_COMB_COLS - 1) acc = g1_dbl(acc);
-      for (int s = s_begin; s < s_end; s++) {
-        const uint32_t idx = digits[((size_t)col * (size_t)n_public + s) * n + i];
-        if (idx != 0) acc = g1_add_mixed(acc, msm_entry(msm_tab, ((size_t)s << G16_COMB_TEETH) + idx));
+    // Software pipeline (round 4): the table entry of addition k + 1 (a random 80-byte read of a 671 MB table) and the digit of addition k + 2 are in flight while
+    // addition k computes.  Without it every addition waited for its own digit, then for its own entry, with two wavefronts per SIMD to hide that behind
+    // (VALU-active 0.37, profiles/r02_cfg5_pmc_summary.csv).  (col, s) walks the columns from the top, the chunk's inputs inside a column.
+    auto digit_at = [&](int col, int s) -> uint32_t { return digits[((size_t)col * (size_t)n_public + (size_t)s) * n + i]; };
+    auto entry_at = [&](int s, uint32_t idx) -> G1Aff { return msm_entry(msm_tab, ((size_t)s << G16_COMB_TEETH) + idx); };   // idx 0: a valid (unused) slot of the table
+    auto advance = [&](int& col, int& s) { if (++s == s_end) { s = s_begin; col--; } };
+    if (s_begin < s_end) {
+      int col1 = G16_COMB_COLS - 1, s1 = s_begin;            // position of addition k + 1 while addition k runs
+      uint32_t d_cur = digit_at(col1, s1);
+      G1Aff e_cur = entry_at(s1, d_cur);
+      int col0 = col1, s0 = s1;
+      advance(col1, s1);
+      uint32_t d_nxt = col1 >= 0 ? digit_at(col1, s1) : 0u;
+      int col2 = col1, s2 = s1;                               // position of addition k + 2
+      if (col2 >= 0) advance(col2, s2);
+      while (col0 >= 0) {
+        G1Aff e_nxt = e_cur;
+        uint32_t d_nn = 0u;
+        if (col1 >= 0) e_nxt = entry_at(s1, d_nxt);
+        if (col2 >= 0) d_nn = digit_at(col2, s2);
+        if (s0 == s_begin && col0 != G16_COMB_COLS - 1) acc = g1_dbl(acc);
+        if (d_cur != 0) acc = g1_add_mixed(acc, e_cur);
+        col0 = col1; s0 = s1; d_cur = d_nxt; e_cur = e_nxt;
+        col1 = col2; s1 = s2; d_nxt = d_nn;
+        if (col2 >= 0) advance(col2, s2);
       }
     }
   }
@@ -746,7 +766,9 @@ hipError_t bn254_launch_g16(const G16LaunchArgs& a, hipStream_t s, hipEvent_t* e
   if (a.strict_scalars && a.n_public > 0) hipLaunchKernelGGL(k_g16_check_scalars, dim3(grid), dim3(256), 0, s, a.inputs, a.n_public, n, a.status);
   if (wide) {
     // inputs of one proof spread over `chunks` lanes, proofs in slices that fit the partial-sum buffer
-    const int per = G16_WIDE_MSM_INPUTS_PER_LANE, chunks = (a.n_public + per - 1) / per;
+    // BN254_WIDE_PER (experiments): inputs per lane, at least G16_WIDE_MSM_INPUTS_PER_LANE (the partial-sum buffer is sized for that many chunks)
+    static const int per_env = [] { const char* e = getenv("BN254_WIDE_PER"); int v = e ? atoi(e) : 0; return v >= G16_WIDE_MSM_INPUTS_PER_LANE && v <= 256 ? v : 0; }();
+    const int per = per_env ? per_env : G16_WIDE_MSM_INPUTS_PER_LANE, chunks = (a.n_public + per - 1) / per;
     unsigned pg = (unsigned)(((size_t)n * chunks + 255) / 256);
     {
       ProfScope ps_(prof, KID_MSM_PARTIAL, s);

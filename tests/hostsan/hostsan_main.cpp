@@ -223,6 +223,32 @@ int main(int argc, char** argv) {
     }
     printf("hostsan: plonk key fuzz: %ld of %ld mutated keys still parse\n", ok, fuzz_iters / 4 + 1);
   }
+  // ---------------------------------------------------------------- PlonK proof bytes: the parser and the layout function the device's chain lane uses instead of it
+  {
+    // k_plonk_stage1 runs parse_plonk_proof on one lane and, on another, the transcripts from plonk_proof_layout alone: wherever the parser accepts, the layout must
+    // accept with the same offsets and counts; wherever the layout refuses, the parser must refuse too.  Mutated fixture proofs, hostile counts included.
+    std::vector<uint8_t> fx = read_file(golden + "/sp1/fibonacci_plonk_proof.bin");
+    std::vector<uint8_t> raw(2048); size_t raw_len = 0; int variant = 0; uint8_t pin[64], vh[32];
+    CHECK(!fx.empty() && bn254_sp1_fixture_parse(fx.data(), fx.size(), &variant, raw.data(), raw.size(), &raw_len, pin, vh) == 0 && variant == 2);
+    raw.resize(raw_len);
+    const std::vector<size_t> counts = {512, 516 + 7 * 32 + 96};          // n_claimed, n_bsb
+    long agree = 0, parsed = 0;
+    for (long it = 0; it < fuzz_iters * 8; it++) {
+      std::vector<uint8_t> m = it == 0 ? raw : mutate(raw, g, counts);
+      if (it % 5 == 1 && m.size() > 516) { const uint32_t v = (uint32_t)(g() % 20); m[512] = 0; m[513] = 0; m[514] = 0; m[515] = (uint8_t)v; }     // plausible claimed-value counts
+      bn254host::PlonkProof pr; bn254host::PlonkLayout lay;
+      const int st = bn254host::parse_plonk_proof(pr, m.data(), m.size());
+      const bool ok = bn254host::plonk_proof_layout(lay, m.data(), m.size());
+      if (st == bn254host::PL_OK) {
+        parsed++;
+        CHECK(ok && lay.off_claimed == pr.off_claimed && lay.off_zs_h == pr.off_zs_h && lay.off_bsb == pr.off_bsb && lay.n_claimed == pr.n_claimed && lay.n_bsb == pr.n_bsb);
+      }
+      if (!ok) CHECK(st != bn254host::PL_OK);
+      if (ok) { CHECK(lay.off_bsb + 64 * (size_t)lay.n_bsb <= m.size() && lay.off_claimed + 32 * (size_t)lay.n_claimed + 100 <= m.size() + 0); agree++; }
+    }
+    CHECK(parsed >= 1);
+    printf("hostsan: plonk proof fuzz: %ld of %ld mutated proofs parse, layout usable for %ld\n", parsed, fuzz_iters * 8, agree);
+  }
   // ---------------------------------------------------------------- SP1 fixture reader and the point codecs
   {
     std::vector<uint8_t> fx = read_file(golden + "/sp1/fibonacci_plonk_proof.bin");
