@@ -129,10 +129,18 @@ static int check_device(int device) {
   HIPCK(hipSetDevice(device));
   return BN254_OK;
 }
+// *dst stays null unless the copy is complete: a caller that retries after a failure uploads exactly what is still missing (a sanitizer run of the
+// allocation-failure paths found the retry overwriting -- leaking -- the tables an earlier, partly failed attempt had already uploaded)
 template <typename T> static int upload(T** dst, const std::vector<T>& src) {
+  if (*dst) return BN254_OK;
   size_t bytes = (src.size() ? src.size() : 1) * sizeof(T);
-  HIPCK(hipMalloc((void**)dst, bytes));
-  if (!src.empty()) HIPCK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  T* p = nullptr;
+  HIPCK(hipMalloc((void**)&p, bytes));
+  if (!src.empty()) {
+    hipError_t e = hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p); return set_err(BN254_E_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+  }
+  *dst = p;
   return BN254_OK;
 }
 static DevState* dev_state(const bn254_g16_pvk* pvk, int device) {
