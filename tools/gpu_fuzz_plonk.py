@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run of the PlonK batch entry on the GPU box: a pool of distinct cases (the reference's four fixtures and mutations of their proofs
 and public inputs, every status the path can return) gets its verdicts from the CPU oracle once; then many batches of random sizes -- 1 .. 21 000 proofs, with
-the sizes around the limits of the scalar-multiplication launch forms (2520, 5041 proofs) and of the sub-batch plan over-represented -- are drawn from the pool
+the sizes around the limits of the row plans, the row sums and the batch plan (and round 3's launch-form limits) over-represented -- are drawn from the pool
 in random order, on ONE prepared key (its contexts keep the capacities earlier batches gave them), and every status byte is compared.
   python tools/gpu_fuzz_plonk.py [--cases 60] [--seed 1]"""
 import argparse, importlib, json, os, random, sys, time
@@ -44,8 +44,10 @@ def main():
     verdict = [O.plonk_verify(p, vk, [int.from_bytes(q[:32], "big"), int.from_bytes(q[32:], "big")]) for p, q in pool]
     oracle_s = time.time() - t0
     pvk = pkg.PreparedPlonkVk(vk)
-    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 1000, 2166, 2167, 2519, 2520, 2521, 2560, 4096, 4332, 4333, 4864, 4865, 5039, 5040, 5041, 5042, 5120, 5121, 6000, 8192,
-             10079, 10080, 10081, 12345, 15120, 15121, 20160, 20161, 21000]
+    # the limits of round 4's forms: split rows while 2 x variable terms x lanes <= 65536 (KZG launch: 4096 proofs, digest launch: 6528), four lanes per row sum up to
+    # 8192 (two sums) / 16384 proofs (one), passes of <= 5040 proofs up to 9000 per call, one pass up to 20 000, two up to 40 000, passes of 65 536 above; and round 3's
+    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 1000, 2166, 2167, 2519, 2520, 2521, 2560, 4095, 4096, 4097, 4332, 4333, 4864, 4865, 5039, 5040, 5041, 5042, 5120, 5121, 6000,
+             6528, 6529, 8192, 8193, 9000, 9001, 10079, 10080, 10081, 12345, 15120, 15121, 16384, 16385, 20000, 20001, 20160, 20161, 21000, 40000, 40001]
     checked = 0
     classes = {}
     for case in range(args.cases):
