@@ -612,13 +612,16 @@ def _plonk_accounting(pkg, km, batch, stage_ms):
                                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
     def rows(stage):
-        nr, nv = C.c_int(), C.c_int(); sc = C.c_size_t(); ch = C.c_int(); sums, fixed = (C.c_int * 2)(), (C.c_int * 2)(); desc = (C.c_int * 256)()
+        nr, nv = C.c_int(), C.c_int(); sc = C.c_size_t(); ch = C.c_int(); sums, fixed = (C.c_int * 2)(), (C.c_int * 2)(); desc = (C.c_int * (32 * 9))()
         assert L.bn254_dbg_plonk_msm_plan(1, stage, pass_n, 0, C.byref(nr), C.byref(nv), C.byref(sc), C.byref(ch), sums, fixed, desc) == 0
         per_row = []
         for r in range(nr.value):
-            vt, lo, hi, ut, _s, _slot, flo, fhi = desc[8 * r:8 * r + 8]
+            vt, lo, hi, ut, _s, _slot, flo, fhi, jmask = desc[9 * r:9 * r + 9]
             m = 0.0
-            if vt >= 0:
+            if jmask:
+                g = bin(jmask).count("1")      # a joint row: g tables, 64 steps of one pair of doublings + g additions
+                m += g * (comp["table_head"] + 9 * comp["table_add"]) + 64 * (2 * comp["dbl"] + g * comp.get("joint_add", comp["step"] - 2 * comp["dbl"]))
+            elif vt >= 0:
                 m += comp["table_head"] + 9 * comp["table_add"] + (hi - lo) / 2 * comp["step"] + lo * comp["dbl"]
             if ut >= 0:
                 m += comp["unit"]

@@ -270,8 +270,9 @@ int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2
 
 /* host-only probes of the PlonK batch plan (sub-batches side by side, proofs per sub-batch, proofs per pass) and of the MSM launches (csrc/bn254_msm.h): the row plan of
  * the stage-1 / stage-2 launch for a key with n_qcp commitments and n proofs under a lane budget (0 = the library's) -- rows, rows that use window-table scratch, the
- * scratch lanes that launch needs, its longest row in the planner's cost units, rows and fixed terms per sum, optionally the rows themselves (MSM rows x 8 ints:
- * variable term, pos_lo, pos_hi, unit term, sum, scratch slot, fixed windows [lo, hi)); and the scratch lanes a context of `capacity` proofs allocates for launches
+ * scratch lanes that launch needs, its longest row in the planner's cost units, rows and fixed terms per sum, optionally the rows themselves (MSM rows x 9 ints:
+ * variable term (-1: none, or a joint row), pos_lo, pos_hi, unit term, sum, first scratch slot, fixed windows [lo, hi), and for a JOINT row -- several variable terms
+ * walked together over all 128 positions, large launches -- the bit mask of its terms); and the scratch lanes a context of `capacity` proofs allocates for launches
  * of n_var variable terms.  tests/test_capi_cpu.py: need <= allocation for every n <= capacity. */
 int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per_worker, size_t* per_pass);
 /* host-only probe of the Groth16 plan (csrc/bn254_g16_plan.h: the functions the library itself allocates and enqueues by): a key with key_inputs public inputs

@@ -315,6 +315,14 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
   *out = &d;
   return BN254_OK;
 }
+// Variable terms per JOINT row of an MSM launch over m_pad lanes per row (bn254_msm.h: Straus rows share the doublings of a step between their terms; 0 = one row per
+// term).  A launch must still fill the GPU: two wavefronts per SIMD are 131 072 lanes, so joint rows pay from passes of tens of thousands of proofs on.
+// BN254_MSM_JOINT=g forces a group size (0: never).
+static int plonk_joint_g(size_t m_pad) {
+  static const int env = [] { const char* e = getenv("BN254_MSM_JOINT"); return e ? atoi(e) : -1; }();
+  if (env >= 0) return env > MSM_MAX_JOINT ? MSM_MAX_JOINT : env;
+  return m_pad >= 49152 ? MSM_MAX_JOINT : 0;      // measured (profiles/r04_msm_joint_rows_sweep.txt): all the terms of a sum in one row, from 49 152 proofs per pass
+}
 // lanes an MSM launch may use at one wavefront per SIMD: the planner splits variable terms over two rows while the launch stays within it (bn254_msm.h)
 static size_t msm_lane_budget() { static const size_t v = [] { const char* e = getenv("BN254_MSM_LANE_BUDGET"); long x = e ? atol(e) : 65536; return (size_t)(x < 64 ? 64 : x); }(); return v; }
 // Lanes of window-table scratch a context of capacity `need` proofs must hold: the largest launch ANY batch of up to `need` proofs can make with a launch of
@@ -1221,7 +1229,7 @@ static int plonk_msm(const PlonkDev* d, PlonkCtx& c, const MsmShape& shape, size
   const size_t m_pad = (m + 63) & ~(size_t)63;
   // BN254_MSM_SPLIT_AT (experiments): the bit position at which the variable terms' low and high rows meet, instead of the planner's choice
   static const int force_a = [] { const char* e = getenv("BN254_MSM_SPLIT_AT"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 126 && !(v & 1)) ? v : 0; }();
-  if (!msm_plan_build(plan, shape, m_pad, msm_lane_budget(), force_a)) return set_err(BN254_E_BAD_ARG, "PlonK key shape needs more MSM rows than the launch supports");
+  if (!msm_plan_build(plan, shape, m_pad, msm_lane_budget(), force_a, plonk_joint_g(m_pad))) return set_err(BN254_E_BAD_ARG, "PlonK key shape needs more MSM rows than the launch supports");
   if (m > c.cap || bn254_g1_msm_scratch_lanes(plan, m) > c.glv_lanes || (size_t)plan.n_rows > (size_t)MSM_MAX_ROWS)
     return set_err(BN254_E_HIP, "PlonK context smaller than the launch (internal sizing error)");
   hipError_t e = bn254_launch_g1_msm_rows(plan, (const int32_t*)c.terms, c.flags, m, n_terms, c.part, c.glv_tab, d->fixed_tabs, c.stream);
@@ -1721,14 +1729,16 @@ int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget,
   MsmShape sh;
   if (stage == 1) plonk_msm1_shape(key, sh); else plonk_msm2_shape(key, sh);
   MsmPlan plan;
-  if (!msm_plan_build(plan, sh, (n + 63) & ~(size_t)63, lane_budget ? lane_budget : msm_lane_budget())) return set_err(BN254_E_BAD_ARG, "shape cannot be planned");
+  if (!msm_plan_build(plan, sh, (n + 63) & ~(size_t)63, lane_budget ? lane_budget : msm_lane_budget(), 0, plonk_joint_g((n + 63) & ~(size_t)63))) return set_err(BN254_E_BAD_ARG, "shape cannot be planned");
   *n_rows = plan.n_rows; *n_var_rows = plan.n_var_rows; *scratch_lanes = bn254_g1_msm_scratch_lanes(plan, n); *chain = msm_plan_chain(plan);
   for (int k = 0; k < 2; k++) { sum_rows[k] = plan.count[k]; fixed_terms[k] = plan.n_fixed[k]; }
   if (rows_out)
     for (int r = 0; r < plan.n_rows; r++) {
       const MsmRow& w = plan.row[r];
-      int* o = rows_out + 8 * r;
-      o[0] = w.var_term; o[1] = w.pos_lo; o[2] = w.pos_hi; o[3] = w.unit_term; o[4] = w.sum; o[5] = w.glv_slot; o[6] = w.fw_lo; o[7] = w.fw_hi;
+      int* o = rows_out + 9 * r;
+      o[0] = w.n_joint ? -1 : w.var_term; o[1] = w.pos_lo; o[2] = w.pos_hi; o[3] = w.unit_term; o[4] = w.sum; o[5] = w.glv_slot; o[6] = w.fw_lo; o[7] = w.fw_hi;
+      o[8] = 0;                                     // a joint row: the bit mask of the terms it walks together
+      for (int j = 0; j < w.n_joint; j++) o[8] |= 1 << plan.var_list[w.sum][w.var_term + j];
     }
   return BN254_OK;
 }

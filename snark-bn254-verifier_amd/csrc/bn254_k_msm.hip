@@ -14,6 +14,8 @@ namespace bn254 {
 // a lane's 16 x 28 dwords of window-table scratch (global memory: one contiguous 108-byte read per step, issued before the doublings)
 struct DevGlvTab {
   int32_t* base;
+  size_t slot_stride;      // dwords between the same lane's tables in consecutive scratch rows (joint rows keep one table per term)
+  __device__ __forceinline__ DevGlvTab slot(int j) const { return DevGlvTab{base + (size_t)j * slot_stride, slot_stride}; }
   __device__ __forceinline__ void put(int i, const G1Proj& p) const {
     const Fp x = fp_reduce(p.x), y = fp_reduce(p.y), z = fp_reduce(p.z);
     int4* q = (int4*)(base + i * 28);
@@ -47,6 +49,7 @@ struct DevMsmIO {
     for (int k = 0; k < 4; k++) { k1[k] = (uint32_t)e[18 + k]; k2[k] = (uint32_t)e[22 + k]; }
     fl = flags_i[t];
   }
+  __device__ __forceinline__ uint32_t kword(int t, int half, int w) const { return (uint32_t)terms_i[(size_t)t * MSM_TERM_DWORDS + 18 + 4 * half + w]; }
   __device__ __forceinline__ uint32_t scalar_byte(int t, int w) const { return ((const uint8_t*)(terms_i + (size_t)t * MSM_TERM_DWORDS + 18))[w]; }
   __device__ __forceinline__ G1Aff entry(int tab, int w, uint32_t d) const {
     return msm_entry(tabs + (size_t)tab * ((size_t)32 * 255 * MSM_ENTRY_DWORDS), (size_t)w * 255 + d);
@@ -68,7 +71,7 @@ k_g1_msm_rows(MsmPlan plan_arg, const int32_t* __restrict__ terms, const uint8_t
   const bool live = i < n;
   const uint32_t ii = live ? i : n - 1;
   DevMsmIO io{terms + (size_t)ii * (size_t)n_terms * MSM_TERM_DWORDS, flags + (size_t)ii * (size_t)n_terms, tabs};
-  DevGlvTab tab{glv_tab + ((size_t)plan.row[r].glv_slot * n_pad + i) * (size_t)(G1_GLV_TAB_BYTES_PER_LANE / 4)};
+  DevGlvTab tab{glv_tab + ((size_t)plan.row[r].glv_slot * n_pad + i) * (size_t)(G1_GLV_TAB_BYTES_PER_LANE / 4), (size_t)n_pad * (size_t)(G1_GLV_TAB_BYTES_PER_LANE / 4)};
   const G1Proj acc = msm_row_eval(plan, r, io, tab);
   if (!live) return;
   int32_t* o = part + (size_t)r * 27 * n + i;

@@ -4,7 +4,9 @@
 // A launch evaluates up to two sums  S_s = sum_t k_t P_t  per item (proof).  Its terms are of three kinds:
 //   variable   P_t comes with the proof (commitments, openings): the scalar arrives GLV-decomposed, k = +-k1 +- k2 lambda with 128-bit halves, and is
 //              walked by the joint two-bit-window form of bn254_rlc.h over the 128 joint bit positions -- by ONE row, or by two rows that take the low and
-//              the high positions (the high row doubles its result 64 more times), which shortens the chain where a launch is latency-bound;
+//              the high positions (the high row doubles its result a more times), which shortens the chain where a launch is latency-bound; or -- large
+//              launches, where the total work counts -- by a JOINT row that walks up to MSM_MAX_JOINT terms of a sum together (Straus): one pair of doublings
+//              per step for all of them instead of one pair per term;
 //   fixed      P_t belongs to the verifying key: a byte-window table of the point (32 x 255 multiples, bn254_host.hpp::build_window_table) turns the term
 //              into at most 32 complete mixed additions, and those additions are dealt out window by window -- to the LOW rows of the variable terms, which
 //              have time to spare while the high rows double, and to rows of their own;
@@ -21,6 +23,7 @@ namespace bn254 {
 
 #define MSM_MAX_ROWS 32
 #define MSM_MAX_FIXED 16
+#define MSM_MAX_JOINT 8        // variable terms of one joint row
 #define MSM_TERM_DWORDS 26       // MsmTerm (bn254_plonk.hpp): 18 digits of the affine point, 8 scalar words
 struct MsmRow {
   int8_t var_term;      // term whose GLV halves this row walks, or -1
@@ -29,6 +32,9 @@ struct MsmRow {
   uint8_t sum;          // the sum the row belongs to
   uint8_t glv_slot;     // which of the launch's window-table scratch rows it uses (variable rows only)
   uint16_t fw_lo, fw_hi;    // byte windows [fw_lo, fw_hi) of its sum's fixed terms, flattened: window q = byte q & 31 of fixed term q >> 5
+  uint8_t n_joint;      // > 0: a JOINT row -- var_term is then the INDEX of its first term in var_list[sum], it walks n_joint consecutive ones over all 128
+                        // positions with shared doublings; their window tables are the slots glv_slot .. glv_slot + n_joint - 1
+  uint8_t reserved;
 };
 struct MsmPlan {
   int32_t n_rows, n_var_rows;
@@ -36,6 +42,7 @@ struct MsmPlan {
   int32_t n_fixed[2];
   int8_t fixed_term[2][MSM_MAX_FIXED];              // term index of the f-th fixed term of sum s (its scalar: 8 canonical words in the term's k[])
   int8_t fixed_tab[2][MSM_MAX_FIXED];               // and which of the key's window tables it reads
+  int8_t var_list[2][MSM_MAX_FIXED];                // the variable terms of sum s in the order given (joint rows index it)
   MsmRow row[MSM_MAX_ROWS];
 };
 // what the caller says about a launch: per sum the term indices of each kind
@@ -50,6 +57,7 @@ struct MsmShape {
 #define MSM_COST_DBL 1243
 #define MSM_COST_MIXED 1815
 #define MSM_COST_TABLE 24149
+#define MSM_COST_JADD (MSM_COST_STEP - 2 * MSM_COST_DBL)     // the addition of a step without its two doublings: a joint row's cost per term and step
 // Rows for `n_pad` items (a multiple of 64: a wavefront never straddles two rows) within `lane_budget` lanes (one wavefront per SIMD: 65536).
 //   * While twice the variable terms fit the budget the launch is latency-bound -- it lasts as long as its LONGEST row -- and every variable term is SPLIT over a
 //     low row (joint bit positions [0, a)) and a high row ([a, 128), which doubles its result a more times).  Per sum the planner tries every even a and keeps
@@ -86,7 +94,8 @@ inline MsmSplit msm_best_split(int L, int wf, long spare, int force_a = 0) {
   }
   return best;
 }
-inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t lane_budget, int force_a = 0 /* experiments: the split position, even, 2..126 */) {
+inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t lane_budget, int force_a = 0 /* experiments: the split position, even, 2..126 */,
+                           int joint_g = 0 /* > 1: unsplit launches walk up to that many variable terms of a sum in one JOINT row (large launches) */) {
   std::memset(&p, 0, sizeof p);
   if (sh.n_sums < 1 || sh.n_sums > 2 || n_pad == 0) return false;
   int total_var = 0;
@@ -95,6 +104,8 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
     total_var += sh.n_var[s];
   }
   const bool split = total_var > 0 && (size_t)(2 * total_var) * n_pad <= lane_budget;
+  if (joint_g > MSM_MAX_JOINT) joint_g = MSM_MAX_JOINT;
+  const bool joint = !split && joint_g > 1;
   const long chain_full = MSM_COST_TABLE + 64L * MSM_COST_STEP;
   long spare = split ? (long)(lane_budget / n_pad) - 2 * total_var : MSM_MAX_ROWS;             // rows the budget still has
   int r = 0, slot = 0;
@@ -103,11 +114,17 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
     p.n_fixed[s] = sh.n_fixed[s];
     for (int f = 0; f < sh.n_fixed[s]; f++) { p.fixed_term[s][f] = sh.fixed_term[s][f]; p.fixed_tab[s][f] = sh.fixed_tab[s][f]; }
     const int wf = 32 * sh.n_fixed[s], L = sh.n_var[s];
+    for (int t = 0; t < L; t++) p.var_list[s][t] = sh.var_term[s][t];
     int low_each = 0, own_rows = 0, own_each = 0, a = 64;
+    // joint rows: the L terms in ceil(L / joint_g) rows of sizes that differ by at most one
+    const int j_rows = joint && L > 0 ? (L + joint_g - 1) / joint_g : 0;
     if (split && L > 0) {
       // rows left for THIS sum's windows: what the budget has, minus nothing -- later sums take what remains (PlonK: only the first sum of a launch has fixed terms)
       const MsmSplit b = msm_best_split(L, wf, spare > MSM_MAX_ROWS - r - 2 * L ? MSM_MAX_ROWS - r - 2 * L : spare, force_a);
       a = b.a; low_each = b.low_each; own_rows = b.own_rows; own_each = b.own_each;
+    } else if (wf > 0 && j_rows) {
+      // joint rows carry the sum's fixed windows themselves, levelled (below): no rows of their own -- a large launch is over when its LAST row is, and a short
+      // row of windows beside long joint rows would leave its lanes idle
     } else if (wf > 0) {
       const int own_cap = (int)((split ? MSM_COST_TABLE + 32L * MSM_COST_STEP + 64L * MSM_COST_DBL : chain_full) / MSM_COST_MIXED);   // windows of a row that has nothing else to do
       own_rows = (wf + own_cap - 1) / own_cap;
@@ -117,8 +134,28 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
     spare -= own_rows;
     int q = 0, unit_i = 0;                                                                      // next fixed window / unit term to hand out
     auto fixed_slice = [&](MsmRow& w, int want) { w.fw_lo = (uint16_t)q; q = q + want < wf ? q + want : wf; w.fw_hi = (uint16_t)q; };
-    auto blank = [&](MsmRow& w) { w.var_term = -1; w.unit_term = -1; w.pos_lo = w.pos_hi = 0; w.sum = (uint8_t)s; w.glv_slot = 0; w.fw_lo = w.fw_hi = 0; };
-    for (int t = 0; t < L; t++) {
+    auto blank = [&](MsmRow& w) { w.var_term = -1; w.unit_term = -1; w.pos_lo = w.pos_hi = 0; w.sum = (uint8_t)s; w.glv_slot = 0; w.fw_lo = w.fw_hi = 0; w.n_joint = 0; w.reserved = 0; };
+    if (j_rows) {
+      // the terms over the rows, sizes differing by at most one; then the windows poured onto the rows with fewer terms until all are level, the rest spread evenly
+      int gsz[MSM_MAX_FIXED], win[MSM_MAX_FIXED];
+      for (int k = 0, t0 = 0; k < j_rows; k++) { gsz[k] = (L - t0 + (j_rows - k) - 1) / (j_rows - k); t0 += gsz[k]; win[k] = 0; }
+      const long per_term = MSM_COST_TABLE + 64L * MSM_COST_JADD;
+      int left = wf;
+      for (int k = 0; k < j_rows && left > 0; k++) {
+        const int room = (int)((long)(gsz[0] - gsz[k]) * per_term / MSM_COST_MIXED);             // gsz[0] is the largest group
+        win[k] = room < left ? room : left; left -= win[k];
+      }
+      for (int k = 0; left > 0; k = (k + 1) % j_rows) { const int share = (left + (j_rows - k) - 1) / (j_rows - k); win[k] += share; left -= share; }
+      for (int k = 0, t0 = 0; k < j_rows; k++) {
+        if (r + 1 > MSM_MAX_ROWS) return false;
+        MsmRow& w = p.row[r++];
+        blank(w);
+        w.var_term = (int8_t)t0; w.n_joint = (uint8_t)gsz[k]; w.pos_lo = 0; w.pos_hi = 128; w.glv_slot = (uint8_t)slot; slot += gsz[k]; t0 += gsz[k];
+        if (unit_i < sh.n_unit[s]) w.unit_term = sh.unit_term[s][unit_i++];
+        fixed_slice(w, win[k]);
+      }
+    }
+    for (int t = 0; t < (j_rows ? 0 : L); t++) {
       if (r + 2 > MSM_MAX_ROWS) return false;
       MsmRow& lo = p.row[r++];
       blank(lo);
@@ -153,7 +190,8 @@ inline int msm_plan_chain(const MsmPlan& p) {
   for (int r = 0; r < p.n_rows; r++) {
     const MsmRow& w = p.row[r];
     int c = (w.fw_hi - w.fw_lo) * MSM_COST_MIXED + (w.unit_term >= 0 ? MSM_COST_MIXED : 0);
-    if (w.var_term >= 0) c += MSM_COST_TABLE + (w.pos_hi - w.pos_lo) / 2 * MSM_COST_STEP + w.pos_lo * MSM_COST_DBL;
+    if (w.n_joint) c += w.n_joint * (MSM_COST_TABLE + 64 * MSM_COST_JADD) + 128 * MSM_COST_DBL;
+    else if (w.var_term >= 0) c += MSM_COST_TABLE + (w.pos_hi - w.pos_lo) / 2 * MSM_COST_STEP + w.pos_lo * MSM_COST_DBL;
     if (c > worst) worst = c;
   }
   return worst;
@@ -165,8 +203,9 @@ inline int msm_plan_chain(const MsmPlan& p) {
 // point operations for the table, against one (doubling + addition) per position for the one-bit form: 0.75 of the chain.  The table lives where TAB puts
 // it (k_g1_msm_rows: 15 x 28 dwords of global memory per lane -- one contiguous 108-byte read per step, issued before the doublings; the host test keeps it
 // in an array).  The halves are first shifted so that position pos_hi - 1 is the top bit.  pos_lo, pos_hi even and uniform over the wavefront.
+// the 15 non-zero combinations i P1 + j P2 at index 4 i + j, P1 = +-P, P2 = +-phi(P)
 template <class TAB>
-BN_HD G1Proj g1_mul_glv_w2_range(const G1Aff& P, const uint32_t k1[4], bool neg1, const uint32_t k2[4], bool neg2, int pos_lo, int pos_hi, TAB& tab) {
+BN_HD void glv_w2_table(const G1Aff& P, bool neg1, bool neg2, TAB& tab) {
   G1Aff P1 = P, P2;
   P1.y = fp_select(neg1, fp_neg(P.y), P.y);
   P2.x = fp_mul(P.x, fp_from_limbs(BN_GLV_BETA)); P2.y = fp_select(neg2, fp_neg(P.y), P.y);
@@ -182,6 +221,10 @@ BN_HD G1Proj g1_mul_glv_w2_range(const G1Aff& P, const uint32_t k1[4], bool neg1
       for (int j = 1; j < 4; j++) tab.put(4 * i + j, g1_add(tab.get(4 * i), tab.get(j)));
   }
   tab.fence();
+}
+template <class TAB>
+BN_HD G1Proj g1_mul_glv_w2_range(const G1Aff& P, const uint32_t k1[4], bool neg1, const uint32_t k2[4], bool neg2, int pos_lo, int pos_hi, TAB& tab) {
+  glv_w2_table(P, neg1, neg2, tab);
   uint32_t a[4], b[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) { a[i] = k1[i]; b[i] = k2[i]; }
@@ -225,11 +268,50 @@ BN_HD G1Proj g1_mul_glv_w2(const G1Aff& P, const uint32_t* k1, bool neg1, const 
 // IO supplies the item's data: term(t, P, k1, k2, flags) -- the affine point, the GLV halves and the flag byte (bit 0: the point is the identity, bits 1 / 2:
 // signs; for a unit term bit 1 is the sign) of term t; scalar_byte(t, w) -- byte w (weight 2^(8 w)) of the canonical scalar of fixed term t;
 // entry(tab, w, d) -- multiple d + 1 of window w of key table `tab`.
+// ---- a joint row: sum_j (+-k1_j +- k2_j lambda) P_j for n_joint terms of a sum, Straus' way -- every term gets its 15-entry table (slot j of the row's scratch), then
+// 64 steps of  acc <- 4 acc + sum_j T_j[digit_j]: ONE pair of doublings per step whatever the number of terms.  The scalar words are re-read per step (io.kword:
+// eight words per term would be 56 registers for seven terms) and, like the table entry of the NEXT addition, fetched while the current addition runs.
+template <class IO, class TAB>
+BN_HD G1Proj msm_joint_eval(const MsmPlan& plan, const MsmRow& row, IO& io, TAB& glv) {
+  const int s = row.sum, g = row.n_joint;
+  uint32_t dead = 0;                                   // bit j: term j's point is the identity, its digits count as zero
+  for (int j = 0; j < g; j++) {
+    G1Aff P; uint32_t k1[4], k2[4]; uint32_t fl;
+    io.term(plan.var_list[s][row.var_term + j], P, k1, k2, fl);
+    if (fl & 1) dead |= 1u << j;
+    TAB tj = glv.slot(j);
+    glv_w2_table(P, (fl & 2) != 0, (fl & 4) != 0, tj);
+  }
+  // digit of term j at step st: bits 127 - 2 st and 126 - 2 st of each half (the position is odd: both bits sit in one word)
+  auto digit = [&](int st, int j) -> uint32_t {
+    const int ph = 127 - 2 * st, w = ph >> 5, sh = (ph & 31) - 1, t = plan.var_list[s][row.var_term + j];
+    const uint32_t idx = (((io.kword(t, 0, w) >> sh) & 3u) << 2) | ((io.kword(t, 1, w) >> sh) & 3u);
+    return ((dead >> j) & 1u) ? 0u : idx;
+  };
+  G1Proj acc = g1_identity();
+  uint32_t idx = digit(0, 0);
+  G1Proj q = glv.slot(0).get(idx != 0 ? idx : 1u);
+  int st = 0, j = 0;
+  for (int k = 0; k < 64 * g; k++) {
+    int jn = j + 1, stn = st;
+    if (jn == g) { jn = 0; stn = st + 1; }
+    uint32_t idx_n = 0; G1Proj qn = q;
+    if (stn < 64) { idx_n = digit(stn, jn); qn = glv.slot(jn).get(idx_n != 0 ? idx_n : 1u); }
+    if (j == 0) acc = g1_dbl(g1_dbl(acc));
+    const G1Proj c = g1_add(acc, q);
+    const bool take = idx != 0;
+    acc.x = fp_select(take, c.x, acc.x); acc.y = fp_select(take, c.y, acc.y); acc.z = fp_select(take, c.z, acc.z);
+    idx = idx_n; q = qn; j = jn; st = stn;
+  }
+  return acc;
+}
+
 template <class IO, class TAB>
 BN_HD G1Proj msm_row_eval(const MsmPlan& plan, int r, IO& io, TAB& glv) {
   const MsmRow& row = plan.row[r];
   G1Proj acc = g1_identity();
-  if (row.var_term >= 0) {
+  if (row.n_joint) acc = msm_joint_eval(plan, row, io, glv);
+  else if (row.var_term >= 0) {
     G1Aff P; uint32_t k1[4], k2[4]; uint32_t fl;
     io.term(row.var_term, P, k1, k2, fl);
     if (fl & 1) {

@@ -66,7 +66,7 @@ def _plonk_cases(O, fixtures, rng, per_fixture):
 
 def test_plonk_plans_agree_and_the_lane_pairing_path(pkg, O, fixtures):
     """The PlonK batch plans against each other through bn254_set_plonk_params: eight chains of 5040-proof passes, the measured default, ONE pass of the whole batch --
-    at 41 472 proofs that pass is above the cooperative kernel's range, so the pairing check runs on the lane kernels (k_miller_run_fixed2: the whole two-pair Miller
+    at 41 472 and 53 000 proofs that pass is above the cooperative kernel's range, so the pairing check runs on the lane kernels (k_miller_run_fixed2: the whole two-pair Miller
     loop in one launch, then the final-exponentiation program) and the MSM launches take their unsplit row form.  Same status bytes, and those are the oracle's."""
     rng = random.Random(41)
     cases, vk = _plonk_cases(O, fixtures, rng, 5)
@@ -76,7 +76,7 @@ def test_plonk_plans_agree_and_the_lane_pairing_path(pkg, O, fixtures):
     k = len(cases)
     pvk = pkg.PreparedPlonkVk(vk)
     try:
-        for n in (12000, 41472):
+        for n in (12000, 41472, 53000):     # 53 000 in one pass: the MSM launches walk the variable terms of a sum in JOINT rows
             reps, tail = divmod(n, k)
             p, q, want = pb * reps + pb[:904 * tail], ib * reps + ib[:64 * tail], exp * reps + exp[:tail]
             for plan in (dict(piece=5040, workers=8, big_from=1 << 30), dict(big_from=0), dict(piece=5040, workers=1, big_from=1, big_piece=65536),
@@ -141,7 +141,7 @@ def test_plonk_other_key_shapes_vs_oracle(pkg, O, fixtures):
         stride = max(len(p) for p, _ in cases)
         pvk = pkg.PreparedPlonkVk(key)
         assert pvk.n_public == npub
-        for total in (1, 257, 5041):
+        for total in (1, 257, 5041, 49200):        # 49 200: joint rows over this key shape's terms
             reps = -(-total // len(cases))
             sel = (cases * reps)[:total]
             pb = b"".join(p.ljust(stride, b"\0") for p, _ in sel)

@@ -27,7 +27,7 @@ def _shape_ints(sums):
     return (C.c_int * len(out))(*out)
 
 
-def _run(hostsim, L, O, rng, sums, n_terms, n_pad, budget, zero_scalar_terms=(), identity_terms=()):
+def _run(hostsim, L, O, rng, sums, n_terms, n_pad, budget, zero_scalar_terms=(), identity_terms=(), joint_g=0):
     g = O.g1_gen()
     n_tabs = 1 + max([b for _, _, f in sums for _, b in f] + [0])
     bases = [O.g1_mul(g, rng.randrange(1, R)) for _ in range(n_tabs)]
@@ -66,7 +66,7 @@ def _run(hostsim, L, O, rng, sums, n_terms, n_pad, budget, zero_scalar_terms=(),
             recs.append(bytes(129))
     out = (C.c_uint8 * (64 * len(sums)))()
     info = (C.c_int * 5)()
-    assert hostsim.hs_msm_rows(out, info, _shape_ints(sums), b"".join(recs), b"".join(bases), n_pad, budget) == 1
+    assert hostsim.hs_msm_rows_joint(out, info, _shape_ints(sums), b"".join(recs), b"".join(bases), n_pad, budget, joint_g) == 1
     got = bytes(out)
     for s in range(len(sums)):
         assert got[64 * s:64 * s + 64] == acc[s], (sums, n_pad, budget, s)
@@ -102,16 +102,37 @@ def test_msm_rows_odd_shapes(hostsim, pkg, O):
     _run(hostsim, L, O, rng, [([0], [1], [(2 + i, i % 3) for i in range(7)])], 9, 64, 65536)
 
 
+def test_msm_joint_rows_vs_oracle(hostsim, pkg, O):
+    """Large launches: up to joint_g variable terms of a sum in ONE row that shares the doublings of a step between them (Straus; bn254_msm.h::msm_joint_eval), the
+    fixed windows on rows of their own.  The PlonK shapes with groups of 2 / 4 / 8, zero scalars and identity points inside a group, a sum of one term, odd shapes."""
+    L = pkg.lib()
+    rng = random.Random(33)
+    q = 1
+    s1 = [([0, q + 6, q + 7, q + 8, q + 9], [], [(q + i, i) for i in range(6)])]
+    s2 = [([0, 1, 2, 3, 6 + q, 8 + q, 9 + q], [], [(4, 6), (5, 7), (6, 9), (7 + q, 8)]), ([11 + q], [10 + q], [])]
+    i1 = _run(hostsim, L, O, rng, s1, 10 + q, 65536, 65536, joint_g=4)
+    assert i1[1] == 5 and i1[0] <= 5                       # five table slots, two joint rows (3 + 2 terms) + rows of fixed windows
+    i2 = _run(hostsim, L, O, rng, s2, 12 + q, 65536, 65536, zero_scalar_terms=(2,), identity_terms=(0, 9 + q), joint_g=4)
+    assert i2[1] == 8 and i2[4] == 1                       # seven terms in two joint rows (4 + 3), the second sum's one term a joint row of its own with the unit term
+    _run(hostsim, L, O, rng, s2, 12 + q, 65536, 65536, zero_scalar_terms=(1, 3), joint_g=8)
+    _run(hostsim, L, O, rng, s2, 12 + q, 65536, 65536, joint_g=2)
+    _run(hostsim, L, O, rng, s1, 10 + q, 65536, 65536, identity_terms=(0, q + 6, q + 7, q + 8, q + 9), joint_g=8)      # every point of the group the identity
+    _run(hostsim, L, O, rng, [([0, 1, 2], [3], [])], 4, 65536, 65536, joint_g=3)
+    _run(hostsim, L, O, rng, [([0], [], [(1, 0)]), ([2, 3], [], [])], 4, 65536, 65536, joint_g=2)
+    # a split launch ignores the group size
+    assert _run(hostsim, L, O, rng, s1, 10 + q, 4096, 65536, joint_g=4)[0] == 12
+
+
 def _plan(L, n_qcp, stage, n, budget=0):
     rows, var = C.c_int(), C.c_int()
     scratch = C.c_size_t()
     chain = C.c_int()
     sums, fixed = (C.c_int * 2)(), (C.c_int * 2)()
-    desc = (C.c_int * (32 * 8))()
+    desc = (C.c_int * (32 * 9))()
     L.bn254_dbg_plonk_msm_plan.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     assert L.bn254_dbg_plonk_msm_plan(n_qcp, stage, n, budget, C.byref(rows), C.byref(var), C.byref(scratch), C.byref(chain), sums, fixed, desc) == 0
-    return rows.value, var.value, scratch.value, chain.value, list(sums), list(fixed), [list(desc[8 * r:8 * r + 8]) for r in range(rows.value)]
+    return rows.value, var.value, scratch.value, chain.value, list(sums), list(fixed), [list(desc[9 * r:9 * r + 9]) for r in range(rows.value)]
 
 
 def test_plonk_msm_plans_cover_every_term_once(pkg):
@@ -122,7 +143,7 @@ def test_plonk_msm_plans_cover_every_term_once(pkg):
         for stage in (1, 2):
             n_var = (4 + q) if stage == 1 else 8
             n_fixed = [6, 0] if stage == 1 else [3 + q, 0]
-            for n in (1, 63, 64, 65, 1000, 2048, 2520, 2521, 4095, 4096, 4097, 5040, 5041, 8192, 65536):
+            for n in (1, 63, 64, 65, 1000, 2048, 2520, 2521, 4095, 4096, 4097, 5040, 5041, 8192, 49151, 49152, 49153, 65536):
                 rows, var, scratch, chain, sums, fixed, desc = _plan(L, q, stage, n)
                 n_pad = (n + 63) // 64 * 64
                 assert rows <= 32 and fixed == n_fixed and sum(sums) == rows
@@ -134,7 +155,15 @@ def test_plonk_msm_plans_cover_every_term_once(pkg):
                 units = []
                 windows = [set(), set()]
                 slots = set()
-                for r, (vt, lo, hi, ut, s, slot, flo, fhi) in enumerate(desc):
+                for r, (vt, lo, hi, ut, s, slot, flo, fhi, jmask) in enumerate(desc):
+                    if jmask:                                  # a joint row: its terms over all 128 positions, one table slot each
+                        assert vt == -1 and (lo, hi) == (0, 128) and not split
+                        for t in range(32):
+                            if jmask >> t & 1:
+                                cover.setdefault(t, []).append((0, 128))
+                                assert slot not in slots
+                                slots.add(slot)
+                                slot += 1
                     if vt >= 0:
                         assert lo % 2 == 0 and hi % 2 == 0 and lo < hi <= 128
                         cover.setdefault(vt, []).append((lo, hi))

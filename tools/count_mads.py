@@ -126,20 +126,33 @@ def model_components(name, ins):
     groups = [g for g in groups if g[2] > 0]
     comp, in_loops = {}, 0
     if name == "k_g1_msm_rows":
+        # Two copies of the variable-term code, in address order: the JOINT rows (a loop over the row's terms that holds a table head + the 3 x 3 table loop, then
+        # the step loop: a conditional pair of doublings + one addition per term and step) and the single-term rows (table, step loop, trailing doublings); then
+        # the mixed additions of the fixed windows.
+        steps = sorted((h, c) for h, l, c in groups if 4300 <= c <= 4600)
+        assert len(steps) == 2, ("k_g1_msm_rows: a joint and a single step loop expected", groups)
+        joint_tab = [(h, c) for h, l, c in groups if 7500 <= c <= 8800]
+        assert len(joint_tab) == 1 and joint_tab[0][0] < steps[0][0], ("k_g1_msm_rows: the joint rows' table loop expected first", groups)
         for h, l, c in groups:
-            key = "step" if 4300 <= c <= 4600 else "table_add" if 1950 <= c <= 2050 else "dbl" if 1150 <= c <= 1350 else "mixed" if 1700 <= c <= 1900 else None
+            if (h, c) == steps[0] or (h, c) == joint_tab[0]:
+                continue
+            key = "step" if (h, c) == steps[1] else "table_add" if 1950 <= c <= 2050 else "dbl" if 1150 <= c <= 1350 else "mixed" if 1700 <= c <= 1900 else None
             if key == "table_add" and comp.get(key) == c:
-                continue                                  # the 3 x 3 table loop: the outer loop holds nothing but the inner one
+                continue                                  # the 3 x 3 table loops (two copies, outer loops that hold nothing but the inner one)
             assert key and key not in comp, ("k_g1_msm_rows: loop layout changed", c, comp)
             comp[key] = c; in_loops += c
         assert set(comp) == {"step", "table_add", "dbl", "mixed"}, comp
+        in_loops += steps[0][1] + joint_tab[0][1]
         rest = len(mads) - in_loops
         comp["unit"] = comp["mixed"]                      # the unit term: one mixed addition outside the loops
         comp["table_head"] = rest - comp["unit"]          # multiples of P and phi(P): 2 doublings, 2 mixed additions, beta x
+        comp["joint_add"] = steps[0][1] - 2 * comp["dbl"]     # a joint row's step: one pair of doublings + this per term
+        assert abs(joint_tab[0][1] - comp["table_add"] - comp["table_head"]) <= 64 and 1900 <= comp["joint_add"] <= 2050, (joint_tab, comp)
         full = comp["table_head"] + 9 * comp["table_add"] + 64 * comp["step"]
         return {"static_mads": len(mads), "components": comp, "mads_per_proof_launch": float(full), "unmodelled": [],
                 "model": "row kernel: multiply-adds per loop body (complete addition %(table_add)d x9 for the window table, two-bit step %(step)d, doubling %(dbl)d, mixed addition "
-                         "%(mixed)d per fixed-base byte window / unit term; table head %(table_head)d); mads_per_proof_launch = ONE unsplit variable row (table + 64 steps); a "
+                         "%(mixed)d per fixed-base byte window / unit term; table head %(table_head)d; joint rows: %(joint_add)d per term and step + one pair of doublings per step); "
+                         "mads_per_proof_launch = ONE unsplit variable row (table + 64 steps); a "
                          "launch is priced from its plan" % comp}
     if name == "k_g1_sum_affine":
         # two loops hold a complete addition each: the rows of a lane, the butterfly steps over a quad of lanes (four lanes per item for small batches)

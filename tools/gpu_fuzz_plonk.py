@@ -45,9 +45,9 @@ def main():
     oracle_s = time.time() - t0
     pvk = pkg.PreparedPlonkVk(vk)
     # the limits of round 4's forms: split rows while 2 x variable terms x lanes <= 65536 (KZG launch: 4096 proofs, digest launch: 6528), four lanes per row sum up to
-    # 8192 (two sums) / 16384 proofs (one), passes of <= 5040 proofs up to 9000 per call, one pass up to 20 000, two up to 40 000, passes of 65 536 above; and round 3's
+    # 8192 (two sums) / 16384 proofs (one), passes of <= 5040 proofs up to 9000 per call, one pass up to 20 000, two up to 40 000, passes of 65 536 above, joint MSM rows from 49 089 proofs per pass; and round 3's
     sizes = [1, 2, 63, 64, 65, 255, 256, 257, 1000, 2166, 2167, 2519, 2520, 2521, 2560, 4095, 4096, 4097, 4332, 4333, 4864, 4865, 5039, 5040, 5041, 5042, 5120, 5121, 6000,
-             6528, 6529, 8192, 8193, 9000, 9001, 10079, 10080, 10081, 12345, 15120, 15121, 16384, 16385, 20000, 20001, 20160, 20161, 21000, 40000, 40001]
+             6528, 6529, 8192, 8193, 9000, 9001, 10079, 10080, 10081, 12345, 15120, 15121, 16384, 16385, 20000, 20001, 20160, 20161, 21000, 40000, 40001, 49088, 49089, 49152, 65536, 65537]
     checked = 0
     classes = {}
     for case in range(args.cases):
