@@ -2,6 +2,7 @@
 oracle's status codes, prepares keys on the host, refuses to verify without a GPU (no CPU fallback), and its synthetic
 workload generator emits gnark bytes that the ORACLE judges exactly as the generator predicts."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -291,6 +292,25 @@ def test_fr_product_forms_agree(pkg):
             x, y = pairs[i]
             got = int.from_bytes(outs[0][32 * i:32 * i + 32], "big")
             assert got == (x % mod) * (y % mod) % mod, (field, hex(x), hex(y))
+
+
+def test_kernel_mads_record_matches_the_built_library(tmp_path):
+    """profiles/kernel_mads.json (tools/count_mads.py: multiply-adds per proof and launch from the gfx950 code objects, what every VALU fraction of the bench line is
+    made of) is the count of the library as BUILT -- same figures, same list of loops the model prices once -- and the figures the rooflines rest on are in their known
+    ranges (round 4: a restructured loop was silently priced as straight-line code and a config's fraction read 0.07 instead of 0.5 until a bench line looked wrong)."""
+    import subprocess, sys
+    out = tmp_path / "kernel_mads.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "count_mads.py")], env=dict(os.environ, COUNT_MADS_OUT=str(out)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    new = json.load(open(out))["kernels"]
+    rec = json.load(open(os.path.join(ROOT, "profiles", "kernel_mads.json")))["kernels"]
+    assert set(new) == set(rec), sorted(set(new) ^ set(rec))
+    for k, e in new.items():
+        assert len(e.get("unmodelled") or []) == len(rec[k].get("unmodelled") or []), (k, e.get("unmodelled"))      # a loop the model does not know shows up here first
+        assert abs(e["mads_per_proof_launch"] - rec[k]["mads_per_proof_launch"]) <= 1e-6 * max(1.0, rec[k]["mads_per_proof_launch"]), (k, e["mads_per_proof_launch"], rec[k]["mads_per_proof_launch"])
+    for k, lo, hi in (("k_miller_run", 2.4e6, 2.7e6), ("k_g16_msm_partial_comb", 3.5e7, 4.2e7), ("k_coop12_miller_g16", 5.3e6, 5.9e6), ("k_coop12_miller_fixed", 4.2e6, 4.8e6),
+                      ("k_f12_mul", 7.5e3, 9.0e3), ("k_g1_msm_rows", 2.9e5, 3.3e5), ("k_miller_run_fixed2", 8.0e5, 1.1e6), ("k_g16_prepare", 1.0e5, 2.6e5)):
+        assert lo <= new[k]["mads_per_proof_launch"] <= hi, (k, new[k]["mads_per_proof_launch"])
 
 
 def test_plonk_plan(pkg):
