@@ -105,12 +105,14 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
   uint32_t* wl = lds + wave * 64 * PREP_LDS_ROW;
   const bool aligned = ((((uintptr_t)proofs) | stride) & 3) == 0;
   if (aligned) {
-    // record j of this wave: one 256-byte contiguous segment per load instruction
-    for (int j = 0; j < 64; j++) {
-      uint32_t rec = first + j;
-      uint32_t v = 0;
-      if (rec < n) v = *(const uint32_t*)(proofs + (size_t)rec * stride + (size_t)lane * 4);
-      wl[j * PREP_LDS_ROW + lane] = v;
+    // record j of this wave: one 256-byte contiguous segment per load instruction; SIXTEEN records per step, so that sixteen loads are in flight together (one
+    // record at a time compiled to load / wait / store: 64 dependent round trips to HBM per wavefront)
+    for (int j0 = 0; j0 < 64; j0 += 16) {
+      uint32_t v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const uint32_t rec = first + (uint32_t)(j0 + u); v[u] = rec < n ? *(const uint32_t*)(proofs + (size_t)rec * stride + (size_t)lane * 4) : 0u; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) wl[(j0 + u) * PREP_LDS_ROW + lane] = v[u];
     }
   } else {
     for (int j = 0; j < 64; j++) {
@@ -197,23 +199,22 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
       }
       // byte j of the big-endian scalar is sw[j / 4] >> (8 (j % 4)); window wi (weight 2^(8 wi)) is byte 31 - wi.  The bytes are
       // consumed from the low end of sw[0] and the 256-bit array is shifted down by 8 each time: no dynamic register indexing.
-      for (int j = 0; j < 32; j++) {
-        const int wi = 31 - j;
-        uint32_t dig = sw[0] & 0xff;
+      // The 80-byte table entry of window j + 1 (18 digits + 2 pad, 16-byte aligned: five 16-byte loads per lane) is in flight while the addition of window j
+      // runs (round 4: load, wait, add per window left the read's latency exposed 64 times per proof with two wavefronts per SIMD to hide it).
+      auto next_digit = [&]() -> uint32_t {
+        const uint32_t dg = sw[0] & 0xff;
 #pragma unroll
         for (int k = 0; k < 7; k++) sw[k] = (sw[k] >> 8) | (sw[k + 1] << 24);
         sw[7] >>= 8;
-        if (dig != 0) {
-          // 80-byte table entry (18 digits + 2 pad), 16-byte aligned: five 16-byte loads per lane
-          const int4* e = (const int4*)(msm_tab + ((size_t)(s * 32 + wi) * 255 + (dig - 1)) * MSM_ENTRY_DWORDS);
-          int4 v0 = e[0], v1 = e[1], v2 = e[2], v3 = e[3], v4 = e[4];
-          G1Aff q;
-          q.x.v[0] = v0.x; q.x.v[1] = v0.y; q.x.v[2] = v0.z; q.x.v[3] = v0.w; q.x.v[4] = v1.x; q.x.v[5] = v1.y; q.x.v[6] = v1.z; q.x.v[7] = v1.w;
-          q.x.v[8] = v2.x; q.y.v[0] = v2.y; q.y.v[1] = v2.z; q.y.v[2] = v2.w; q.y.v[3] = v3.x; q.y.v[4] = v3.y; q.y.v[5] = v3.z; q.y.v[6] = v3.w;
-          q.y.v[7] = v4.x; q.y.v[8] = v4.y;
-          BN_SETB(q.x, 1.0, 0.5); BN_SETB(q.y, 1.0, 0.5);
-          L = g1_add_mixed(L, q);
-        }
+        return dg;
+      };
+      uint32_t dig = next_digit();
+      G1Aff q = msm_entry(msm_tab, (size_t)(s * 32 + 31) * 255 + (dig ? dig - 1 : 0));
+      for (int j = 0; j < 32; j++) {
+        uint32_t dn = 0; G1Aff qn = q;
+        if (j + 1 < 32) { dn = next_digit(); qn = msm_entry(msm_tab, (size_t)(s * 32 + 30 - j) * 255 + (dn ? dn - 1 : 0)); }
+        if (dig != 0) L = g1_add_mixed(L, q);
+        dig = dn; q = qn;
       }
     }
   }

@@ -184,7 +184,20 @@ def model_kernel(name, ins):
     groups = [g for g in groups if g[2] > 0]
     notes, weight_ranges = [], []   # (lo, hi, factor): instructions in [lo, hi] are multiplied by factor (innermost-first, nested factors multiply)
     unmodelled = []
+    prepare_windows = None
+    if name == "k_g16_prepare":
+        # the public-input MSM of the 2-input path: n_public x 32 byte windows, a table addition unless the byte is zero.  The software-pipelined loop (the next
+        # window's table entry in flight during the addition) is laid out with several back edges over ONE copy of the addition: the union of those regions
+        # executes n_public x 32 times, however the compiler nests them
+        w = [(h, l[-1]) for h, l, c in groups if 1700 <= c <= 1900]
+        if w:
+            prepare_windows = (min(a for a, _ in w), max(b for _, b in w))
+            assert 1700 <= count_in(mads, *prepare_windows) <= 1900, ("k_g16_prepare: more than one addition in the window loops", w)
+            weight_ranges.append((prepare_windows[0], prepare_windows[1], N_PUBLIC * 32.0 * 255.0 / 256.0))
+            notes.append("byte-window loop: %d inputs x 32 windows, table addition (%d mads) unless the byte is zero" % (N_PUBLIC, count_in(mads, *prepare_windows)))
     for h, latches, c in groups:
+        if prepare_windows and prepare_windows[0] <= h and latches[-1] <= prepare_windows[1]:
+            continue
         inner = [g for g in groups if g is not (h, latches, c) and h <= g[0] and g[1][-1] <= latches[-1] and (g[0], g[1][-1]) != (h, latches[-1])]
         own = c - sum(g[2] for g in inner if not any(o is not g and o[0] <= g[0] and g[1][-1] <= o[1][-1] and o in inner for o in inner))
         first = count_in(mads, h, latches[0])
