@@ -706,11 +706,23 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=512, in_flight=T
             d2 = time.perf_counter() - t2
         assert all(o == st for o in outs), "PlonK: statuses differ between concurrent calls"
         in_flight[str(k)] = {"value": k * rounds * batch / d2, "unit": "proofs/s", "ms_per_round": d2 * 1e3 / rounds, "rounds": rounds}
+    # BN254_FLAG_RLC on the PlonK entry (honoured from 8192 proofs per pass): the pairing checks of a pass batched over groups of 64 proofs -- same status bytes, checked
+    rlc_mode = None
+    if batch >= 8192:
+        for _ in range(max(1, warmup)):
+            st2 = pvk.verify_batch(pb, ib, flags=pkg.FLAG_RLC)
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            st2 = pvk.verify_batch(pb, ib, flags=pkg.FLAG_RLC)
+        d2 = time.perf_counter() - t2
+        assert st2 == st, "PlonK: BN254_FLAG_RLC changed a status byte"
+        rlc_mode = {"workload": "the same batch with BN254_FLAG_RLC (one pairing check per 64 proofs, exact fallback on groups that fail: none in this batch -- its invalid proofs fail before the pairing check)",
+                    "unit": "proofs/s", "exact": batch * steps / dt, "rlc": batch * steps / d2, "speedup": dt / d2, "ms_per_step": d2 * 1e3 / steps}
     pvk.close()
     return {"workload": "BASELINE configs[3]: PlonK batch %d, 904-byte proofs (the reference's fixtures + mutations), 2 public inputs, 1/8 invalid; host buffers in, status bytes out" % batch,
             "value": batch * steps / dt, "unit": "proofs/s", "ms_per_step": dt * 1e3 / steps, "steps": steps, "batch": batch,
             "status_check": "first %d statuses == oracle; %d ACCEPT of %d" % (m, batch - batch // 8, batch),
-            "calls_in_flight": in_flight,
+            "calls_in_flight": in_flight, "rlc_mode": rlc_mode,
             "roofline": roofline, "pairing_check": pairing, "valu_whole_path": whole, "plan": acct["plan"], "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "hbm_roofline": {"algorithmic_bytes_per_proof": 904 + 64 + 1, "achieved": batch * steps / dt * 969 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": batch * steps / dt * 969 / 1e9 / HBM_PEAK_GBPS},
             # a rate from fewer than 256 proofs is not quoted: the entry at 4096 proofs carries the baseline of this workload

@@ -154,15 +154,22 @@ int bn254_groth16_proof_write_raw(const uint8_t a[64], const uint8_t b[128], con
  * Status bytes: BN254_ACCEPT or an error code; PlonK never returns BN254_REJECT (plonk/verify.rs:316).  Each proof occupies
  * proof_stride bytes (>= its length: 904 for the SP1 circuits); public inputs are n_public x 32 big-endian bytes per proof.
  * Threads: a prepared key may be used from several host threads at once.  Each call takes one of the key's eight per-device contexts (stream, device
- * buffers, pinned staging) per sub-batch -- one per 5040 proofs, up to all eight -- and a call that finds too few free waits; up to eight batches of 4096 are therefore in
+ * buffers, pinned staging) per sub-batch of its plan (bn254_set_plonk_params) and a call that finds too few free waits; up to eight batches of 4096 are therefore in
  * flight on one key, which is how a verifier that always has requests pending should drive it: a single batch of that size is a chain of latency-bound
- * launches (0.76 M proofs/s), two in flight give 1.04 M proofs/s, four 1.3 M. */
+ * launches (1.06 M proofs/s), two in flight give 1.2-1.3 M proofs/s, four 1.4-1.6 M; calls of 65 536 proofs and more run at 2.5-3.1 M proofs/s. */
 typedef struct bn254_plonk_pvk bn254_plonk_pvk;
 int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** out);
 void bn254_plonk_vk_free(bn254_plonk_pvk* pvk);
 size_t bn254_plonk_vk_num_public(const bn254_plonk_pvk* pvk);
 int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                              size_t n_public, size_t n, uint8_t* status, int device);
+/* The same with flags.  BN254_FLAG_RLC (round 4): the pairing checks of a pass are batched across proofs -- every proof's two points carry a random 128-bit
+ * weight (drawn per call, folded into the scalars of the multi-scalar multiplication at no group cost), the weighted points of the 64 proofs of a wavefront are
+ * added and ONE pairing check runs per group; the proofs of a group that fails are then checked one by one, so the status bytes are those of the exact path
+ * except that a forged proof is accepted with probability ~2^-127 (weights are odd 128-bit values; the same kind of batching the reference applies to a proof's two openings, plonk/kzg.rs:149-187).
+ * Honoured from 8192 proofs per pass (BN254_PLONK_RLC_MIN); below, the one remaining pairing is the same latency-bound launch and the flag changes nothing. */
+int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                                   size_t n_public, size_t n, uint8_t* status, int device, unsigned flags);
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                        size_t n_public, uint8_t* status);
 /* Knobs of the PlonK batch plan (process-wide, atomic; -1 leaves a knob alone; initial values from BN254_PLONK_PIECE / _WORKERS / _BIG_FROM / _BIG_PIECE, read once at

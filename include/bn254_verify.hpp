@@ -187,9 +187,10 @@ class PreparedPlonkVk {
   PreparedPlonkVk(const PreparedPlonkVk&) = delete;
   PreparedPlonkVk& operator=(const PreparedPlonkVk&) = delete;
   size_t num_public() const { return bn254_plonk_vk_num_public(h_); }
-  Bytes verify_batch(const uint8_t* proofs, size_t stride, const uint8_t* public_inputs, size_t n_public, size_t n, int device = 0) const {
+  // flags: BN254_FLAG_RLC batches the pairing checks of a pass across proofs (same status bytes; honoured from 8192 proofs per pass)
+  Bytes verify_batch(const uint8_t* proofs, size_t stride, const uint8_t* public_inputs, size_t n_public, size_t n, int device = 0, unsigned flags = 0) const {
     Bytes st(n ? n : 1);
-    detail::check(bn254_plonk_verify_batch(h_, proofs, stride, public_inputs, n_public, n, st.data(), device));
+    detail::check(bn254_plonk_verify_batch_flags(h_, proofs, stride, public_inputs, n_public, n, st.data(), device, flags));
     st.resize(n);
     return st;
   }

@@ -132,9 +132,14 @@ impl PreparedPlonkVk {
     }
     pub fn num_public(&self) -> usize { unsafe { sys::bn254_plonk_vk_num_public(self.h) } }
     pub fn verify_batch_raw(&self, proofs: &[u8], proof_stride: usize, public_inputs: &[u8], n_public: usize, n: usize, device: i32) -> Result<Vec<Status>, Error> {
+        self.verify_batch_flags(proofs, proof_stride, public_inputs, n_public, n, device, 0)
+    }
+    /// `flags`: `sys::BN254_FLAG_RLC` batches the pairing checks of a pass across proofs (one check per 64 proofs, exact fallback on the groups that fail;
+    /// honoured from 8192 proofs per pass).  Same status bytes as `verify_batch_raw`.
+    pub fn verify_batch_flags(&self, proofs: &[u8], proof_stride: usize, public_inputs: &[u8], n_public: usize, n: usize, device: i32, flags: u32) -> Result<Vec<Status>, Error> {
         assert!(proofs.len() >= n * proof_stride && public_inputs.len() >= n * n_public * 32);
         let mut st = vec![0u8; n];
-        check(unsafe { sys::bn254_plonk_verify_batch(self.h, proofs.as_ptr(), proof_stride, public_inputs.as_ptr(), n_public, n, st.as_mut_ptr(), device) })?;
+        check(unsafe { sys::bn254_plonk_verify_batch_flags(self.h, proofs.as_ptr(), proof_stride, public_inputs.as_ptr(), n_public, n, st.as_mut_ptr(), device, flags) })?;
         Ok(st.into_iter().map(Status::from).collect())
     }
 }

@@ -88,6 +88,7 @@ def lib():
         L.bn254_plonk_vk_num_public.argtypes = [C.c_void_p]
         L.bn254_plonk_vk_num_public.restype = C.c_size_t
         L.bn254_plonk_verify_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        L.bn254_plonk_verify_batch_flags.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_uint]
         L.bn254_plonk_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p]
         L.bn254_groth16_kernel_kind_name.restype = C.c_char_p
         L.bn254_groth16_kernel_kind_name.argtypes = [C.c_int]
@@ -142,13 +143,14 @@ class PreparedPlonkVk:
         _check(lib().bn254_plonk_vk_prepare(bytes(vk_bytes), len(vk_bytes), C.byref(self._h)))
         self.n_public = lib().bn254_plonk_vk_num_public(self._h)
 
-    def verify_batch(self, proofs, public_inputs, n=None, proof_stride=904, n_public=None, device=0):
-        """proofs: n * proof_stride bytes; public_inputs: n * n_public * 32 bytes.  Returns n status bytes."""
+    def verify_batch(self, proofs, public_inputs, n=None, proof_stride=904, n_public=None, device=0, flags=0):
+        """proofs: n * proof_stride bytes; public_inputs: n * n_public * 32 bytes.  Returns n status bytes.  flags: FLAG_RLC batches the pairing checks of a pass across
+        proofs (honoured from 8192 proofs per pass; exact fallback on the groups that fail)."""
         n_public = self.n_public if n_public is None else n_public
         if n is None:
             n = len(proofs) // proof_stride
         st = (C.c_uint8 * max(n, 1))()
-        _check(lib().bn254_plonk_verify_batch(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device))
+        _check(lib().bn254_plonk_verify_batch_flags(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device, flags))
         return bytes(st)[:n]
 
     def last_timing(self, device=0):

@@ -38,7 +38,9 @@ hipError_t bn254_plonk_dev_init(int device);
 hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs, size_t stride, const uint8_t* d_inputs, size_t n_public, size_t n, const uint32_t lam_key[11],
                                      void* d_work, void* d_terms, uint8_t* d_flags, int T1, hipStream_t s);
 hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
-                                     void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s);
+                                     void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, const uint32_t* weight_key, hipStream_t s);
+hipError_t bn254_launch_plonk_group_sums(int32_t* ws, const uint8_t* status, size_t n, int32_t* grp_ws, uint8_t* grp_status, int e_p0, int inf0, int e_p1, int inf1, hipStream_t s);
+hipError_t bn254_launch_plonk_group_scatter(uint8_t* status, size_t n, const uint8_t* grp_status, uint32_t* n_failed, hipStream_t s);
 
 hipError_t bn254_launch_plonk_dbg_zeta(const void* d_work, size_t n, uint8_t* d_zeta, uint8_t* d_status, hipStream_t s);
 
@@ -241,6 +243,8 @@ struct PlonkCtx {
   MsmTerm* h_terms = nullptr; uint8_t *h_flags = nullptr, *h_status = nullptr, *h_inf = nullptr; uint32_t* h_words = nullptr;
   // device-side stages (bn254_k_plonk.hip): the batch's proofs and inputs in device memory (through a pinned copy), per-proof state between the stages
   uint8_t *d_in = nullptr, *h_in = nullptr; size_t in_cap = 0; void* d_work = nullptr;
+  // BN254_FLAG_RLC: the pairing checks of a pass batched over groups of 64 proofs -- the groups' points and status bytes in a workspace of their own, failed groups counted
+  int32_t* grp_ws = nullptr; uint8_t* grp_status = nullptr; uint32_t* d_fail = nullptr; uint32_t* h_fail = nullptr;
 };
 struct PlonkDev {
   bool ready = false;
@@ -277,14 +281,14 @@ struct bn254_plonk_pvk {
   PlonkKey key;
   std::vector<int32_t> tab0, tab1, one;
   std::vector<int32_t> fixed_tabs;     // bn254_host.hpp::build_window_table of every key point that enters an MSM (bn254_plonk.hpp::plonk_table_point)
-  MsmShape shape1, shape2;             // term kinds of the two MSM launches (plonk_msm1_shape / plonk_msm2_shape)
+  MsmShape shape1, shape2, shape2_rlc; // term kinds of the two MSM launches (plonk_msm1_shape / plonk_msm2_shape; _rlc: the weighted form of BN254_FLAG_RLC)
   mutable std::mutex mu;               // protects the map below (lookup / insertion / first upload); batches take contexts from the device's pool
   mutable std::map<int, PlonkDev> dev;
 };
 static void plonk_ctx_free(PlonkCtx& c) {
-  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status, c.d_in, c.d_work};
+  void* ptrs[] = {c.ws, c.part, c.glv_tab, c.terms, c.flags, c.words, c.inf, c.status, c.d_in, c.d_work, c.grp_ws, c.grp_status, c.d_fail};
   for (auto q : ptrs) if (q) (void)hipFree(q);
-  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words, c.h_in};
+  void* hp[] = {c.h_terms, c.h_flags, c.h_status, c.h_inf, c.h_words, c.h_in, c.h_fail};
   for (auto q : hp) if (q) (void)hipHostFree(q);
   if (c.stream) (void)hipStreamDestroy(c.stream);
   if (c.aux) (void)hipStreamDestroy(c.aux);
@@ -346,6 +350,8 @@ static int shape_var(const MsmShape& sh) { int v = 0; for (int s = 0; s < sh.n_s
 static std::atomic<long> g_plonk_piece{[] { long v = env_long("BN254_PLONK_PIECE", 5040); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
 static std::atomic<int> g_plonk_workers{[] { long v = env_long("BN254_PLONK_WORKERS", PLONK_WORKERS); return (int)(v < 1 ? 1 : (v > PLONK_WORKERS ? PLONK_WORKERS : v)); }()};
 static std::atomic<long> g_plonk_big_from{[] { long v = env_long("BN254_PLONK_BIG_FROM", 0); return v < 0 ? 0 : v; }()};      // 0: the measured plan of plonk_auto_plan
+// BN254_FLAG_RLC on the PlonK entry: honoured from this many proofs per pass (BN254_PLONK_RLC_MIN gives the initial value)
+static std::atomic<long> g_plonk_rlc_min{[] { long v = env_long("BN254_PLONK_RLC_MIN", 8192); return v < 64 ? 64 : v; }()};
 static std::atomic<long> g_plonk_big_piece{[] { long v = env_long("BN254_PLONK_BIG_PIECE", PLONK_MAX_LAUNCH); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
 // the plan of a batch (bn254_plonk_verify_batch): sub-batches side by side, proofs per sub-batch, proofs per pass of a sub-batch
 // The default plan by batch size (profiles/r04_plonk_plan_sweep.txt, one MI355X): chains of 5040-proof passes side by side up to ~9000 proofs (8192: 7.06 ms against
@@ -386,9 +392,10 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n, s
   // drop the old buffers and forget them BEFORE anything is allocated: if an allocation below fails the context is left empty (cap = 0, every
   // pointer null), never with a stale pointer that a later call or plonk_ctx_free would free a second time
   auto drop = [&c] {
-    void** dp[] = {(void**)&c.ws, (void**)&c.part, (void**)&c.glv_tab, (void**)&c.terms, (void**)&c.flags, (void**)&c.words, (void**)&c.inf, (void**)&c.status, (void**)&c.d_work};
+    void** dp[] = {(void**)&c.ws, (void**)&c.part, (void**)&c.glv_tab, (void**)&c.terms, (void**)&c.flags, (void**)&c.words, (void**)&c.inf, (void**)&c.status, (void**)&c.d_work,
+                   (void**)&c.grp_ws, (void**)&c.grp_status, (void**)&c.d_fail};
     for (auto q : dp) { if (*q) (void)hipFree(*q); *q = nullptr; }
-    void** hp[] = {(void**)&c.h_terms, (void**)&c.h_flags, (void**)&c.h_status, (void**)&c.h_inf, (void**)&c.h_words};
+    void** hp[] = {(void**)&c.h_terms, (void**)&c.h_flags, (void**)&c.h_status, (void**)&c.h_inf, (void**)&c.h_words, (void**)&c.h_fail};
     for (auto q : hp) { if (*q) (void)hipHostFree(*q); *q = nullptr; }
     c.cap = 0; c.glv_lanes = 0;
   };
@@ -396,7 +403,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n, s
   const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
   const size_t tmax = (size_t)(TT > T1 ? TT : T1);
   // window-table scratch of the variable rows: the bound over every batch size up to `need` and both launches (plonk_scratch_lanes)
-  const int v1 = shape_var(pvk->shape1), v2 = shape_var(pvk->shape2);
+  const int v1 = shape_var(pvk->shape1), v2 = shape_var(pvk->shape2_rlc);        // (the weighted form of the second launch has one variable term more)
   const size_t tab_lanes = plonk_scratch_lanes(need, v1 > v2 ? v1 : v2);
   hipError_t e = hipSuccess;
   auto dm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes ? bytes : 1); };
@@ -411,11 +418,16 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n, s
   dm((void**)&c.inf, need);
   dm((void**)&c.status, need);
   dm((void**)&c.d_work, need * bn254_plonk_work_bytes());
+  const size_t groups = (need / 64 + 255) / 256 * 256;                             // need is a multiple of 256: need / 64 groups, rounded to whole workgroups
+  dm((void**)&c.grp_ws, groups * (size_t)G16_WS_BYTES_PER_PROOF);
+  dm((void**)&c.grp_status, groups);
+  dm((void**)&c.d_fail, sizeof(uint32_t));
   hm((void**)&c.h_terms, need * tmax * sizeof(MsmTerm));
   hm((void**)&c.h_flags, need * tmax);
   hm((void**)&c.h_status, need);
   hm((void**)&c.h_inf, need);
   hm((void**)&c.h_words, need * 16 * sizeof(uint32_t));
+  hm((void**)&c.h_fail, sizeof(uint32_t));
   if (e != hipSuccess) { drop(); return set_err(BN254_E_HIP, std::string("PlonK context allocation: ") + hipGetErrorString(e)); }
   c.cap = need;
   return BN254_OK;
@@ -1211,7 +1223,7 @@ int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** o
       th.emplace_back([&, t_]() { for (int i = (int)t_; i < nt; i += (int)hw) build_window_table(p->fixed_tabs.data() + (size_t)i * per, plonk_table_point(p->key, i)); });
     for (auto& x : th) x.join();
   }
-  plonk_msm1_shape(p->key, p->shape1); plonk_msm2_shape(p->key, p->shape2);
+  plonk_msm1_shape(p->key, p->shape1); plonk_msm2_shape(p->key, p->shape2); plonk_msm2_shape(p->key, p->shape2_rlc, true);
   *out = p;
   return BN254_OK;
 }
@@ -1360,7 +1372,7 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
 // The same sub-batch with BOTH host stages on the device (bn254_k_plonk.hip): one H2D copy of the proofs and inputs, stage 1 -> digest MSM -> stage 2 ->
 // folding MSMs -> pairing check on the context's stream without a host wait in between, one D2H copy of the status bytes.
 static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c, int device, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
-                            size_t n_public, size_t m, uint8_t* status) {
+                            size_t n_public, size_t m, uint8_t* status, unsigned flags) {
   HIPCK(hipSetDevice(device));
   const PlonkKey& key = pvk->key;
   const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key), TT = T2 + 2;
@@ -1387,14 +1399,33 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
   int mrc = plonk_msm(d, c, pvk->shape1, m, T1, true, &c.last_lanes[0], c.tk[2]);
   if (mrc) return mrc;
   HIPCK(hipEventRecord(c.tk[3], c.stream));
-  e = bn254_launch_plonk_stage2(d->d_key, d_proofs, proof_stride, m, c.d_work, c.words, c.inf, c.terms, c.flags, c.status, TT, T2, c.stream);
+  // BN254_FLAG_RLC: the pairing checks of the pass batched over groups of 64 proofs -- honoured from g_plonk_rlc_min proofs per pass (below, the one remaining
+  // pairing is the same latency-bound launch as the per-proof checks and nothing is gained)
+  const bool rlc = (flags & BN254_FLAG_RLC) != 0 && m >= (size_t)g_plonk_rlc_min.load();
+  e = bn254_launch_plonk_stage2(d->d_key, d_proofs, proof_stride, m, c.d_work, c.words, c.inf, c.terms, c.flags, c.status, TT, T2, rlc ? lam_key : nullptr, c.stream);
   HIPCK(hipEventRecord(c.tk[4], c.stream));
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 2 launch: ") + hipGetErrorString(e));
-  mrc = plonk_msm(d, c, pvk->shape2, m, TT, false, &c.last_lanes[1], c.tk[5]);
+  mrc = plonk_msm(d, c, rlc ? pvk->shape2_rlc : pvk->shape2, m, TT, false, &c.last_lanes[1], c.tk[5]);
   if (mrc) return mrc;
   HIPCK(hipEventRecord(c.tk[6], c.stream));
-  e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
-  if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
+  bool exact = !rlc;
+  if (rlc) {
+    // group sums (weighted points of the 64 proofs of a wavefront) -> one pairing check per group -> pending proofs of passed groups accepted; the proofs of a
+    // failed group stay pending and the exact check below runs on exactly their wavefronts (every other wavefront of its kernels exits at once)
+    const size_t groups = (m + 63) / 64;
+    HIPCK(hipMemsetAsync(c.d_fail, 0, sizeof(uint32_t), c.stream));
+    e = bn254_launch_plonk_group_sums(c.ws, c.status, m, c.grp_ws, c.grp_status, VE_LX_ELEM, BN254_ST_LINF, VE_CX_ELEM, BN254_ST_LINF2, c.stream);
+    if (e == hipSuccess) e = bn254_launch_pairing2_fixed(c.grp_ws, c.grp_status, groups, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
+    if (e == hipSuccess) e = bn254_launch_plonk_group_scatter(c.status, m, c.grp_status, c.d_fail, c.stream);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("joint pairing launch: ") + hipGetErrorString(e));
+    HIPCK(hipMemcpyAsync(c.h_fail, c.d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipStreamSynchronize(c.stream));
+    exact = *c.h_fail != 0;
+  }
+  if (exact) {
+    e = bn254_launch_pairing2_fixed(c.ws, c.status, m, d->tab0, d->tab1, d->one, BN254_ERR_PAIRING_FAILED, c.stream, c.aux, c.ev_fork, c.ev_join);
+    if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
+  }
   HIPCK(hipEventRecord(c.tk[7], c.stream));
   HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
@@ -1427,7 +1458,12 @@ int bn254_plonk_last_timing(const bn254_plonk_pvk* pvk, int device, float ms[BN2
 
 int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                              size_t n_public, size_t n, uint8_t* status, int device) {
+  return bn254_plonk_verify_batch_flags(pvk, proofs, proof_stride, public_inputs, n_public, n, status, device, 0);
+}
+int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                                   size_t n_public, size_t n, uint8_t* status, int device, unsigned flags) {
   if (!pvk || (n && (!proofs || !status)) || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (flags & ~(unsigned)BN254_FLAG_RLC) return set_err(BN254_E_BAD_ARG, "unknown flag (the PlonK batch entry knows BN254_FLAG_RLC)");
   if (n == 0) return BN254_OK;
   PlonkDev* d;
   int rc;
@@ -1457,7 +1493,7 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
     const size_t lo = (size_t)w * per, hi = lo + per < n ? lo + per : n;
     for (size_t off = lo; off < hi; off += pass_cap) {
       const size_t m = hi - off < pass_cap ? hi - off : pass_cap;
-      int r = dev_stages ? plonk_run_device(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off)
+      int r = dev_stages ? plonk_run_device(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off, flags)
                          : plonk_run(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
                                      (hw + workers - 1) / workers);
       if (r) {

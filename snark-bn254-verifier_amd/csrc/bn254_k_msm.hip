@@ -134,9 +134,63 @@ k_g1_sum_affine(const int32_t* __restrict__ part, int first, int count, uint32_t
   }
 }
 
+// ---- BN254_FLAG_RLC on the PlonK path: the pairing checks of a pass batched over the 64 proofs of a wavefront ---------------------------------------------------
+// Every pending proof i arrives with P0_i, P1_i already multiplied by its random weight (k_plonk_stage2).  One wavefront per group of 64 consecutive proofs: each
+// lane takes its proof's point (the identity if the proof is decided already or its point is the identity), six butterfly steps of complete additions leave the
+// group's sum in every lane, lane 0 writes it -- affine, in the pairing stage's layout -- to the GROUP workspace (n_groups "proofs") with the group's status byte:
+// pending (+ identity flags), or decided (ACCEPT) when none of its proofs is pending.
+__global__ void __launch_bounds__(256, 2)
+k_plonk_group_sums(int32_t* ws, uint32_t n, const uint8_t* __restrict__ status, int32_t* grp_ws, uint32_t n_groups, uint8_t* __restrict__ grp_status,
+                   int e_p0, int inf0, int e_p1, int inf1) {
+  const uint32_t gl = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t g = gl >> 6, lane = gl & 63u, i = g * 64u + lane;
+  const uint8_t st = i < n ? status[i] : (uint8_t)0;
+  const bool pend = (st & BN254_ST_PENDING) != 0;
+  DevWs w(ws, n, i < n ? i : DEAD_LANE);
+  DevWs wg(grp_ws, n_groups, (lane == 0 && g < n_groups) ? g : DEAD_LANE);
+  uint32_t flags = 0;
+#pragma unroll 1
+  for (int which = 0; which < 2; which++) {
+    G1Aff p; p.x = w.ld(which ? e_p1 : e_p0); p.y = w.ld((which ? e_p1 : e_p0) + 1);
+    const bool skip = !pend || (st & (which ? inf1 : inf0)) != 0;
+    G1Proj L = g1_from_affine(p);
+    const G1Proj id = g1_identity();
+    L.x = fp_select(skip, id.x, L.x); L.y = fp_select(skip, id.y, L.y); L.z = fp_select(skip, id.z, L.z);
+    for (int m = 1; m < 64; m <<= 1) L = g1_add(L, g1_shfl_xor(L, m));
+    const bool l_inf = g1_is_identity(L);
+    G1Aff La = g1_to_affine(L);
+    La.y = fp_select(l_inf, fp_one(), La.y);
+    wg.st(which ? e_p1 : e_p0, La.x); wg.st((which ? e_p1 : e_p0) + 1, La.y);
+    if (l_inf) flags |= (uint32_t)(which ? inf1 : inf0);
+  }
+  const bool any = __builtin_amdgcn_ballot_w64(pend) != 0;
+  if (lane == 0 && g < n_groups) grp_status[g] = any ? (uint8_t)(BN254_ST_PENDING | flags) : (uint8_t)BN254_ST_ACCEPT;
+}
+// ... and back: a pending proof whose group passed is accepted; the proofs of a failed group stay pending (the exact per-proof check then runs on exactly
+// those wavefronts) and the group counts once in *n_failed
+__global__ void __launch_bounds__(256, 2)
+k_plonk_group_scatter(uint8_t* __restrict__ status, uint32_t n, const uint8_t* __restrict__ grp_status, uint32_t* __restrict__ n_failed) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t gs = grp_status[i >> 6];
+  if (status[i] & BN254_ST_PENDING) {
+    if (gs == BN254_ST_ACCEPT) status[i] = BN254_ST_ACCEPT;
+  }
+  if ((i & 63u) == 0 && gs != BN254_ST_ACCEPT) atomicAdd(n_failed, 1u);
+}
+
 }  // namespace bn254
 
 using namespace bn254;
+hipError_t bn254_launch_plonk_group_sums(int32_t* ws, const uint8_t* status, size_t n, int32_t* grp_ws, uint8_t* grp_status, int e_p0, int inf0, int e_p1, int inf1, hipStream_t s) {
+  const size_t groups = (n + 63) / 64;
+  hipLaunchKernelGGL(k_plonk_group_sums, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, s, ws, (uint32_t)n, status, grp_ws, (uint32_t)groups, grp_status, e_p0, inf0, e_p1, inf1);
+  return hipGetLastError();
+}
+hipError_t bn254_launch_plonk_group_scatter(uint8_t* status, size_t n, const uint8_t* grp_status, uint32_t* n_failed, hipStream_t s) {
+  hipLaunchKernelGGL(k_plonk_group_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, status, (uint32_t)n, grp_status, n_failed);
+  return hipGetLastError();
+}
 // lanes of window-table scratch (G1_GLV_TAB_BYTES_PER_LANE each) a launch of this plan over n items needs
 size_t bn254_g1_msm_scratch_lanes(const MsmPlan& plan, size_t n) { return (size_t)plan.n_var_rows * ((n + 63) & ~(size_t)63); }
 // part: plan.n_rows * 27 * n dwords; glv_tab: bn254_g1_msm_scratch_lanes(plan, n) lanes; tabs: the key's window tables

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(128) k_plonk_stage1(const PlonkKey* __restrict
 
 __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict__ key, const uint8_t* __restrict__ proofs, size_t stride, uint32_t n,
                                                      PlonkWork* __restrict__ work, const uint32_t* __restrict__ lin_words, const uint8_t* __restrict__ lin_inf,
-                                                     MsmTerm* __restrict__ terms, uint8_t* __restrict__ flags, uint8_t* __restrict__ status, int TT, int T2, uint32_t lane_stride) {
+                                                     MsmTerm* __restrict__ terms, uint8_t* __restrict__ flags, uint8_t* __restrict__ status, int TT, int T2, uint32_t lane_stride,
+                                                     ChaChaKey w_key, int weighted) {
   const uint8_t* unused_inputs;
   const uint8_t* my_proof = pl_stage_lds(proofs, stride, proofs, 0, n, lane_stride, &unused_inputs);
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -159,7 +160,16 @@ __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict_
     wk.pr.raw = my_proof;
     uint32_t lw[16];
     for (int q = 0; q < 16; q++) lw[q] = lin_words[(size_t)i * 16 + q];
-    plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2);
+    if (weighted) {
+      // BN254_FLAG_RLC: the proof's weight in the pass's joint pairing check -- 128 bits of the call's second ChaCha20 stream, forced odd (non-zero)
+      uint32_t rw[4];
+      chacha20_block4(rw, w_key, i);
+      uint8_t rb[16];
+      rw[0] |= 1u;
+      for (int j = 0; j < 4; j++) { rb[15 - 4 * j] = (uint8_t)rw[j]; rb[14 - 4 * j] = (uint8_t)(rw[j] >> 8); rb[13 - 4 * j] = (uint8_t)(rw[j] >> 16); rb[12 - 4 * j] = (uint8_t)(rw[j] >> 24); }
+      const FrM wgt = fr_ctx().from_be_reduce(rb, 16);
+      plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2, &wgt);
+    } else plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2);
     status[i] = BN254_ST_PENDING;
   } else {
     status[i] = (uint8_t)wk.status;
@@ -198,12 +208,17 @@ hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs,
                      (PlonkWork*)d_work, (MsmTerm*)d_terms, d_flags, T1, ls);
   return hipGetLastError();
 }
+// weight_key != nullptr: BN254_FLAG_RLC -- every scalar of the proof's two sums carries the proof's weight (the call's key with another nonce word: a stream of its own)
 hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
-                                     void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, hipStream_t s) {
+                                     void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int T2, const uint32_t* weight_key /* 11 words or nullptr */, hipStream_t s) {
+  ChaChaKey wkey;
+  for (int i = 0; i < 8; i++) wkey.k[i] = weight_key ? weight_key[i] : 0u;
+  for (int i = 0; i < 3; i++) wkey.nonce[i] = weight_key ? weight_key[8 + i] : 0u;
+  wkey.nonce[2] ^= 0x00524c43u;      // "RLC": not the stream the KZG batching scalars come from
   const uint32_t ls = pl_lane_stride(stride, 0);
   if (16 + 64 * (size_t)ls > 65536) { hipError_t ae = hipFuncSetAttribute((const void*)k_plonk_stage2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 + 64 * (size_t)ls)); if (ae != hipSuccess) return ae; }
   hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words,
-                     d_lin_inf, (MsmTerm*)d_terms, d_flags, d_status, TT, T2, ls);
+                     d_lin_inf, (MsmTerm*)d_terms, d_flags, d_status, TT, T2, ls, wkey, weight_key ? 1 : 0);
   return hipGetLastError();
 }
 

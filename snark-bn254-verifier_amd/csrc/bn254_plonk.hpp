@@ -785,7 +785,9 @@ inline void plonk_msm1_shape(const PlonkKey& vk, MsmShape& sh) {
   for (int i = 0; i < 4; i++) sh.var_term[0][sh.n_var[0]++] = (int8_t)(q + 6 + i);
 }
 // stage 2 (term order of plonk_stage2): P0 = lin l r o | s1 s2 qcp[0..q) | z | kzg_g1 | batch_h zs_h ;  P1 = batch_h (scalar -1) | zs_h
-inline void plonk_msm2_shape(const PlonkKey& vk, MsmShape& sh) {
+// joint = the pairing checks of a pass are batched across proofs (BN254_FLAG_RLC): every scalar of both sums carries the proof's random weight, so the -1 of
+// batch_h is a scalar like the others and the term a variable one
+inline void plonk_msm2_shape(const PlonkKey& vk, MsmShape& sh, bool joint = false) {
   memset(&sh, 0, sizeof sh);
   const int q = (int)vk.n_qcp;
   sh.n_sums = 2;
@@ -796,7 +798,8 @@ inline void plonk_msm2_shape(const PlonkKey& vk, MsmShape& sh) {
   sh.var_term[0][sh.n_var[0]++] = (int8_t)(6 + q);
   sh.fixed_term[0][sh.n_fixed[0]] = (int8_t)(7 + q); sh.fixed_tab[0][sh.n_fixed[0]++] = PLONK_TAB_KZG_G1;
   sh.var_term[0][sh.n_var[0]++] = (int8_t)(8 + q); sh.var_term[0][sh.n_var[0]++] = (int8_t)(9 + q);
-  sh.unit_term[1][sh.n_unit[1]++] = (int8_t)(10 + q);
+  if (joint) sh.var_term[1][sh.n_var[1]++] = (int8_t)(10 + q);
+  else sh.unit_term[1][sh.n_unit[1]++] = (int8_t)(10 + q);
   sh.var_term[1][sh.n_var[1]++] = (int8_t)(11 + q);
 }
 
@@ -980,8 +983,10 @@ PL_HD int plonk_stage1(const PlonkKey& vk, const uint8_t* proof, size_t proof_le
 //   P0 = sum_i gamma^i D_i + lambda Z - fe G_kzg + zeta H_batch + lambda zeta omega H_zs      (plonk_stage2_terms(vk) terms)
 //   P1 = -(H_batch + lambda H_zs)                                                              (2 terms)
 // for the check e(P0, g2[0]) e(P1, g2[1]) == 1 (kzg.rs:175-187).  t1 must be t0 + plonk_stage2_terms(vk): one flag array (t0_inf) covers both.
+// weight != nullptr (BN254_FLAG_RLC): every scalar of P0 and P1 is multiplied by *weight, a random non-zero value of the call -- the pass then checks
+//   e(sum_i w_i P0_i, g2[0]) e(sum_i w_i P1_i, g2[1]) == 1  over groups of proofs (GT has prime order: a group passes iff each of its proofs does, up to 2^-128).
 PL_HD void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWork& wk, const uint32_t lin_words[16], bool lin_inf,
-                         MsmTerm* t0, uint8_t* t0_inf, MsmTerm* t1) {
+                         MsmTerm* t0, uint8_t* t0_inf, MsmTerm* t1, const FrM* weight = nullptr) {
   const FrCtx& F = fr_ctx();
   const PlonkProof& pr = wk.pr;
   const int nd = 6 + (int)vk.n_qcp;
@@ -1018,8 +1023,9 @@ PL_HD void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWor
   int np = 0;
   PL_MARK(18);
   for (int j = 0; j < plonk_stage2_terms(vk) + 2; j++) t0_inf[j] = 0;
-  auto put = [&](const G1Aff& p, const FrM& k) { put_term(t0[np], p, k, &t0_inf[np]); np++; };
-  auto fix = [&](const FrM& k) { put_fixed(t0[np], k, &t0_inf[np]); np++; };              // key-side points: fixed-base tables (plonk_msm2_shape)
+  auto wt = [&](const FrM& k) -> FrM { return weight ? F.mul(k, *weight) : k; };
+  auto put = [&](const G1Aff& p, const FrM& k) { put_term(t0[np], p, wt(k), &t0_inf[np]); np++; };
+  auto fix = [&](const FrM& k) { put_fixed(t0[np], wt(k), &t0_inf[np]); np++; };          // key-side points: fixed-base tables (plonk_msm2_shape)
   t0_inf[np] = lin_inf ? 1 : 0; put(lin, gi[0]);
   put(pr.lro[0], gi[1]); put(pr.lro[1], gi[2]); put(pr.lro[2], gi[3]);
   fix(gi[4]); fix(gi[5]);                                                                  // s1, s2
@@ -1029,8 +1035,9 @@ PL_HD void plonk_stage2(const PlonkKey& vk, const uint8_t* proof, const PlonkWor
   put(pr.batch_h, wk.zeta);
   put(pr.zs_h, F.mul(lam, shifted));
   // P1 = -(H_batch + lambda H_zs): the two terms follow P0's (t1 = t0 + plonk_stage2_terms(vk), their flags likewise); the first is the bare point, negated
-  put_unit(t1[0], pr.batch_h, true, &t0_inf[np]);
-  put_term(t1[1], pr.zs_h, F.neg(lam), &t0_inf[np + 1]);
+  if (weight) put_term(t1[0], pr.batch_h, F.neg(*weight), &t0_inf[np]);
+  else put_unit(t1[0], pr.batch_h, true, &t0_inf[np]);
+  put_term(t1[1], pr.zs_h, wt(F.neg(lam)), &t0_inf[np + 1]);
   PL_MARK(19);
 }
 

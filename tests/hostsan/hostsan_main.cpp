@@ -60,10 +60,31 @@ hipError_t bn254_launch_plonk_stage1(const void*, const uint8_t* d_proofs, size_
   return hipSuccess;
 }
 hipError_t bn254_launch_plonk_stage2(const void*, const uint8_t*, size_t, size_t n, void*, const uint32_t* words, const uint8_t* inf, void* d_terms, uint8_t* d_flags, uint8_t* d_status, int TT, int,
-                                     hipStream_t) {
+                                     const uint32_t* weight_key, hipStream_t) {
+  if (weight_key) (void)weight_key[10];
   g_launches++;
   (void)words[n * 16 - 1]; (void)inf[n - 1];
   memset(d_terms, 0, n * (size_t)TT * sizeof(MsmTerm)); memset(d_flags, 0, n * (size_t)TT); memset(d_status, BN254_ST_PENDING, n);
+  return hipSuccess;
+}
+// BN254_FLAG_RLC on the PlonK path: the group stage reads / writes exactly what the real kernels do (ASan checks the extents); a proof whose first status bit pattern
+// is "pending" and whose index is a multiple of 1000 makes its group fail, so that the exact fallback runs
+hipError_t bn254_launch_plonk_group_sums(int32_t* ws, const uint8_t* status, size_t n, int32_t* grp_ws, uint8_t* grp_status, int, int, int, int, hipStream_t) {
+  g_launches++;
+  const size_t groups = (n + 63) / 64;
+  (void)ws[0]; (void)status[n - 1];
+  memset(grp_ws, 0x33, groups * (size_t)G16_WS_BYTES_PER_PROOF);
+  for (size_t g = 0; g < groups; g++) grp_status[g] = BN254_ST_PENDING;
+  return hipSuccess;
+}
+hipError_t bn254_launch_plonk_group_scatter(uint8_t* status, size_t n, const uint8_t* grp_status, uint32_t* n_failed, hipStream_t) {
+  g_launches++;
+  for (size_t i = 0; i < n; i++) {
+    const bool group_failed = ((i / 64) % 16) == 3;
+    (void)grp_status[i / 64];
+    if ((status[i] & BN254_ST_PENDING) && !group_failed) status[i] = BN254_ST_ACCEPT;
+    if (i % 64 == 0 && group_failed) (*n_failed)++;
+  }
   return hipSuccess;
 }
 hipError_t bn254_launch_plonk_dbg_zeta(const void*, size_t n, uint8_t* z, uint8_t* s, hipStream_t) { memset(z, 0, 32 * n); memset(s, 1, n); return hipSuccess; }
@@ -203,6 +224,11 @@ int main(int argc, char** argv) {
     for (auto& x : th) x.join();
     CHECK(bn254_plonk_verify_batch(pk, pp.data(), pstride, pi.data(), 2, pn, ps.data(), 0) == 0);
     CHECK(ps[pn] == 0xAB);
+    // ... and with the pairing checks batched across proofs (group workspace, failure counter, the exact fallback on the groups the stand-in fails)
+    CHECK(bn254_plonk_verify_batch_flags(pk, pp.data(), pstride, pi.data(), 2, pn, ps.data(), 0, BN254_FLAG_RLC) == 0);
+    CHECK(ps[pn] == 0xAB);
+    CHECK(bn254_plonk_verify_batch_flags(pk, pp.data(), pstride, pi.data(), 2, 100, ps.data(), 0, BN254_FLAG_RLC) == 0);          // below the threshold: the flag is ignored
+    CHECK(bn254_plonk_verify_batch_flags(pk, pp.data(), pstride, pi.data(), 2, 100, ps.data(), 0, 0x80u) != 0);                   // an unknown flag is refused
     for (size_t fail = 1; fail < 60; fail++) {
       bn254_plonk_pvk* q = nullptr;
       CHECK(bn254_plonk_vk_prepare(pvkb.data(), pvkb.size(), &q) == 0);

@@ -88,6 +88,49 @@ def test_plonk_plans_agree_and_the_lane_pairing_path(pkg, O, fixtures):
         pvk.close()
 
 
+def test_plonk_rlc_flag_gives_the_exact_statuses(pkg, O, fixtures):
+    """BN254_FLAG_RLC on the PlonK entry: the pairing checks of a pass batched over the 64 proofs of a wavefront (weights folded into the MSM scalars, one check per
+    group, the exact check on the groups that fail).  Statuses must equal the exact path's and the oracle's: all-valid batches (no fallback), batches with every
+    status class incl. proofs that fail ONLY the pairing check (tests/kzg_forgery.py: valid points, wrong opening) sprinkled so that some groups fail and some pass,
+    sizes on both sides of the threshold below which the flag is ignored, a pass with joint MSM rows (53 000), several passes in flight (150 000)."""
+    from kzg_forgery import forge, KNOWN_LAMBDA
+    fx, vk = fixtures
+    rng = random.Random(47)
+    cases, _ = _plonk_cases(O, fixtures, rng, 4)
+    f = fx["fibonacci_plonk"]
+    proof = bytes.fromhex(f["raw_proof"]); pis = [int(x) for x in f["public_inputs"]]
+    tampered, forged = forge(O, proof, vk, pis, KNOWN_LAMBDA)
+    ib0 = b"".join(be(x) for x in pis)
+    valid = [c for c in cases if O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) == pkg.ACCEPT]
+    assert len(valid) >= 4
+    mixed = cases + [(forged, ib0), (tampered, ib0)]
+    exp_of = {id(c): O.plonk_verify(c[0], vk, [int.from_bytes(c[1][:32], "big"), int.from_bytes(c[1][32:], "big")]) for c in mixed}
+    # the two proofs of tests/kzg_forgery.py fail the pairing check under every batching scalar but the one they were built for (the oracle's default: there the
+    # forged one verifies -- tests/test_gpu_round2.py::test_plonk_rejects_the_known_lambda_forgery has the story); the product draws its own
+    exp_of[id(mixed[-1])] = 8; exp_of[id(mixed[-2])] = 8
+    assert len(set(exp_of.values())) >= 4
+    pvk = pkg.PreparedPlonkVk(vk)
+    try:
+        for n in (8191, 8192, 12345, 53000, 150000):
+            # (a) all valid
+            sel = [valid[i % len(valid)] for i in range(n)]
+            p, q = b"".join(c[0] for c in sel), b"".join(c[1] for c in sel)
+            assert pvk.verify_batch(p, q, n, flags=pkg.FLAG_RLC) == bytes([pkg.ACCEPT]) * n, n
+            # (b) mostly valid, every class somewhere, pairing-only failures in a few groups (and two of them in one group)
+            sel = list(sel)
+            for k in range(0, n, 997):
+                sel[k] = mixed[(k // 997) % len(mixed)]
+            sel[5] = mixed[-1]; sel[6] = mixed[-2]; sel[n - 1] = mixed[-1]
+            p, q = b"".join(c[0] for c in sel), b"".join(c[1] for c in sel)
+            want = bytes(exp_of.get(id(c), pkg.ACCEPT) for c in sel)
+            assert want.count(bytes([8])) >= 3
+            got = pvk.verify_batch(p, q, n, flags=pkg.FLAG_RLC)
+            assert got == want, (n, [(i, got[i], want[i]) for i in range(n) if got[i] != want[i]][:8])
+            assert pvk.verify_batch(p, q, n) == want, n
+    finally:
+        pvk.close()
+
+
 def _reshape_plonk_key(vk, n_qcp, nb_public=None):
     """The SP1 key with another number of BSB22 commitments (the commitment point and its constraint index dropped or repeated) and, optionally, another public-input
     count: layout of plonk/converter.rs:18-119."""
