@@ -54,12 +54,13 @@ def main():
         n = rng.choice(sizes) if rng.random() < 0.8 else rng.randrange(1, 21000)
         valid_share = rng.choice([1.0, 0.9, 0.5, 0.0])
         idx = [rng.randrange(len(base)) if rng.random() < valid_share else rng.randrange(len(pool)) for _ in range(n)]
-        st = pvk.verify_batch(b"".join(pool[i][0] for i in idx), b"".join(pool[i][1] for i in idx))
+        flags = pkg.FLAG_RLC if rng.random() < 0.5 else 0        # half of the cases with the pairing checks batched across proofs (honoured from 8192 proofs per pass)
+        st = pvk.verify_batch(b"".join(pool[i][0] for i in idx), b"".join(pool[i][1] for i in idx), flags=flags)
         exp = bytes(verdict[i] for i in idx)
         assert st == exp, (case, n, [(k, st[k], exp[k]) for k in range(n) if st[k] != exp[k]][:5])
         checked += n
         for b in set(exp): classes[str(b)] = classes.get(str(b), 0) + exp.count(bytes([b]))
-        print(json.dumps({"case": case, "n": n, "valid_share": valid_share, "ok": True}), flush=True)
+        print(json.dumps({"case": case, "n": n, "valid_share": valid_share, "rlc": bool(flags), "ok": True}), flush=True)
     pvk.close()
     print(json.dumps({"cases": args.cases, "pool": len(pool), "pool_verdicts": {str(v): verdict.count(v) for v in sorted(set(verdict))}, "oracle_seconds": round(oracle_s, 1),
                       "status_bytes_checked": checked, "status_classes_seen": classes, "seconds": round(time.time() - t0, 1), "all_ok": True}))
