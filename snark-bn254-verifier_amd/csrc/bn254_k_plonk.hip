@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict_
     wk.pr.raw = my_proof;
     uint32_t lw[16];
     for (int q = 0; q < 16; q++) lw[q] = lin_words[(size_t)i * 16 + q];
+    FrM wgt = {{0, 0, 0, 0}};
     if (weighted) {
       // BN254_FLAG_RLC: the proof's weight in the pass's joint pairing check -- 128 bits of the call's second ChaCha20 stream, forced odd (non-zero)
       uint32_t rw[4];
@@ -167,9 +168,9 @@ __global__ void __launch_bounds__(64) k_plonk_stage2(const PlonkKey* __restrict_
       uint8_t rb[16];
       rw[0] |= 1u;
       for (int j = 0; j < 4; j++) { rb[15 - 4 * j] = (uint8_t)rw[j]; rb[14 - 4 * j] = (uint8_t)(rw[j] >> 8); rb[13 - 4 * j] = (uint8_t)(rw[j] >> 16); rb[12 - 4 * j] = (uint8_t)(rw[j] >> 24); }
-      const FrM wgt = fr_ctx().from_be_reduce(rb, 16);
-      plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2, &wgt);
-    } else plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2);
+      wgt = fr_ctx().from_be_reduce(rb, 16);
+    }
+    plonk_stage2(*key, my_proof, wk, lw, lin_inf[i] != 0, t, fl, t + T2, weighted ? &wgt : nullptr);      // ONE copy of the stage in the kernel (two were 22 us of instruction fetch)
     status[i] = BN254_ST_PENDING;
   } else {
     status[i] = (uint8_t)wk.status;
