@@ -76,6 +76,13 @@ def g16_wide(seed):
 def plonk_batches(seed):
     r = random.Random(seed)
     while time.time() < stop and not errors:
+        if r.random() < 0.05:
+            # a large call with the pairing checks batched across proofs (BN254_FLAG_RLC: one pass of 10 400 proofs = the 5200 twice), beside the small ones
+            st = plonk.verify_batch(ppb * 2, pib * 2, 10400, flags=pkg.FLAG_RLC if r.random() < 0.7 else 0)
+            if st != plonk_ref * 2:
+                errors.append(("plonk rlc batch", 10400, 0))
+            note("plonk_rlc_batch")
+            continue
         n = r.choice([1, 33, 700, 1500, 2500, 4500, 5000, 5200])      # 2500 / 4500 / 5000: the window-table limits of a context
         off = r.randrange(0, 5200 - n + 1)
         st = plonk.verify_batch(ppb[904 * off:904 * (off + n)], pib[64 * off:64 * (off + n)], n)
