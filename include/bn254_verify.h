@@ -167,7 +167,8 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
  * weight (drawn per call, folded into the scalars of the multi-scalar multiplication at no group cost), the weighted points of the 64 proofs of a wavefront are
  * added and ONE pairing check runs per group; the proofs of a group that fails are then checked one by one, so the status bytes are those of the exact path
  * except that a forged proof is accepted with probability ~2^-127 (weights are odd 128-bit values; the same kind of batching the reference applies to a proof's two openings, plonk/kzg.rs:149-187).
- * Honoured from 8192 proofs per pass (BN254_PLONK_RLC_MIN); below, the one remaining pairing is the same latency-bound launch and the flag changes nothing. */
+ * Honoured from 8192 proofs per pass (BN254_PLONK_RLC_MIN); below, the one remaining pairing is the same latency-bound launch and the flag changes nothing.  (The
+ * diagnostic host-thread stages of BN254_PLONK_HOST=1 ignore the flag.)  Any other flag bit is refused with BN254_E_BAD_ARG. */
 int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                                    size_t n_public, size_t n, uint8_t* status, int device, unsigned flags);
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
