@@ -121,6 +121,11 @@ def test_plonk_rlc_flag_gives_the_exact_statuses(pkg, O, fixtures):
             for k in range(0, n, 997):
                 sel[k] = mixed[(k // 997) % len(mixed)]
             sel[5] = mixed[-1]; sel[6] = mixed[-2]; sel[n - 1] = mixed[-1]
+            early = [c for c in mixed if exp_of[id(c)] not in (pkg.ACCEPT, 8)]            # decided before the pairing check
+            for k in range(128, 192):                                                    # a whole group (one wavefront) without a pending proof
+                sel[k] = early[k % len(early)]
+            for k in range(256, 320):                                                    # ... and a group whose every proof fails only the pairing check
+                sel[k] = mixed[-1 - (k & 1)]
             p, q = b"".join(c[0] for c in sel), b"".join(c[1] for c in sel)
             want = bytes(exp_of.get(id(c), pkg.ACCEPT) for c in sel)
             assert want.count(bytes([8])) >= 3
