@@ -647,7 +647,10 @@ def _plonk_accounting(pkg, km, batch, stage_ms):
         ach = sum(r2) * pass_n / (t2 * 1e-3)
         n_lanes = len(r2) * ((pass_n + 63) // 64 * 64)
         out["roofline"] = {"bound": "valu", "kernel": "k_g1_msm_rows (KZG check: P0 and P1)", "unit": "T mad/s", **_peak_fields(), "achieved": ach / 1e12, "frac": ach / VALU_PEAK_MAD_PER_S,
-                           "avg_launch_ms": t2, "rows_per_proof": len(r2), "lanes_per_launch": n_lanes, "executed_mads_per_proof": sum(r2), "longest_row_mads": max(r2), "traffic": None,
+                           "avg_launch_ms": t2, "rows_per_proof": len(r2), "lanes_per_launch": n_lanes, "executed_mads_per_proof": sum(r2), "longest_row_mads": max(r2),
+                           # HBM counter bytes of one launch: per-proof figure of the committed rocprofv3 --pmc passes at 4096 proofs per call (profiles/pmc_traffic_plonk.json: the
+                           # average of the pass's two row launches) x the proofs of this launch; mostly the lanes' window tables (1.7 KB written once, read once per step)
+                           "traffic": (lambda tr: (tr["read_bytes_per_proof"] + tr["write_bytes_per_proof"]) * pass_n if tr else None)((_load_json("pmc_traffic_plonk.json") or {}).get("k_g1_msm_rows")),
                            "note": "achieved = multiply-adds the launched rows EXECUTE (plan rows x loop bodies of the code object) x proofs of the launch / its HIP-event duration; "
                                    "%d lanes = %.2f wavefronts per SIMD, so up to one wavefront per SIMD the launch lasts as long as its longest row (%d multiply-adds)" % (n_lanes, n_lanes / 65536.0, int(max(r2)))}
     tp = stage_ms.get("pairing_check", 0)

@@ -143,6 +143,9 @@ if "k_miller_run" in sq:
                "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 (r04 SQ pass): instructions per wavefront of k_miller_run over the whole Miller loop of 2^18 proofs (all its launches)"},
               open(os.path.join(out, "miller_run_pmc_counts.json"), "w"), indent=1)
 # PlonK, 4096 proofs per batch (the warm-up batches of bench_plonk.py included: per-launch averages)
+plonk_traffic = {"_note": "HBM bytes per PROOF and launch of the PlonK kernels at 4096 proofs per call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled as "
+                          "for the Groth16 rows of pmc_traffic.json); k_g1_msm_rows and k_g1_sum_affine: the average of the pass's two launches (digest, KZG check)"}
 pmc_table("pmcp", 4096, tag + "_plonk4096_pmc_summary.csv",
           "# rocprofv3 --pmc passes (SQ activity | FETCH_SIZE | WRITE_SIZE), each its own run of: python3 tools/bench_plonk.py --batch 4096 --steps 2 --warmup 1 --cpu-sample 0 --no-in-flight "
-          "(PlonK batches of 4096 proofs; per-launch averages; bytes per PROOF of the batch)\n")
+          "(PlonK batches of 4096 proofs; per-launch averages; bytes per PROOF of the batch)\n", plonk_traffic)
+json.dump(plonk_traffic, open(os.path.join(out, "pmc_traffic_plonk.json"), "w"), indent=1, sort_keys=True)
