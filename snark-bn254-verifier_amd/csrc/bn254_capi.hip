@@ -161,7 +161,7 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
     d.ready = true;
   }
   // what a reservation of n proofs needs (bn254_g16_plan.h: the same function the plan probe and its property test read)
-  const G16Alloc need = g16_alloc_for(n, pvk->host.n_k - 1, pvk->host.msm_comb);
+  const G16Alloc need = g16_alloc_for(n, pvk->host.key_inputs(), pvk->host.msm_comb);
   if (need.ws_proofs > d.ws_cap) {
     if (d.ws) HIPCK(hipFree(d.ws));   // hipFree waits for the device: no batch is still using the old workspace
     d.ws = nullptr; d.ws_cap = 0;
@@ -563,7 +563,7 @@ int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn
   if (parse_g16_vk(key, vk, vk_len, (int)mode) != DEC_OK) return set_err(BN254_E_VK, "verifying key does not parse");
   bn254_g16_pvk* p = new (std::nothrow) bn254_g16_pvk();
   if (!p) return set_err(BN254_E_NOMEM, "out of memory");
-  if (!prepare_g16(p->host, key, (int)mode)) { delete p; return set_err(BN254_E_VK, "verifying key has a degenerate G2 element or no K points"); }
+  if (!prepare_g16(p->host, key, (int)mode)) { delete p; return set_err(BN254_E_VK, "no line table for a G2 element of the key (unreachable for a point on the twist: bn254_host.hpp::prepare_g16)"); }
   *out = p;
   return BN254_OK;
 }
@@ -576,7 +576,7 @@ void bn254_groth16_vk_free(bn254_g16_pvk* pvk) {
   }
   delete pvk;
 }
-size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk) { return pvk ? pvk->host.n_k - 1 : 0; }
+size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk) { return pvk ? (pvk->host.n_k ? pvk->host.n_k - 1 : (size_t)-1) : 0; }
 
 int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device) {
   if (!pvk) return set_err(BN254_E_BAD_ARG, "null key");
@@ -615,7 +615,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
   for (size_t off = 0; off < n; off += chunk) {
     size_t m = n - off < chunk ? n - off : chunk;
     G16ChunkPlan plan;
-    if (!g16_plan_chunk(plan, m, pvk->host.n_k - 1, n_public, n_streams, d->single_stream)) return set_err(BN254_E_BAD_ARG, "batch cannot be planned");
+    if (!g16_plan_chunk(plan, m, pvk->host.key_inputs(), n_public, n_streams, d->single_stream)) return set_err(BN254_E_BAD_ARG, "batch cannot be planned");
     const bool wide = plan.wide, concurrent = plan.concurrent, split_small = plan.split_small;
     const int parts = plan.parts;
     // the buffers were sized by ensure_dev (bn254_groth16_reserve or the entry point itself): this path only enqueues, after checking the plan against them
@@ -636,7 +636,7 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       a.inputs = (const uint8_t*)d_inputs + (off + lo) * n_public * 32; a.n_public = (int)n_public; a.n = hi - lo;
       a.ws = d->ws + lo * (size_t)(G16_WS_BYTES_PER_PROOF / 4); a.status = (uint8_t*)d_status + off + lo; a.msm_tab = d->msm; a.k0 = d->k0;
       a.gtab = d->gtab; a.dtab = d->dtab; a.target = d->target;
-      a.inputs_match_key = (n_public + 1 == pvk->host.n_k) ? 1 : 0;
+      a.inputs_match_key = pvk->host.inputs_match(n_public) ? 1 : 0;
       a.strict_scalars = (flags & BN254_FLAG_STRICT_SCALARS) ? 1 : 0;
       a.part_of_larger = parts > 1 ? 1 : 0;
       a.msm_part = wide ? d->msm_part : nullptr;
@@ -802,7 +802,7 @@ static bool rlc_bypass(RlcDev& r) {
 }
 // does a batch of this shape qualify for the RLC mode at all (the adaptive bypass, rlc_bypass, is decided separately, once per call)
 static bool rlc_eligible(const bn254_g16_pvk* pvk, size_t n_public, size_t n, unsigned flags) {
-  return (flags & BN254_FLAG_RLC) && n_public + 1 == pvk->host.n_k && n_public <= (size_t)RLC_MAX_PUBLIC && n >= (size_t)g_rlc_min_batch.load();
+  return (flags & BN254_FLAG_RLC) && pvk->host.inputs_match(n_public) && n_public <= (size_t)RLC_MAX_PUBLIC && n >= (size_t)g_rlc_min_batch.load();
 }
 // one batch on `user`: waits for the previous batch of this (key, device), runs the exact or the RLC pipeline, records busy_ev.
 // use_rlc: -1 = decide here; 0 / 1 = the caller (the host-buffer entry, which must know before it cuts the batch into chunks) has decided
@@ -1162,6 +1162,22 @@ int bn254_groth16_verify_batch_multi(const bn254_g16_pvk* pvk, const uint8_t* pr
   return BN254_OK;
 }
 
+// load_groth16_proof_from_bytes (groth16/converter.rs:14-26) on the host, for the one case in which no kernel can run: a single proof against key bytes that do not
+// load.  A, B, C in this order; per point: every coordinate < p (Field(NotMember)), the curve equation (Group(NotOnCurve)), and for B the r-torsion (Group(NotInSubgroup)).
+static uint8_t g16_proof_loader_status(const uint8_t* p /* 256 bytes */) {
+  auto g1 = [](const uint8_t* b) -> uint8_t {
+    if (!be_lt_p(b) || !be_lt_p(b + 32)) return BN254_ERR_NOT_MEMBER;
+    G1Aff a; a.x = fp_from_be(b); a.y = fp_from_be(b + 32);
+    return g1_on_curve(a) ? BN254_ACCEPT : BN254_ERR_NOT_ON_CURVE;
+  };
+  uint8_t st = g1(p);
+  if (st != BN254_ACCEPT) return st;
+  for (int i = 0; i < 4; i++) if (!be_lt_p(p + 64 + 32 * i)) return BN254_ERR_NOT_MEMBER;
+  G2Aff b; b.x.c1 = fp_from_be(p + 64); b.x.c0 = fp_from_be(p + 96); b.y.c1 = fp_from_be(p + 128); b.y.c0 = fp_from_be(p + 160);
+  if (!g2_on_curve(b)) return BN254_ERR_NOT_ON_CURVE;
+  if (!g2_in_subgroup(b)) return BN254_ERR_NOT_IN_SUBGROUP;
+  return g1(p + 192);
+}
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                          size_t n_public, unsigned mode, uint8_t* status) {
   if (!proof || !vk || !status || mode > 1) return set_err(BN254_E_BAD_ARG, "bad argument");
@@ -1175,10 +1191,10 @@ int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* 
     bn254_g16_pvk* raw = nullptr;
     int rc = bn254_groth16_vk_prepare(vk, vk_len, mode, &raw);
     if (rc == BN254_E_VK) {
-      // the key does not parse: a proof error still wins, so run the proof checks against a throw-away key shape.  Without a
-      // key nothing can be launched; report the key error unless the proof bytes themselves are invalid (checked on the GPU
-      // by the caller's next call with a valid key).  The reference panics in both cases; the status byte says MALFORMED.
-      *status = BN254_ERR_MALFORMED;
+      // the key does not load (lib.rs:46 panics) -- but the proof was loaded first (lib.rs:45), so its loader error wins.  Nothing can be launched without a key: the
+      // loader's checks (< p, curve equation, r-torsion of B; groth16/converter.rs:14-26) run here on the host, once, for this one proof
+      const uint8_t ps = g16_proof_loader_status(proof);
+      *status = ps == BN254_ACCEPT ? (uint8_t)BN254_ERR_MALFORMED : ps;
       return BN254_OK;
     }
     if (rc) return rc;
@@ -1202,7 +1218,7 @@ int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** o
   if (parse_plonk_vk(p->key, vk, vk_len) != DEC_OK) { delete p; return set_err(BN254_E_VK, "PlonK verifying key does not parse"); }
   // line tables of the two KZG G2 points (kzg.rs:175-187: e(P0, g2[0]) e(P1, g2[1]) == 1); target = 1 in GT
   std::vector<FixedLine> t0(BN_ATE_STEPS), t1(BN_ATE_STEPS);
-  if (!fixed_line_table(t0.data(), p->key.kzg_g2[0]) || !fixed_line_table(t1.data(), p->key.kzg_g2[1])) { delete p; return set_err(BN254_E_VK, "degenerate KZG G2 point"); }
+  if (!fixed_line_table(t0.data(), p->key.kzg_g2[0]) || !fixed_line_table(t1.data(), p->key.kzg_g2[1])) { delete p; return set_err(BN254_E_VK, "no line table for a KZG G2 point (unreachable for a point on the twist: bn254_host.hpp::prepare_g16)"); }
   p->tab0.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS); p->tab1.resize((size_t)BN_ATE_STEPS * FIXED_LINE_DWORDS);
   for (int s = 0; s < BN_ATE_STEPS; s++) {
     int32_t* a = p->tab0.data() + (size_t)s * FIXED_LINE_DWORDS; int32_t* b = p->tab1.data() + (size_t)s * FIXED_LINE_DWORDS;
@@ -1529,7 +1545,14 @@ int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk
   if (!pvk) {
     bn254_plonk_pvk* raw = nullptr;
     int rc = bn254_plonk_vk_prepare(vk, vk_len, &raw);
-    if (rc == BN254_E_VK) { *status = BN254_ERR_MALFORMED; return BN254_OK; }
+    if (rc == BN254_E_VK) {
+      // the proof is loaded before the key (lib.rs:70 before :71): its loader error (short buffer, coordinate >= p, off the curve; plonk/converter.rs:121-178) wins
+      // over the key's.  Host work for this one proof: no kernel can run without a key
+      PlonkProof pr;
+      const int ps = parse_plonk_proof(pr, proof, proof_len);
+      *status = ps == PL_OK ? (uint8_t)BN254_ERR_MALFORMED : (uint8_t)ps;
+      return BN254_OK;
+    }
     if (rc) return rc;
     pvk = plonk_key_cache().insert(vk, vk_len, 0, raw);
   }

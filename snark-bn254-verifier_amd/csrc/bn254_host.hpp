@@ -153,7 +153,9 @@ inline int parse_g16_vk(G16Key& vk, const uint8_t* b, size_t n, int mode) {
 
 // ---------------------------------------------------------------- prepared key (host image of what the kernels read)
 struct G16Prepared {
-  size_t n_k = 0;                        // len(vk.K)
+  size_t n_k = 0;                        // len(vk.K); 0 is a key the reference loads and then answers PrepareInputsFailed for every input count (groth16/verify.rs:54-56)
+  size_t key_inputs() const { return n_k ? n_k - 1 : 0; }                       // public inputs the tables are built for
+  bool inputs_match(size_t n_public) const { return n_public + 1 == n_k; }      // groth16/verify.rs:54 (never true for n_k = 0)
   std::vector<int32_t> k0;               // 18
   std::vector<int32_t> gtab, dtab;       // BN_ATE_STEPS * FIXED_LINE_DWORDS
   std::vector<int32_t> target;           // 108
@@ -228,11 +230,18 @@ inline void build_comb_table(int32_t* out /* (1 << G16_COMB_TEETH) * MSM_ENTRY_D
 }
 // mode 0: reference-literal equation  e(A,B) e(L, gamma') e(C, -delta') == e(alpha, -beta')   (groth16/verify.rs:70-77, converter.rs:79)
 // mode 1: gnark                       e(A,B) e(L, -gamma) e(C, -delta)  == e(alpha, beta)
+// Returns false only if a line table cannot be built.  That does not happen for a key that parsed: its G2 elements are ON THE TWIST by construction (y is computed
+// from x, converter.rs:113-133), and for no point of E'(Fp2) other than the identity does a step of the optimal-ate walk meet T = +-S or T = O -- the order of such a point
+// would have to divide one of the walk's partial multipliers (all below 2^66; none is a multiple of a prime factor of #E'(Fp2) = r * 10069 * 5864401 * 1875725156269 * c177),
+// or the Frobenius eigenvalue on one of its prime components would have to equal +-(6u+2) (tests/test_capi_cpu.py::test_line_tables_exist_for_every_twist_point
+// enumerates both).  So "unchecked" key points (off the r-torsion) are computed on exactly as the reference does, by the same group law.
 inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
   out.n_k = vk.k.size();
-  if (out.n_k == 0) return false;
   out.k0.resize(2 * BN_NL);
-  fp_to_limbs(out.k0.data(), vk.k[0].x); fp_to_limbs(out.k0.data() + BN_NL, vk.k[0].y);
+  // a key without K points never reaches prepare_inputs' sum: the generator stands in for K[0] so that the loader checks of the proofs (which come first, lib.rs:45)
+  // still run through the same kernels; every proof that passes them is answered BN254_ERR_INPUT_LEN (inputs_match is never true)
+  G1Aff k0; if (out.n_k) k0 = vk.k[0]; else { k0.x = fp_one(); k0.y = fp_add(fp_one(), fp_one()); }
+  fp_to_limbs(out.k0.data(), k0.x); fp_to_limbs(out.k0.data() + BN_NL, k0.y);
   G2Aff g = (mode == 0) ? vk.gamma : g2_neg(vk.gamma);
   G2Aff d = g2_neg(vk.delta);
   G2Aff b = (mode == 0) ? g2_neg(vk.beta) : vk.beta;
@@ -245,11 +254,11 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
     put_fp2(g_, tg[s].m); put_fp2(g_ + 2 * BN_NL, tg[s].c); put_fp2(g_ + 4 * BN_NL, tg[s].xc);
     put_fp2(d_, td[s].m); put_fp2(d_ + 2 * BN_NL, td[s].c); put_fp2(d_ + 4 * BN_NL, td[s].xc);
   }
-  out.alpha = vk.alpha; out.k0_pt = vk.k[0]; out.b_arg = b;
+  out.alpha = vk.alpha; out.k0_pt = k0; out.b_arg = b;
   Fp12 t = final_exponentiation(miller_loop<0>(vk.alpha, b, nullptr, nullptr));
   out.target.resize(12 * BN_NL);
   put_fp12(out.target.data(), t);
-  size_t nb = out.n_k - 1;
+  size_t nb = out.key_inputs();
   // keys with more than G16_WIDE_MSM_MIN_INPUTS inputs: comb tables (BN254_WIDE_COMB=0 keeps the byte-window form for comparison)
   const char* ce = getenv("BN254_WIDE_COMB");
   out.msm_comb = nb > (size_t)G16_WIDE_MSM_MIN_INPUTS && !(ce && atoi(ce) == 0);
