@@ -71,8 +71,18 @@ def measure_valu_peak(pkg, device=0):
     return VALU_PEAK_MEASURED
 
 
+VALU_ISSUE_CEILING = 1024 * 16 * 2.4e9   # 39.3 T: 1024 SIMDs x 64 lanes / 4 cycles per wavefront instruction x 2.4 GHz nominal -- what no box can exceed
+
+
 def _peak_fields():
-    return {"peak": VALU_PEAK_MAD_PER_S / 1e12, "peak_measured": (VALU_PEAK_MEASURED / 1e12) if VALU_PEAK_MEASURED else None, "peak_reference": VALU_PEAK_REFERENCE / 1e12}
+    return {"peak": VALU_PEAK_MAD_PER_S / 1e12, "peak_measured": (VALU_PEAK_MEASURED / 1e12) if VALU_PEAK_MEASURED else None, "peak_reference": VALU_PEAK_REFERENCE / 1e12,
+            "issue_ceiling": VALU_ISSUE_CEILING / 1e12}
+
+
+def _fracs(mads_per_s):
+    """One achieved rate against the three denominators, so that lines of different rounds and boxes compare: `frac` = the peak measured on THIS box in THIS run,
+    `frac_vs_reference` = the round-1 constant (35.1 T: what rounds 1-3 divided by), `frac_vs_issue_ceiling` = 39.3 T (4-cycle issue at the nominal clock)."""
+    return {"frac": mads_per_s / VALU_PEAK_MAD_PER_S, "frac_vs_reference": mads_per_s / VALU_PEAK_REFERENCE, "frac_vs_issue_ceiling": mads_per_s / VALU_ISSUE_CEILING}
 METRIC = "Groth16 verifies/sec (2 pub-inputs) at batch=2^20, 1/2/4/8 MI355X"
 SEED = 0xB2540002
 
@@ -367,9 +377,9 @@ def _valu_roofline(dom, launches_ms, per_launch, passes=None):
         else:
             total = mads * per_launch * launches
         ach = total / (union_ms * 1e-3) / 1e12
-        r.update({"mads_per_proof_launch": mads, "achieved": ach, "frac": ach / (VALU_PEAK_MAD_PER_S / 1e12)})
+        r.update({"mads_per_proof_launch": mads, "achieved": ach, **_fracs(ach * 1e12)})
     else:
-        r.update({"achieved": None, "frac": None})
+        r.update({"achieved": None, "frac": None, "frac_vs_reference": None, "frac_vs_issue_ceiling": None})
     return r
 
 
@@ -385,7 +395,7 @@ def _valu_whole_path(breakdown, proofs_per_s_per_gpu):
             continue
         mads += e.get("mads_per_proof_batch", cnt * e["mads_per_proof_launch"])
     ach = mads * proofs_per_s_per_gpu
-    return {"mads_per_proof": mads, "achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S,
+    return {"mads_per_proof": mads, "achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", **_fracs(ach),
             "kernels_without_count": missing}
 
 
@@ -605,7 +615,8 @@ def _plonk_accounting(pkg, km, batch, stage_ms):
     if batch <= 9000: piece, mw = 5040, 8
     elif batch <= 20000: piece, mw = batch, 1
     elif batch <= 40000: piece, mw = (batch + 1) // 2, 2
-    else: piece, mw = min(batch, 65536), 8
+    elif batch <= 65536: piece, mw = batch, 8
+    else: piece, mw = min(batch, 131072), 8      # PLONK_BIG_PIECE_DEFAULT (csrc/bn254_capi.hip)
     assert L.bn254_dbg_plonk_plan(batch, piece, mw, C.byref(w), C.byref(per), C.byref(ps)) == 0
     pass_n = min(ps.value, batch)
     L.bn254_dbg_plonk_msm_plan.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
@@ -646,7 +657,7 @@ def _plonk_accounting(pkg, km, batch, stage_ms):
         # one launch of the first sub-batch: its pass_n proofs x the rows' multiply-adds / the launch's duration (other sub-batches may run beside it: a per-launch figure)
         ach = sum(r2) * pass_n / (t2 * 1e-3)
         n_lanes = len(r2) * ((pass_n + 63) // 64 * 64)
-        out["roofline"] = {"bound": "valu", "kernel": "k_g1_msm_rows (KZG check: P0 and P1)", "unit": "T mad/s", **_peak_fields(), "achieved": ach / 1e12, "frac": ach / VALU_PEAK_MAD_PER_S,
+        out["roofline"] = {"bound": "valu", "kernel": "k_g1_msm_rows (KZG check: P0 and P1)", "unit": "T mad/s", **_peak_fields(), "achieved": ach / 1e12, **_fracs(ach),
                            "avg_launch_ms": t2, "rows_per_proof": len(r2), "lanes_per_launch": n_lanes, "executed_mads_per_proof": sum(r2), "longest_row_mads": max(r2),
                            # HBM counter bytes of one launch: per-proof figure of the committed rocprofv3 --pmc passes at 4096 proofs per call (profiles/pmc_traffic_plonk.json: the
                            # average of the pass's two row launches) x the proofs of this launch; mostly the lanes' window tables (1.7 KB written once, read once per step)
@@ -656,7 +667,7 @@ def _plonk_accounting(pkg, km, batch, stage_ms):
     tp = stage_ms.get("pairing_check", 0)
     if pair and tp > 0:
         a2 = pair * pass_n / (tp * 1e-3)
-        out["pairing"] = {"kernel": "k_coop12_miller_fixed" if coop else "k_miller_run_fixed2 + final exponentiation", "ms": tp, "mads_per_proof": pair, "achieved": a2 / 1e12, "frac": a2 / VALU_PEAK_MAD_PER_S}
+        out["pairing"] = {"kernel": "k_coop12_miller_fixed" if coop else "k_miller_run_fixed2 + final exponentiation", "ms": tp, "mads_per_proof": pair, "achieved": a2 / 1e12, **_fracs(a2)}
     if pair:
         out["whole"] = {"mads_per_proof": msm + sums + pair, "msm_rows": msm, "sums": sums, "pairing": pair,
                         "note": "k_plonk_stage1 / k_plonk_stage2 (transcripts, Fr arithmetic on 32-bit words) carry < 1 % of a proof's multiply-adds and are not counted"}
@@ -664,17 +675,38 @@ def _plonk_accounting(pkg, km, batch, stage_ms):
 
 
 def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=512, in_flight=True):
-    """BASELINE configs[3]: PlonK batch (the reference's 4 fixtures + mutated copies, every 8th proof invalid), host buffers in, status bytes
-    out.  Statuses of the first cpu_sample proofs against the oracle; cpu_baseline = the oracle's PlonK verifier on one core."""
+    """BASELINE configs[3]: PlonK batch (the reference's 4 fixtures + mutated copies, every 8th proof invalid).  `value`: proofs, inputs and status bytes RESIDENT in
+    HBM (bn254_plonk_verify_batch_device), like the headline; `host_buffers`: the same batch through the host-buffer entry (pageable memory in, status bytes out: the
+    PCIe-inclusive rate, never `value`).  Statuses of the first cpu_sample proofs against the oracle; cpu_baseline = the oracle's PlonK verifier on one core."""
     from oracle import oracle as O
+    import torch
     vk, pb, ib, proofs, inputs = plonk_workload(batch)
     pvk = pkg.PreparedPlonkVk(vk)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_p = torch.frombuffer(bytearray(pb), dtype=torch.uint8).to(dev); d_q = torch.frombuffer(bytearray(ib), dtype=torch.uint8).to(dev)
+    d_st = torch.full((batch,), 0xEE, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def resident(flags=0):
+        pvk.verify_batch_device(d_p.data_ptr(), d_q.data_ptr(), d_st.data_ptr(), batch, proof_stride=904, device=dev.index, stream=stream.cuda_stream, flags=flags)
+
+    # the host-buffer entry first (it also sizes the contexts' staging), then the resident entry: the timed `value`
     for _ in range(warmup):
-        st = pvk.verify_batch(pb, ib)
+        st_h = pvk.verify_batch(pb, ib, device=dev.index)
     t = time.perf_counter()
     for _ in range(steps):
-        st = pvk.verify_batch(pb, ib)
+        st_h = pvk.verify_batch(pb, ib, device=dev.index)
+    dt_host = time.perf_counter() - t
+    for _ in range(warmup):
+        resident()
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(steps):
+        resident()
+    torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t
+    st = bytes(d_st.cpu().numpy().tobytes())
+    assert st == st_h, "PlonK: the resident and the host-buffer entry disagree"
     # Accounting.  Multiply-adds EXECUTED by the launched form, from the row plans the library made for this batch size (bn254_dbg_plonk_msm_plan) priced with the
     # loop bodies of the code object (tools/count_mads.py -> kernel_mads.json `components`), against the HIP-event durations of the first sub-batch's launches.
     stage_ms, lanes = pvk.last_timing()
@@ -683,7 +715,7 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=512, in_flight=T
     roofline, pairing, whole = acct["roofline"], acct["pairing"], acct["whole"]
     if whole:
         ach = whole["mads_per_proof"] * batch * steps / dt
-        whole.update({"achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", "frac": ach / VALU_PEAK_MAD_PER_S})
+        whole.update({"achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", **_fracs(ach)})
     m = min(cpu_sample, batch)
     t = time.perf_counter()
     ref = bytes(O.plonk_verify(proofs[i], vk, [int.from_bytes(inputs[i][:32], "big"), int.from_bytes(inputs[i][32:], "big")]) for i in range(m))
@@ -713,17 +745,24 @@ def plonk_config(pkg, batch=4096, steps=5, warmup=1, cpu_sample=512, in_flight=T
     rlc_mode = None
     if batch >= 8192:
         for _ in range(max(1, warmup)):
-            st2 = pvk.verify_batch(pb, ib, flags=pkg.FLAG_RLC)
+            resident(pkg.FLAG_RLC)
         t2 = time.perf_counter()
         for _ in range(steps):
-            st2 = pvk.verify_batch(pb, ib, flags=pkg.FLAG_RLC)
+            resident(pkg.FLAG_RLC)
+        torch.cuda.synchronize(dev)
         d2 = time.perf_counter() - t2
+        st2 = bytes(d_st.cpu().numpy().tobytes())
         assert st2 == st, "PlonK: BN254_FLAG_RLC changed a status byte"
         rlc_mode = {"workload": "the same batch with BN254_FLAG_RLC (one pairing check per 64 proofs, exact fallback on groups that fail: none in this batch -- its invalid proofs fail before the pairing check)",
                     "unit": "proofs/s", "exact": batch * steps / dt, "rlc": batch * steps / d2, "speedup": dt / d2, "ms_per_step": d2 * 1e3 / steps}
+    held = pvk.footprint(dev.index)
     pvk.close()
-    return {"workload": "BASELINE configs[3]: PlonK batch %d, 904-byte proofs (the reference's fixtures + mutations), 2 public inputs, 1/8 invalid; host buffers in, status bytes out" % batch,
+    del d_p, d_q, d_st
+    return {"workload": "BASELINE configs[3]: PlonK batch %d, 904-byte proofs (the reference's fixtures + mutations), 2 public inputs, 1/8 invalid; proofs, inputs and status bytes resident in HBM" % batch,
             "value": batch * steps / dt, "unit": "proofs/s", "ms_per_step": dt * 1e3 / steps, "steps": steps, "batch": batch,
+            "host_buffers": {"value": batch * steps / dt_host, "unit": "proofs/s", "ms_per_step": dt_host * 1e3 / steps,
+                             "workload": "the same batch through bn254_plonk_verify_batch (pageable host buffers in, status bytes out; PCIe-inclusive, never `value`)"},
+            "context_footprint": {"bytes": held[0], "contexts": held[1]},
             "status_check": "first %d statuses == oracle; %d ACCEPT of %d" % (m, batch - batch // 8, batch),
             "calls_in_flight": in_flight, "rlc_mode": rlc_mode,
             "roofline": roofline, "pairing_check": pairing, "valu_whole_path": whole, "plan": acct["plan"], "stages_ms": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -769,6 +808,7 @@ def other_configs(args, pkg, local_rank, resident_value, keep):
     cfg["batch4096"] = device_config(pkg, local_rank, "BASELINE configs[1]: batch 4096 Groth16 proofs, 2 public inputs, inputs resident", 2, 4096, 20, 2, 0xB2540001, 64)
     cfg["plonk4096"] = plonk_config(pkg, 4096, 5, 1, 512)
     cfg["plonk65536"] = plonk_config(pkg, 65536, 3, 1, 16, in_flight=False)
+    cfg["plonk262144"] = plonk_config(pkg, 262144, 3, 1, 16, in_flight=False)
     cfg["groth16_1024x4096"] = device_config(pkg, local_rank, "BASELINE configs[4]: batch 4096 Groth16 proofs, 1024 public inputs, inputs resident", 1024, 4096, 5, 1, 0xB2540004, 16)
     hb = _host_buffer_line(args, pkg, keep["vk"], keep["proofs"], keep["inputs"], keep["expected0"], local_rank)
     hb["workload"] = "the headline batch through bn254_groth16_verify_batch on pageable host buffers (PCIe-inclusive; never `value`)"

@@ -53,7 +53,10 @@ enum {
   BN254_E_BAD_ARG = -1,
   BN254_E_NO_DEVICE = -2,   /* no usable HIP device / kernel image: the product never falls back to the CPU */
   BN254_E_HIP = -3,         /* a HIP runtime call failed; bn254_last_error() has the text */
-  BN254_E_VK = -4,          /* the verifying key bytes do not parse (status byte equivalent: BN254_ERR_MALFORMED) */
+  BN254_E_VK = -4,          /* the verifying key bytes do not load: whatever load_groth16_verifying_key_from_bytes / load_plonk_verifying_key_from_bytes turn into a panic
+                               (short buffer, flag 0b00, no square root; groth16/converter.rs:28-89, plonk/converter.rs:18-119).  Status byte equivalent: BN254_ERR_MALFORMED.
+                               A key that LOADS is never refused: no K points at all (every proof: loader error, else BN254_ERR_INPUT_LEN), G2 elements outside the r-torsion
+                               (the loaders are "unchecked", converter.rs:113-133: computed on, as the reference does) */
   BN254_E_NOMEM = -5
 };
 
@@ -91,10 +94,12 @@ typedef struct bn254_g16_pvk bn254_g16_pvk;
 /* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
  * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
  * Miller-loop line tables for the two fixed G2 arguments, fixed-base tables for vk.K (byte windows, 650 KB per input; keys with more
- * than 16 inputs: comb tables, 655 KB per input, 2.2 s for 1024 inputs on 8 host threads).  Host work; no GPU needed. */
+ * than 16 inputs: comb tables, 655 KB per input).  Host work; no GPU needed.
+ * LIMITS a caller must plan for: a key with 1024 public inputs takes 2.2 s to prepare on 8 host threads and holds 671 MB of tables on the host AND on every device it is used on
+ * (uploaded at the first batch or bn254_groth16_reserve); keep the handle, do not prepare per call.  A 2-input key: 9 ms, 1.3 MB. */
 int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out);
 void bn254_groth16_vk_free(bn254_g16_pvk* pvk);
-/* number of public inputs the key expects (len(vk.K) - 1) */
+/* number of public inputs the key expects (len(vk.K) - 1); SIZE_MAX for a key without K points: no input count satisfies groth16/verify.rs:54 */
 size_t bn254_groth16_vk_num_public(const bn254_g16_pvk* pvk);
 
 /* verify_batch on host buffers.  proofs: n records of proof_stride bytes (>= 256; bytes beyond 256 -- gnark's commitment
@@ -171,13 +176,28 @@ int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, 
  * diagnostic host-thread stages of BN254_PLONK_HOST=1 ignore the flag.)  Any other flag bit is refused with BN254_E_BAD_ARG. */
 int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
                                    size_t n_public, size_t n, uint8_t* status, int device, unsigned flags);
+/* The same three entry shapes as Groth16 (north_star: one verify_batch surface for both verifiers):
+ * _device  proofs, public inputs and status bytes resident in the memory of `device`.  Unlike the Groth16 entry this one is host-synchronous: it first waits for the work
+ *          already enqueued on hip_stream (whatever still writes the inputs), runs the passes on the key's own context streams and returns when the status bytes are in
+ *          d_status (a PlonK batch is several passes on several contexts driven by host threads, and BN254_FLAG_RLC has to read a counter back between two stages).
+ * _multi   several GPUs of the node: the contiguous shards of bn254_shard_plan, one host thread per device through the host-buffer entry.
+ * reserve  allocates NOW what a batch of up to n proofs needs on `device` (contexts of the plan, their buffers; proof_stride > 0: also the pinned staging of the host-buffer
+ *          entry for records of that stride), so that the batch itself neither allocates nor frees.  Footprint per context (SP1 key shape, 6.6 KB per proof of capacity plus
+ *          1.8 KB per proof and variable MSM term): 0.45 GB for passes of 8192 proofs, 2.7 GB for 131 072, 5.4 GB for 262 144; a batch above 65 536 proofs uses up to
+ *          eight contexts of its pass size.  bn254_plonk_footprint reports what a key holds on a device right now. */
+int bn254_plonk_verify_batch_device(const bn254_plonk_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_public_inputs, size_t n_public, size_t n,
+                                    void* d_status, int device, void* hip_stream, unsigned flags);
+int bn254_plonk_verify_batch_multi(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n,
+                                   uint8_t* status, uint64_t device_mask, unsigned flags);
+int bn254_plonk_reserve(const bn254_plonk_pvk* pvk, size_t n, size_t proof_stride, int device);
+int bn254_plonk_footprint(const bn254_plonk_pvk* pvk, int device, size_t* bytes, int* contexts);
 int bn254_plonk_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs,
                        size_t n_public, uint8_t* status);
 /* Knobs of the PlonK batch plan (process-wide, atomic; -1 leaves a knob alone; initial values from BN254_PLONK_PIECE / _WORKERS / _BIG_FROM / _BIG_PIECE, read once at
  * load time): below big_from proofs a batch is up to `workers` chains of passes of at most `piece` proofs side by side (latency-bound launches), from big_from on
- * few passes of up to big_piece <= 65536 proofs (throughput-bound launches).  big_from = 0 (the default) selects the plan measured on the MI355X: chains up to
- * ~9000 proofs, one pass up to ~20 000, two passes side by side up to ~40 000, one pass up to 65 536, passes of 65 536 on up to eight contexts beyond.  Same status
- * bytes whatever the plan. */
+ * few passes of up to big_piece <= 262144 proofs (throughput-bound launches).  big_from = 0 (the default) selects the plan measured on the MI355X: chains up to
+ * ~9000 proofs, one pass up to ~20 000, two passes side by side up to ~40 000, one pass up to 65 536, passes of big_piece (default 131 072) on up to eight contexts beyond.
+ * Same status bytes whatever the plan. */
 void bn254_set_plonk_params(long piece, int workers, long big_from, long big_piece);
 /* Durations (ms) of the first sub-batch of the bn254_plonk_verify_batch that finished last on `device`, from HIP events on the sub-batch's stream:
  *   [0] host: staging copy into pinned memory (with BN254_PLONK_HOST=1: stage 1 on host threads)      [1] k_plonk_stage1
@@ -278,7 +298,7 @@ int bn254_dbg_glv_decompose(const uint8_t k32[32], uint8_t k1_16[16], uint8_t k2
 
 /* host-only probes of the PlonK batch plan (sub-batches side by side, proofs per sub-batch, proofs per pass) and of the MSM launches (csrc/bn254_msm.h): the row plan of
  * the stage-1 / stage-2 launch for a key with n_qcp commitments and n proofs under a lane budget (0 = the library's) -- rows, rows that use window-table scratch, the
- * scratch lanes that launch needs, its longest row in the planner's cost units, rows and fixed terms per sum, optionally the rows themselves (MSM rows x 9 ints:
+ * scratch lanes that launch needs, its longest row in the planner's cost units, rows and fixed terms per sum, optionally the rows themselves (MSM_MAX_ROWS = 32 rows x 9 ints:
  * variable term (-1: none, or a joint row), pos_lo, pos_hi, unit term, sum, first scratch slot, fixed windows [lo, hi), and for a JOINT row -- several variable terms
  * walked together over all 128 positions, large launches -- the bit mask of its terms); and the scratch lanes a context of `capacity` proofs allocates for launches
  * of n_var variable terms.  tests/test_capi_cpu.py: need <= allocation for every n <= capacity. */
@@ -294,6 +314,9 @@ int bn254_dbg_g16_plan(size_t key_inputs, int comb, size_t reserved, size_t n, s
  * for `reserved` proofs holds (alloc) */
 int bn254_dbg_g16_rlc_plan(size_t reserved, size_t m, int n_streams, int log2_group, int log2_share, size_t min_lanes, uint64_t* need, uint64_t* alloc);
 size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int n_var);
+/* ... and the projective points (rows x items) the row buffer of a context of `capacity` proofs holds for launches of that key shape and stage (stage 3: the weighted
+ * second launch of BN254_FLAG_RLC): n_rows x n of every launch over n <= capacity items must fit (tests/test_msm_rows.py) */
+size_t bn254_dbg_plonk_part_points(size_t capacity, int n_qcp, int stage);
 int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget, int* n_rows, int* n_var_rows, size_t* scratch_lanes, int* chain, int sum_rows[2],
                              int fixed_terms[2], int* rows_out);
 
@@ -308,6 +331,10 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
  * and the column digits of the 256-bit big-endian x, as the kernels do; out64 = uncompressed point, all zero for the identity */
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]);
 
+/* Revision of this header's binary interface: bumped whenever a function changes its arguments, an array argument its length or a slot its meaning (5: this round --
+ * BN254_PLONK_NUM_TIMINGS has been 9 since revision 4, bn254_dbg_plonk_msm_plan writes 9 ints per row).  A binding compares it with the value it was generated for. */
+#define BN254_ABI_VERSION 5
+int bn254_abi_version(void);
 const char* bn254_status_string(int status_byte);
 const char* bn254_last_error(void);
 const char* bn254_version(void);

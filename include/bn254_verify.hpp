@@ -140,6 +140,18 @@ class PreparedGroth16Vk {
     st.resize(n);
     return st;
   }
+  Bytes verify_batch_multi(const uint8_t* proofs, size_t stride, const uint8_t* public_inputs, size_t n_public, size_t n, uint64_t device_mask, unsigned flags = 0) const {
+    Bytes st(n ? n : 1);
+    detail::check(bn254_groth16_verify_batch_multi(h_, proofs, stride, public_inputs, n_public, n, st.data(), device_mask, flags));
+    st.resize(n);
+    return st;
+  }
+  // enqueues on hip_stream and returns (BN254_FLAG_RLC: after one stream synchronisation)
+  void verify_batch_device(const void* d_proofs, size_t stride, const void* d_public_inputs, size_t n_public, size_t n, void* d_status, int device = 0, void* hip_stream = nullptr,
+                           unsigned flags = 0) const {
+    detail::check(bn254_groth16_verify_batch_device(h_, d_proofs, stride, d_public_inputs, n_public, n, d_status, device, hip_stream, flags));
+  }
+  void reserve(size_t n, int device = 0) const { detail::check(bn254_groth16_reserve(h_, n, device)); }
 
  private:
   bn254_g16_pvk* h_ = nullptr;
@@ -194,6 +206,19 @@ class PreparedPlonkVk {
     st.resize(n);
     return st;
   }
+  // the same over the GPUs selected by device_mask (contiguous shards, one host thread per device)
+  Bytes verify_batch_multi(const uint8_t* proofs, size_t stride, const uint8_t* public_inputs, size_t n_public, size_t n, uint64_t device_mask, unsigned flags = 0) const {
+    Bytes st(n ? n : 1);
+    detail::check(bn254_plonk_verify_batch_multi(h_, proofs, stride, public_inputs, n_public, n, st.data(), device_mask, flags));
+    st.resize(n);
+    return st;
+  }
+  // proofs, inputs and status bytes in device memory; returns when the status bytes are in d_status (bn254_verify.h)
+  void verify_batch_device(const void* d_proofs, size_t stride, const void* d_public_inputs, size_t n_public, size_t n, void* d_status, int device = 0, void* hip_stream = nullptr,
+                           unsigned flags = 0) const {
+    detail::check(bn254_plonk_verify_batch_device(h_, d_proofs, stride, d_public_inputs, n_public, n, d_status, device, hip_stream, flags));
+  }
+  void reserve(size_t n, size_t proof_stride = 0, int device = 0) const { detail::check(bn254_plonk_reserve(h_, n, proof_stride, device)); }
 
  private:
   bn254_plonk_pvk* h_ = nullptr;
@@ -220,8 +245,18 @@ struct PlonkVerifier {
       std::copy(f.begin(), f.end(), in.begin() + 32 * n_public * i);
     }
     size_t stride; std::vector<bool> is_short;
-    const Bytes pb = detail::pack(proofs, 1, &stride, &is_short);
-    return pvk.verify_batch(pb.data(), stride, in.data(), n_public, n, device);
+    const Bytes pb = detail::pack(proofs, 516, &stride, &is_short);
+    Bytes st = pvk.verify_batch(pb.data(), stride, in.data(), n_public, n, device);
+    // a proof shorter than its own layout (plonk/converter.rs:121-178: 8 points, count + claimed values, second opening, count + commitments) is a slice-index panic in
+    // the reference; padded to the stride it would parse as something else
+    for (size_t i = 0; i < n; i++) {
+      const Bytes& p = proofs[i];
+      auto be32 = [&p](size_t o) { return (size_t)p[o] << 24 | (size_t)p[o + 1] << 16 | (size_t)p[o + 2] << 8 | (size_t)p[o + 3]; };
+      bool bad = p.size() < 516;
+      if (!bad) { const size_t off = 516 + 32 * be32(512); bad = p.size() < off + 100 || p.size() < off + 100 + 64 * be32(off + 96); }
+      if (bad) st[i] = BN254_ERR_MALFORMED;
+    }
+    return st;
   }
   static Result<bool, PlonkError> outcome(uint8_t status) { return detail::plonk_outcome(status); }
 };

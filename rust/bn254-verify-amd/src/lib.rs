@@ -131,6 +131,14 @@ impl PreparedPlonkVk {
         Ok(Self { h })
     }
     pub fn num_public(&self) -> usize { unsafe { sys::bn254_plonk_vk_num_public(self.h) } }
+    /// Allocations ahead of the first batch of up to `n` proofs (`proof_stride` > 0: also the pinned staging of the host-buffer entry); see the header for the footprint.
+    pub fn reserve(&self, n: usize, proof_stride: usize, device: i32) -> Result<(), Error> { check(unsafe { sys::bn254_plonk_reserve(self.h, n, proof_stride, device) }) }
+    /// Device memory this key's contexts hold on `device` (bytes) and how many contexts hold any.
+    pub fn footprint(&self, device: i32) -> Result<(usize, i32), Error> {
+        let (mut bytes, mut ctx) = (0usize, 0);
+        check(unsafe { sys::bn254_plonk_footprint(self.h, device, &mut bytes, &mut ctx) })?;
+        Ok((bytes, ctx))
+    }
     pub fn verify_batch_raw(&self, proofs: &[u8], proof_stride: usize, public_inputs: &[u8], n_public: usize, n: usize, device: i32) -> Result<Vec<Status>, Error> {
         self.verify_batch_flags(proofs, proof_stride, public_inputs, n_public, n, device, 0)
     }
@@ -142,8 +150,31 @@ impl PreparedPlonkVk {
         check(unsafe { sys::bn254_plonk_verify_batch_flags(self.h, proofs.as_ptr(), proof_stride, public_inputs.as_ptr(), n_public, n, st.as_mut_ptr(), device, flags) })?;
         Ok(st.into_iter().map(Status::from).collect())
     }
+    /// The same over the GPUs selected by `device_mask` (contiguous shards, one host thread per device: SURVEY.md section 8(e)).
+    pub fn verify_batch_multi_raw(&self, proofs: &[u8], proof_stride: usize, public_inputs: &[u8], n_public: usize, n: usize, device_mask: u64, flags: u32) -> Result<Vec<Status>, Error> {
+        assert!(proofs.len() >= n * proof_stride && public_inputs.len() >= n * n_public * 32);
+        let mut st = vec![0u8; n];
+        check(unsafe { sys::bn254_plonk_verify_batch_multi(self.h, proofs.as_ptr(), proof_stride, public_inputs.as_ptr(), n_public, n, st.as_mut_ptr(), device_mask, flags) })?;
+        Ok(st.into_iter().map(Status::from).collect())
+    }
+    /// Proofs, inputs and status bytes in device memory.  Host-synchronous: waits for `hip_stream`, returns when the status bytes are in `d_status`.
+    /// # Safety
+    /// The three device pointers must be valid for the sizes implied by `n`, `proof_stride`, `n_public` for the duration of the call.
+    pub unsafe fn verify_batch_device(&self, d_proofs: *const c_void, proof_stride: usize, d_inputs: *const c_void, n_public: usize, n: usize, d_status: *mut c_void, device: i32,
+                                      hip_stream: *mut c_void, flags: u32) -> Result<(), Error> {
+        check(sys::bn254_plonk_verify_batch_device(self.h, d_proofs, proof_stride, d_inputs, n_public, n, d_status, device, hip_stream, flags))
+    }
+    /// Durations (ms) of the first sub-batch of the batch that finished last on `device` (slots: `bn254_plonk_last_timing` in the header) and the lanes of its two MSM launches.
+    pub fn last_timing(&self, device: i32) -> Result<([f32; sys::BN254_PLONK_NUM_TIMINGS], [usize; 2]), Error> {
+        let (mut ms, mut lanes) = ([0f32; sys::BN254_PLONK_NUM_TIMINGS], [0usize; 2]);
+        check(unsafe { sys::bn254_plonk_last_timing(self.h, device, ms.as_mut_ptr(), lanes.as_mut_ptr()) })?;
+        Ok((ms, lanes))
+    }
 }
 impl Drop for PreparedPlonkVk { fn drop(&mut self) { unsafe { sys::bn254_plonk_vk_free(self.h) } } }
+
+/// The library this crate was generated for?  (`bn254_abi_version`: bumped whenever a function changes its arguments, an array its length or a slot its meaning.)
+pub fn abi_matches() -> bool { unsafe { sys::bn254_abi_version() == sys::BN254_ABI_VERSION } }
 
 pub struct PlonkVerifier;
 impl PlonkVerifier {
@@ -168,9 +199,23 @@ impl PlonkVerifier {
         let pvk = PreparedPlonkVk::new(vk)?;
         let (buf, stride) = flatten(proofs, 516);
         let n_public = public_inputs.first().map_or(0, |x| x.len());
+        assert!(public_inputs.iter().all(|x| x.len() == n_public), "one input count per batch (a wrong count is a per-key error: InputLen for every proof)");
         let inputs: Vec<u8> = public_inputs.iter().flat_map(|xs| xs.iter().flatten().copied()).collect();
-        pvk.verify_batch_raw(&buf, stride, &inputs, n_public, proofs.len(), 0)
+        let mut st = pvk.verify_batch_raw(&buf, stride, &inputs, n_public, proofs.len(), 0)?;
+        // a proof shorter than its own layout is a slice-index panic in the reference (plonk/converter.rs:121-178); zero-padded to the stride it would parse as something else
+        for (s, p) in st.iter_mut().zip(proofs) { if p.len() < plonk_layout_len(p) { *s = Status::Malformed; } }
+        Ok(st)
     }
+}
+
+/// Bytes `load_plonk_proof_from_bytes` reads of a proof that starts like `p` (`plonk/converter.rs:121-178`): 8 points, u32 count + claimed values, the second opening
+/// (point, value, u32 count) and the BSB22 commitments; `usize::MAX` when `p` ends before a count can be read.
+fn plonk_layout_len(p: &[u8]) -> usize {
+    let be32 = |o: usize| p.get(o..o + 4).map(|b| u32::from_be_bytes([b[0], b[1], b[2], b[3]]) as usize);
+    let Some(n_claimed) = be32(512) else { return usize::MAX };
+    let off = 516 + 32 * n_claimed;
+    let Some(n_bsb) = be32(off + 96) else { return usize::MAX };
+    off + 100 + 64 * n_bsb
 }
 
 /// The contiguous shard of rank `r` of `world` for a batch of `n` (the rule of `bn254_shard_plan` and of the multi-process job).

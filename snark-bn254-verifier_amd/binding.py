@@ -10,6 +10,7 @@ VK_REFERENCE, VK_GNARK = 0, 1
 FLAG_STRICT_SCALARS, FLAG_RLC = 1, 2
 RAW_PROOF_LEN = 324
 NUM_KERNELS = 4
+ABI_VERSION = 5   # include/bn254_verify.h: BN254_ABI_VERSION
 
 
 class Bn254Error(RuntimeError):
@@ -90,6 +91,12 @@ def lib():
         L.bn254_plonk_verify_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
         L.bn254_plonk_verify_batch_flags.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_uint]
         L.bn254_plonk_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p]
+        L.bn254_plonk_verify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
+        L.bn254_plonk_verify_batch_multi.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint]
+        L.bn254_plonk_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.bn254_plonk_footprint.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        if L.bn254_abi_version() != ABI_VERSION:
+            raise Bn254Error("libbn254_verify_amd.so has ABI revision %d, this binding was written for %d" % (L.bn254_abi_version(), ABI_VERSION))
         L.bn254_groth16_kernel_kind_name.restype = C.c_char_p
         L.bn254_groth16_kernel_kind_name.argtypes = [C.c_int]
         L.bn254_set_profile_kernels.argtypes = [C.c_uint]
@@ -152,6 +159,30 @@ class PreparedPlonkVk:
         st = (C.c_uint8 * max(n, 1))()
         _check(lib().bn254_plonk_verify_batch_flags(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device, flags))
         return bytes(st)[:n]
+
+    def verify_batch_multi(self, proofs, public_inputs, device_mask, n=None, proof_stride=904, n_public=None, flags=0):
+        """Same over the GPUs selected by the bits of device_mask (contiguous shards, one host thread per device)."""
+        n_public = self.n_public if n_public is None else n_public
+        if n is None:
+            n = len(proofs) // proof_stride
+        st = (C.c_uint8 * max(n, 1))()
+        _check(lib().bn254_plonk_verify_batch_multi(self._h, bytes(proofs), proof_stride, bytes(public_inputs), n_public, n, st, device_mask, flags))
+        return bytes(st)[:n]
+
+    def verify_batch_device(self, d_proofs, d_inputs, d_status, n, proof_stride=904, n_public=None, device=0, stream=None, flags=0):
+        """Raw device pointers (ints).  Host-synchronous: waits for `stream`, returns when the status bytes are in d_status."""
+        n_public = self.n_public if n_public is None else n_public
+        _check(lib().bn254_plonk_verify_batch_device(self._h, d_proofs, proof_stride, d_inputs, n_public, n, d_status, device, stream, flags))
+
+    def reserve(self, n, proof_stride=0, device=0):
+        """Allocate now what a batch of up to n proofs needs (proof_stride > 0: also the pinned staging of the host-buffer entry)."""
+        _check(lib().bn254_plonk_reserve(self._h, n, proof_stride, device))
+
+    def footprint(self, device=0):
+        """(bytes of device memory this key's contexts hold on `device`, contexts that hold any)"""
+        b, c = C.c_size_t(0), C.c_int(0)
+        _check(lib().bn254_plonk_footprint(self._h, device, C.byref(b), C.byref(c)))
+        return b.value, c.value
 
     def last_timing(self, device=0):
         """Stage and kernel durations (ms) of the first sub-batch of the last verify_batch (bn254_plonk_last_timing)."""

@@ -35,6 +35,7 @@ using namespace bn254host;
 size_t bn254_plonk_work_bytes();
 size_t bn254_plonk_key_bytes();
 hipError_t bn254_plonk_dev_init(int device);
+hipError_t bn254_plonk_self_test(const void* key_host, const void* d_key, std::string* why);
 hipError_t bn254_launch_plonk_stage1(const void* d_key, const uint8_t* d_proofs, size_t stride, const uint8_t* d_inputs, size_t n_public, size_t n, const uint32_t lam_key[11],
                                      void* d_work, void* d_terms, uint8_t* d_flags, int T1, hipStream_t s);
 hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs, size_t stride, size_t n, void* d_work, const uint32_t* d_lin_words, const uint8_t* d_lin_inf,
@@ -229,7 +230,10 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 // threads drive concurrently, so the host stages of one sub-batch (transcripts, Fr arithmetic) overlap the GPU stages of the others; every
 // wait is stream-scoped.
 #define PLONK_WORKERS 8
-#define PLONK_MAX_LAUNCH 65536
+// proofs per pass at most.  Until round 4 this was 65 536 -- one wavefront per SIMD for every one-lane-per-proof kernel of a pass, which left the pairing stage of the
+// largest passes at 0.39 of the multiply-add peak; a pass of 2^18 proofs gives the same kernels four (the context's buffers for it: 5.4 GB at the SP1 key shape)
+#define PLONK_MAX_LAUNCH 262144
+#define PLONK_BIG_PIECE_DEFAULT 131072   // proofs per pass of a batch above 65 536 proofs (profiles/r05_plonk_piece_sweep.txt)
 struct PlonkCtx {
   size_t cap = 0;                      // proofs the buffers below hold
   hipStream_t stream = nullptr, aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -237,6 +241,7 @@ struct PlonkCtx {
   float last_ms[BN254_PLONK_NUM_TIMINGS] = {0}; size_t last_lanes[2] = {0, 0}; bool last_valid = false;
   std::vector<PlonkWork> work;        // host scratch per proof (kept across calls)
   int32_t *ws = nullptr, *part = nullptr, *glv_tab = nullptr;   // part: the rows of an MSM launch (bn254_msm.h); glv_tab: the window tables of its variable rows
+  size_t part_points = 0;              // projective points (rows x items) `part` holds (plonk_part_points of the capacity)
   size_t glv_lanes = 0;                // lanes glv_tab holds (plonk_scratch_lanes of the capacity); a launch checks its need against it before it is enqueued
   MsmTerm* terms = nullptr; uint8_t* flags = nullptr; uint32_t* words = nullptr; uint8_t *inf = nullptr, *status = nullptr;
   // pinned host staging
@@ -312,8 +317,15 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
     // the key and the field constants for the device-side stages
     if (sizeof(PlonkKey) != bn254_plonk_key_bytes()) return set_err(BN254_E_HIP, "PlonK key layout differs between the translation units");
     HIPCK(bn254_plonk_dev_init(device));
-    HIPCK(hipMalloc(&d.d_key, sizeof(PlonkKey)));
+    if (!d.d_key) HIPCK(hipMalloc(&d.d_key, sizeof(PlonkKey)));
     HIPCK(hipMemcpy(d.d_key, &pvk->key, sizeof(PlonkKey), hipMemcpyHostToDevice));
+    // known-answer check of the device stages on this GPU before the key is used there (bn254_k_plonk.hip::bn254_plonk_self_test); BN254_PLONK_SELFTEST=0 skips it
+    static const bool selftest = [] { const char* e = getenv("BN254_PLONK_SELFTEST"); return !e || atoi(e) != 0; }();
+    if (selftest) {
+      std::string why;
+      HIPCK(bn254_plonk_self_test(&pvk->key, d.d_key, &why));
+      if (!why.empty()) return set_err(BN254_E_HIP, why);
+    }
     d.ready = true;
   }
   *out = &d;
@@ -338,6 +350,17 @@ static size_t plonk_scratch_lanes(size_t need, int n_var) {
   const size_t full = (size_t)n_var * need_pad;
   return split > full ? split : full;
 }
+// Points (rows x items) the row buffer of a context of capacity `need` must hold for launches of `shape`: a split launch (latency form) has at most lane_budget / n_pad rows,
+// so rows x items stays within the lane budget; an unsplit one has the rows of its shape's plan without joint rows (joint rows only merge rows), whatever the item count.
+static size_t plonk_part_points(size_t need, const MsmShape& shape) {
+  MsmPlan big;
+  if (!msm_plan_build(big, shape, 64, 0, 0, 0)) return need * (size_t)MSM_MAX_ROWS;
+  const size_t need_pad = (need + 63) & ~(size_t)63;
+  // (a sum without variable terms, or an empty one, takes one row even when the budget has none left: two sums, two rows beyond the budget at most)
+  size_t split = msm_lane_budget() + 2 * need_pad; if (split > need_pad * (size_t)MSM_MAX_ROWS) split = need_pad * (size_t)MSM_MAX_ROWS;
+  const size_t full = (size_t)big.n_rows * need_pad;
+  return split > full ? split : full;
+}
 static int shape_var(const MsmShape& sh) { int v = 0; for (int s = 0; s < sh.n_sums; s++) v += sh.n_var[s]; return v; }
 // Knobs of the PlonK batch plan (bn254_set_plonk_params; the environment gives their initial values once, at load time):
 //   piece      proofs per pass while a batch is a set of latency-bound chains side by side (5040: every launch of a pass is one wavefront generation and the
@@ -352,17 +375,18 @@ static std::atomic<int> g_plonk_workers{[] { long v = env_long("BN254_PLONK_WORK
 static std::atomic<long> g_plonk_big_from{[] { long v = env_long("BN254_PLONK_BIG_FROM", 0); return v < 0 ? 0 : v; }()};      // 0: the measured plan of plonk_auto_plan
 // BN254_FLAG_RLC on the PlonK entry: honoured from this many proofs per pass (BN254_PLONK_RLC_MIN gives the initial value)
 static std::atomic<long> g_plonk_rlc_min{[] { long v = env_long("BN254_PLONK_RLC_MIN", 8192); return v < 64 ? 64 : v; }()};
-static std::atomic<long> g_plonk_big_piece{[] { long v = env_long("BN254_PLONK_BIG_PIECE", PLONK_MAX_LAUNCH); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
+static std::atomic<long> g_plonk_big_piece{[] { long v = env_long("BN254_PLONK_BIG_PIECE", PLONK_BIG_PIECE_DEFAULT); return v < 256 ? 256 : (v > PLONK_MAX_LAUNCH ? (long)PLONK_MAX_LAUNCH : v); }()};
 // the plan of a batch (bn254_plonk_verify_batch): sub-batches side by side, proofs per sub-batch, proofs per pass of a sub-batch
 // The default plan by batch size (profiles/r04_plonk_plan_sweep.txt, one MI355X): chains of 5040-proof passes side by side up to ~9000 proofs (8192: 7.06 ms against
 // 7.27 ms as one pass); ONE pass of the whole batch up to ~20 000 (16 384: 12.2 against 12.7 ms); TWO passes side by side up to ~40 000 (32 768: 18.3 ms against 20.2 ms
 // as one pass and 22.3 ms as chains); one pass again up to 65 536 (49 152: 25.1 ms = 1.96 M proofs/s, 65 536: 28.8 ms = 2.28 M, chains 1.48 M); beyond, passes of up to
-// 65 536 proofs on up to eight contexts (262 144: 2.62 M proofs/s).
-static void plonk_auto_plan(size_t n, size_t chain_piece, int max_workers, size_t* piece, int* workers_cap) {
+// big_piece proofs (bn254_set_plonk_params; default PLONK_BIG_PIECE_DEFAULT) on up to eight contexts (round 4, passes of 65 536: 262 144 proofs at 2.62 M proofs/s).
+static void plonk_auto_plan(size_t n, size_t chain_piece, size_t big_piece, int max_workers, size_t* piece, int* workers_cap) {
   if (n <= 9000) { *piece = chain_piece; *workers_cap = max_workers; }
   else if (n <= 20000) { *piece = n; *workers_cap = 1; }
   else if (n <= 40000) { *piece = (n + 1) / 2; *workers_cap = max_workers < 2 ? max_workers : 2; }
-  else { *piece = n < (size_t)PLONK_MAX_LAUNCH ? n : (size_t)PLONK_MAX_LAUNCH; *workers_cap = max_workers; }
+  else if (n <= 65536) { *piece = n; *workers_cap = max_workers; }
+  else { *piece = n < big_piece ? n : big_piece; *workers_cap = max_workers; }
 }
 static void plonk_plan(size_t n, size_t piece, int max_workers, int* workers, size_t* per, size_t* pass) {
   int w = (int)((n + piece - 1) / piece); if (w > max_workers) w = max_workers; if (w < 1) w = 1;
@@ -397,7 +421,7 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n, s
     for (auto q : dp) { if (*q) (void)hipFree(*q); *q = nullptr; }
     void** hp[] = {(void**)&c.h_terms, (void**)&c.h_flags, (void**)&c.h_status, (void**)&c.h_inf, (void**)&c.h_words, (void**)&c.h_fail};
     for (auto q : hp) { if (*q) (void)hipHostFree(*q); *q = nullptr; }
-    c.cap = 0; c.glv_lanes = 0;
+    c.cap = 0; c.glv_lanes = 0; c.part_points = 0;
   };
   drop();
   const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
@@ -409,7 +433,10 @@ static int plonk_ensure_ctx(const bn254_plonk_pvk* pvk, PlonkCtx& c, size_t n, s
   auto dm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipMalloc(q, bytes ? bytes : 1); };
   auto hm = [&e](void** q, size_t bytes) { if (e == hipSuccess) e = hipHostMalloc(q, bytes ? bytes : 1, hipHostMallocDefault); };
   dm((void**)&c.ws, need * (size_t)G16_WS_BYTES_PER_PROOF);
-  dm((void**)&c.part, need * (size_t)MSM_MAX_ROWS * 27 * sizeof(int32_t));     // one projective point per row of a launch's plan
+  size_t pp = plonk_part_points(need, pvk->shape1);                              // one projective point per row and item of a launch's plan
+  { const size_t b = plonk_part_points(need, pvk->shape2), c2 = plonk_part_points(need, pvk->shape2_rlc); if (b > pp) pp = b; if (c2 > pp) pp = c2; }
+  dm((void**)&c.part, pp * 27 * sizeof(int32_t));
+  c.part_points = pp;
   dm((void**)&c.glv_tab, tab_lanes * (size_t)G1_GLV_TAB_BYTES_PER_LANE);       // 65536 lanes = 117 MB for capacities up to 8192 proofs
   c.glv_lanes = tab_lanes;
   dm((void**)&c.terms, need * tmax * sizeof(MsmTerm));
@@ -533,7 +560,8 @@ static KeyCache<bn254_plonk_pvk, bn254_plonk_vk_free>& plonk_key_cache() { stati
 extern "C" {
 
 const char* bn254_last_error(void) { return g_err.c_str(); }
-const char* bn254_version(void) { return "bn254-verify-amd 0.1 (gfx950)"; }
+const char* bn254_version(void) { return "bn254-verify-amd 0.5 (gfx950)"; }
+int bn254_abi_version(void) { return BN254_ABI_VERSION; }
 const char* bn254_status_string(int s) {
   switch (s) {
     case BN254_REJECT: return "reject"; case BN254_ACCEPT: return "accept"; case BN254_ERR_NOT_MEMBER: return "coordinate not a field member";
@@ -1258,7 +1286,7 @@ static int plonk_msm(const PlonkDev* d, PlonkCtx& c, const MsmShape& shape, size
   // BN254_MSM_SPLIT_AT (experiments): the bit position at which the variable terms' low and high rows meet, instead of the planner's choice
   static const int force_a = [] { const char* e = getenv("BN254_MSM_SPLIT_AT"); int v = e ? atoi(e) : 0; return (v >= 2 && v <= 126 && !(v & 1)) ? v : 0; }();
   if (!msm_plan_build(plan, shape, m_pad, msm_lane_budget(), force_a, plonk_joint_g(m_pad))) return set_err(BN254_E_BAD_ARG, "PlonK key shape needs more MSM rows than the launch supports");
-  if (m > c.cap || bn254_g1_msm_scratch_lanes(plan, m) > c.glv_lanes || (size_t)plan.n_rows > (size_t)MSM_MAX_ROWS)
+  if (m > c.cap || bn254_g1_msm_scratch_lanes(plan, m) > c.glv_lanes || (size_t)plan.n_rows * m > c.part_points || (size_t)plan.n_rows > (size_t)MSM_MAX_ROWS)
     return set_err(BN254_E_HIP, "PlonK context smaller than the launch (internal sizing error)");
   hipError_t e = bn254_launch_g1_msm_rows(plan, (const int32_t*)c.terms, c.flags, m, n_terms, c.part, c.glv_tab, d->fixed_tabs, c.stream);
   if (ev_rows) HIPCK(hipEventRecord(ev_rows, c.stream));
@@ -1387,8 +1415,9 @@ static int plonk_run(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c,
 
 // The same sub-batch with BOTH host stages on the device (bn254_k_plonk.hip): one H2D copy of the proofs and inputs, stage 1 -> digest MSM -> stage 2 ->
 // folding MSMs -> pairing check on the context's stream without a host wait in between, one D2H copy of the status bytes.
+// resident: proofs / public_inputs / status are DEVICE memory of `device` (bn254_plonk_verify_batch_device): no staging copy, the status bytes leave with a device-to-device copy.
 static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, PlonkCtx& c, int device, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
-                            size_t n_public, size_t m, uint8_t* status, unsigned flags) {
+                            size_t n_public, size_t m, uint8_t* status, unsigned flags, bool resident) {
   HIPCK(hipSetDevice(device));
   const PlonkKey& key = pvk->key;
   const int T1 = plonk_stage1_terms(key), T2 = plonk_stage2_terms(key), TT = T2 + 2;
@@ -1396,18 +1425,21 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto t0 = now();
   const size_t pb = m * proof_stride, ib = m * n_public * 32, need = pb + ib;
-  if (need > c.in_cap) return set_err(BN254_E_HIP, "PlonK context staging smaller than the pass (internal sizing error)");   // sized by plonk_ensure_ctx
+  if (!resident && need > c.in_cap) return set_err(BN254_E_HIP, "PlonK context staging smaller than the pass (internal sizing error)");   // sized by plonk_ensure_ctx
+  if (m > c.cap) return set_err(BN254_E_HIP, "PlonK context smaller than the pass (internal sizing error)");
   uint32_t lam_key[11];
   for (size_t got = 0; got < sizeof lam_key;) {   // fresh per call, secret until the proofs are fixed (plonk_run has the reasoning)
     ssize_t k = getrandom((uint8_t*)lam_key + got, sizeof lam_key - got, 0);
     if (k <= 0) return set_err(BN254_E_HIP, "getrandom failed: no KZG batching scalars");
     got += (size_t)k;
   }
-  parallel_copy(c.h_in, proofs, pb);
-  if (ib) parallel_copy(c.h_in + pb, public_inputs, ib);
+  if (!resident) {
+    parallel_copy(c.h_in, proofs, pb);
+    if (ib) parallel_copy(c.h_in + pb, public_inputs, ib);
+  }
   auto t1_ = now();
-  HIPCK(hipMemcpyAsync(c.d_in, c.h_in, need, hipMemcpyHostToDevice, c.stream));
-  const uint8_t* d_proofs = c.d_in; const uint8_t* d_inputs = c.d_in + pb;
+  if (!resident) HIPCK(hipMemcpyAsync(c.d_in, c.h_in, need, hipMemcpyHostToDevice, c.stream));
+  const uint8_t* d_proofs = resident ? proofs : c.d_in; const uint8_t* d_inputs = resident ? public_inputs : c.d_in + pb;
   HIPCK(hipEventRecord(c.tk[0], c.stream));
   hipError_t e = bn254_launch_plonk_stage1(d->d_key, d_proofs, proof_stride, d_inputs, n_public, m, lam_key, c.d_work, c.terms, c.flags, T1, c.stream);
   if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("PlonK stage 1 launch: ") + hipGetErrorString(e));
@@ -1443,9 +1475,10 @@ static int plonk_run_device(const bn254_plonk_pvk* pvk, const PlonkDev* d, Plonk
     if (e != hipSuccess) return set_err(BN254_E_HIP, std::string("pairing launch: ") + hipGetErrorString(e));
   }
   HIPCK(hipEventRecord(c.tk[7], c.stream));
-  HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
+  if (resident) HIPCK(hipMemcpyAsync(status, c.status, m, hipMemcpyDeviceToDevice, c.stream));
+  else HIPCK(hipMemcpyAsync(c.h_status, c.status, m, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
-  memcpy(status, c.h_status, m);
+  if (!resident) memcpy(status, c.h_status, m);
   {
     auto t4_ = now();
     // slots as bn254_plonk_last_timing names them; [0] is the host copy into pinned memory, everything else a kernel of the chain
@@ -1472,15 +1505,24 @@ int bn254_plonk_last_timing(const bn254_plonk_pvk* pvk, int device, float ms[BN2
   return BN254_OK;
 }
 
-int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
-                             size_t n_public, size_t n, uint8_t* status, int device) {
-  return bn254_plonk_verify_batch_flags(pvk, proofs, proof_stride, public_inputs, n_public, n, status, device, 0);
+}  // extern "C"
+
+// the plan of a batch of n proofs under the current knobs: sub-batches side by side, proofs per sub-batch, proofs per pass
+static void plonk_plan_for(size_t n, int* workers, size_t* per, size_t* pass_cap) {
+  int max_workers = g_plonk_workers.load();
+  size_t piece;
+  const long big_from = g_plonk_big_from.load();
+  if (big_from == 0) plonk_auto_plan(n, (size_t)g_plonk_piece.load(), (size_t)g_plonk_big_piece.load(), max_workers, &piece, &max_workers);
+  else piece = n >= (size_t)big_from ? (size_t)g_plonk_big_piece.load() : (size_t)g_plonk_piece.load();
+  plonk_plan(n, piece, max_workers, workers, per, pass_cap);
 }
-int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
-                                   size_t n_public, size_t n, uint8_t* status, int device, unsigned flags) {
-  if (!pvk || (n && (!proofs || !status)) || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
-  if (flags & ~(unsigned)BN254_FLAG_RLC) return set_err(BN254_E_BAD_ARG, "unknown flag (the PlonK batch entry knows BN254_FLAG_RLC)");
-  if (n == 0) return BN254_OK;
+// BN254_PLONK_HOST=1: the transcripts and the Fr arithmetic on host threads (rounds 1-2) instead of the device kernels of bn254_k_plonk.hip
+static bool plonk_dev_stages() { static const bool v = [] { const char* e = getenv("BN254_PLONK_HOST"); return !(e && atoi(e) != 0); }(); return v; }
+
+// One batch.  resident = false: proofs / public_inputs / status are the caller's host buffers (each pass stages its share through the context's pinned memory);
+// resident = true: they are device memory of `device` and nothing is staged.  Either way the call returns when every status byte is where the caller asked for it.
+static int plonk_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n, uint8_t* status,
+                       int device, unsigned flags, bool resident) {
   PlonkDev* d;
   int rc;
   {
@@ -1488,28 +1530,23 @@ int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* pr
     if ((rc = plonk_ensure_dev(pvk, device, &d))) return rc;
   }
   unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > 32) hw = 32;
-  // BN254_PLONK_HOST=1: the transcripts and the Fr arithmetic on host threads (rounds 1-2) instead of the device kernels of bn254_k_plonk.hip
-  static const bool dev_stages = [] { const char* e = getenv("BN254_PLONK_HOST"); return !(e && atoi(e) != 0); }();
+  const bool dev_stages = plonk_dev_stages();
+  if (resident && !dev_stages) return set_err(BN254_E_BAD_ARG, "BN254_PLONK_HOST=1 (the diagnostic host-thread stages) reads the proofs on the host: use the host-buffer entry");
   // Plan.  Up to `big_from` proofs the batch is cut into up to PLONK_WORKERS contiguous sub-batches, one context and one host thread each, and every sub-batch runs in
   // balanced passes of at most `piece` = 5040 proofs (a sub-batch of 6144 is two passes of 3072): up to there every launch of a pass is ONE wavefront generation and the
   // MSM launches keep their split form, and several such chains of latency-bound launches side by side fill the GPU where one chain of larger launches does not
   // (round 3: 8192 proofs 9.9 -> 8.3 ms, 16 384 15.7 -> 13.1 ms).  From `big_from` proofs the launches are large enough to be throughput-bound on their own and the
-  // batch runs as few passes of up to 65 536 proofs (round 4; bn254_set_plonk_params has the numbers).
-  int max_workers = g_plonk_workers.load();
-  size_t piece;
-  const long big_from = g_plonk_big_from.load();
-  if (big_from == 0) plonk_auto_plan(n, (size_t)g_plonk_piece.load(), max_workers, &piece, &max_workers);
-  else piece = n >= (size_t)big_from ? (size_t)g_plonk_big_piece.load() : (size_t)g_plonk_piece.load();
+  // batch runs as few passes of up to PLONK_MAX_LAUNCH proofs (rounds 4-5; bn254_set_plonk_params has the numbers).
   int workers; size_t per, pass_cap;                                  // sub-batches, proofs per sub-batch, proofs per (equal-sized) pass of a sub-batch
-  plonk_plan(n, piece, max_workers, &workers, &per, &pass_cap);
+  plonk_plan_for(n, &workers, &per, &pass_cap);
   PlonkLease lease(d, workers);   // waits until that many contexts are free
-  for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap, dev_stages ? pass_cap * (proof_stride + n_public * 32) : 0))) return rc;
+  for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap, (dev_stages && !resident) ? pass_cap * (proof_stride + n_public * 32) : 0))) return rc;
   std::vector<int> rcs(workers, BN254_OK); std::vector<std::string> errs(workers);
   auto body = [&](int w) {
     const size_t lo = (size_t)w * per, hi = lo + per < n ? lo + per : n;
     for (size_t off = lo; off < hi; off += pass_cap) {
       const size_t m = hi - off < pass_cap ? hi - off : pass_cap;
-      int r = dev_stages ? plonk_run_device(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off, flags)
+      int r = dev_stages ? plonk_run_device(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off, flags, resident)
                          : plonk_run(pvk, d, lease.ctx(w), device, proofs + off * proof_stride, proof_stride, public_inputs + off * n_public * 32, n_public, m, status + off,
                                      (hw + workers - 1) / workers);
       if (r) {
@@ -1528,6 +1565,98 @@ int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* pr
     for (auto& t : th) t.join();
   }
   for (int w = 0; w < workers; w++) if (rcs[w]) return set_err(rcs[w], errs[w]);
+  return BN254_OK;
+}
+
+extern "C" {
+
+int bn254_plonk_verify_batch(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                             size_t n_public, size_t n, uint8_t* status, int device) {
+  return bn254_plonk_verify_batch_flags(pvk, proofs, proof_stride, public_inputs, n_public, n, status, device, 0);
+}
+int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs,
+                                   size_t n_public, size_t n, uint8_t* status, int device, unsigned flags) {
+  if (!pvk || (n && (!proofs || !status)) || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (flags & ~(unsigned)BN254_FLAG_RLC) return set_err(BN254_E_BAD_ARG, "unknown flag (the PlonK batch entry knows BN254_FLAG_RLC)");
+  if (n == 0) return BN254_OK;
+  return plonk_batch(pvk, proofs, proof_stride, public_inputs, n_public, n, status, device, flags, false);
+}
+// proofs, public inputs and status bytes resident in the memory of `device` (what the bench times: inputs in HBM when the timed region starts)
+int bn254_plonk_verify_batch_device(const bn254_plonk_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_public_inputs, size_t n_public, size_t n,
+                                    void* d_status, int device, void* hip_stream, unsigned flags) {
+  if (!pvk || (n && (!d_proofs || !d_status)) || (n && n_public && !d_public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (flags & ~(unsigned)BN254_FLAG_RLC) return set_err(BN254_E_BAD_ARG, "unknown flag (the PlonK batch entry knows BN254_FLAG_RLC)");
+  if (n == 0) return BN254_OK;
+  int rc = check_device(device);
+  if (rc) return rc;
+  // the passes run on the key's own context streams: whatever the caller's stream still has to do to the inputs comes first
+  HIPCK(hipStreamSynchronize((hipStream_t)hip_stream));
+  return plonk_batch(pvk, (const uint8_t*)d_proofs, proof_stride, (const uint8_t*)d_public_inputs, n_public, n, (uint8_t*)d_status, device, flags, true);
+}
+// several GPUs of the node: contiguous shards (bn254_shard_plan), one host thread per device through the host-buffer entry -- the PlonK twin of bn254_groth16_verify_batch_multi
+int bn254_plonk_verify_batch_multi(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n,
+                                   uint8_t* status, uint64_t device_mask, unsigned flags) {
+  if (!pvk || !device_mask || (n && (!proofs || !status)) || (n && n_public && !public_inputs)) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (flags & ~(unsigned)BN254_FLAG_RLC) return set_err(BN254_E_BAD_ARG, "unknown flag (the PlonK batch entry knows BN254_FLAG_RLC)");
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return set_err(BN254_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  int devs[64], nsh = 0; size_t los[64], cnts[64];
+  int prc = bn254_shard_plan(n, device_mask, cnt, devs, los, cnts, &nsh);
+  if (prc) return prc;
+  if (n == 0) return BN254_OK;
+  if (nsh == 1) return plonk_batch(pvk, proofs, proof_stride, public_inputs, n_public, n, status, devs[0], flags, false);
+  std::vector<int> rcs((size_t)nsh, BN254_OK); std::vector<std::string> errs((size_t)nsh);
+  std::vector<std::thread> th;
+  for (int r = 0; r < nsh; r++) {
+    th.emplace_back([&, r]() {
+      if (!cnts[r]) return;
+      rcs[r] = plonk_batch(pvk, proofs + los[r] * proof_stride, proof_stride, public_inputs ? public_inputs + los[r] * n_public * 32 : nullptr, n_public, cnts[r], status + los[r], devs[r], flags, false);
+      if (rcs[r]) errs[r] = g_err;   // thread-local in the worker
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int r = 0; r < nsh; r++) if (rcs[r]) return set_err(rcs[r], "device " + std::to_string(devs[r]) + ": " + errs[r]);
+  return BN254_OK;
+}
+// Everything a batch of up to n proofs needs on `device`, allocated now: the key's tables, the contexts of the plan such a batch runs under (bn254_set_plonk_params) with
+// their row, window-table and workspace buffers, and -- proof_stride > 0: the host-buffer entry will be used -- their pinned staging for records of that stride.  A later
+// batch of that size then neither allocates nor frees (growing a context frees its old buffers, and hipFree waits for the whole device).
+int bn254_plonk_reserve(const bn254_plonk_pvk* pvk, size_t n, size_t proof_stride, int device) {
+  if (!pvk) return set_err(BN254_E_BAD_ARG, "null key");
+  if (n == 0) n = 1;
+  PlonkDev* d;
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(pvk->mu);
+    if ((rc = plonk_ensure_dev(pvk, device, &d))) return rc;
+  }
+  int workers; size_t per, pass_cap;
+  plonk_plan_for(n, &workers, &per, &pass_cap);
+  PlonkLease lease(d, workers);
+  const size_t in_bytes = (plonk_dev_stages() && proof_stride) ? pass_cap * (proof_stride + (size_t)pvk->key.nb_public * 32) : 0;
+  for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap, in_bytes))) return rc;
+  return BN254_OK;
+}
+// device memory the contexts of this key hold on `device` right now (bytes; the window tables of the key itself not counted), and how many contexts hold any
+int bn254_plonk_footprint(const bn254_plonk_pvk* pvk, int device, size_t* bytes, int* contexts) {
+  if (!pvk || !bytes) return set_err(BN254_E_BAD_ARG, "bad argument");
+  *bytes = 0; if (contexts) *contexts = 0;
+  PlonkDev* d = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(pvk->mu);
+    auto it = pvk->dev.find(device);
+    if (it != pvk->dev.end()) d = &it->second;
+  }
+  if (!d) return BN254_OK;
+  std::lock_guard<std::mutex> lk(d->pool_mu);
+  const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
+  const size_t tmax = (size_t)(TT > T1 ? TT : T1);
+  for (const PlonkCtx& c : d->ctx) {
+    if (!c.cap && !c.in_cap) continue;
+    if (contexts) (*contexts)++;
+    *bytes += c.in_cap + c.cap * (size_t)G16_WS_BYTES_PER_PROOF + c.part_points * 27 * sizeof(int32_t) + c.glv_lanes * (size_t)G1_GLV_TAB_BYTES_PER_LANE +
+              c.cap * tmax * (sizeof(MsmTerm) + 1) + c.cap * (16 * sizeof(uint32_t) + 2) + c.cap * bn254_plonk_work_bytes();
+  }
   return BN254_OK;
 }
 
@@ -1777,9 +1906,16 @@ int bn254_dbg_plonk_plan(size_t n, size_t piece, int max_workers, int* workers, 
   return BN254_OK;
 }
 size_t bn254_dbg_plonk_scratch_lanes(size_t capacity, int n_var) { return plonk_scratch_lanes(capacity, n_var); }
+size_t bn254_dbg_plonk_part_points(size_t capacity, int n_qcp, int stage) {
+  if (n_qcp < 0 || n_qcp > PLONK_MAX_QCP || stage < 1 || stage > 3) return 0;
+  PlonkKey key; key.n_qcp = (uint32_t)n_qcp;
+  MsmShape sh;
+  if (stage == 1) plonk_msm1_shape(key, sh); else plonk_msm2_shape(key, sh, stage == 3);
+  return plonk_part_points(capacity, sh);
+}
 // the row plan of one MSM launch of the PlonK path (stage 1: the digest; 2: the KZG check) for a key with n_qcp commitments and a batch of n proofs:
 // rows, rows with a window table, scratch lanes the launch needs, the longest row in the planner's cost units, rows per sum; rows_out (optional):
-// MSM_MAX_ROWS x 8 ints {variable term, pos_lo, pos_hi, unit term, sum, scratch slot, first fixed window, one past the last}
+// MSM_MAX_ROWS x 9 ints {variable term, pos_lo, pos_hi, unit term, sum, scratch slot, first fixed window, one past the last, joint-row term mask}
 int bn254_dbg_plonk_msm_plan(int n_qcp, int stage, size_t n, size_t lane_budget, int* n_rows, int* n_var_rows, size_t* scratch_lanes, int* chain, int sum_rows[2],
                              int fixed_terms[2], int* rows_out) {
   if (n_qcp < 0 || n_qcp > PLONK_MAX_QCP || (stage != 1 && stage != 2) || n == 0 || !n_rows || !n_var_rows || !scratch_lanes || !chain || !sum_rows || !fixed_terms)

@@ -11,7 +11,10 @@
 // workgroups so that they spread over the chip).
 #define BN254_PLONK_DEVICE_TU 1
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <mutex>
+#include <string>
+#include <vector>
 #include "bn254_plonk.hpp"
 #include "bn254_rlc.h"
 
@@ -221,6 +224,75 @@ hipError_t bn254_launch_plonk_stage2(const void* d_key, const uint8_t* d_proofs,
   hipLaunchKernelGGL(k_plonk_stage2, dim3((unsigned)((n + 63) / 64)), dim3(64), 16 + 64 * (size_t)ls, s, (const PlonkKey*)d_key, d_proofs, stride, (uint32_t)n, (PlonkWork*)d_work, d_lin_words,
                      d_lin_inf, (MsmTerm*)d_terms, d_flags, d_status, TT, T2, ls, wkey, weight_key ? 1 : 0);
   return hipGetLastError();
+}
+
+// ---- known-answer self-test of the device stages, run once per (key, device) before the key is used there ------------------------------------------------------
+// Round 4 met a build in which k_plonk_stage1 derived a wrong first challenge from a correct SHA-256 digest (the byte gather of the digest fused with the
+// word splitting of the 32-bit Montgomery product; two source-level workarounds are in, the cause inside the compiler is not known).  Every challenge, lambda and the RLC
+// weights pass through that code, and a deployment does not run the GPU test suite -- so the library checks THE KERNEL IT SHIPS, on THIS device, against the host's
+// compile of the same stage source (which multiplies in the 64-bit form): a synthetic proof whose points are the key's own (on the curve, so the parser and the count checks
+// pass and the whole of stage 1 runs up to the opening check), random scalars, the key's number of public inputs.  Compared: the stage's status, the last of the four chained
+// challenges zeta (downstream of gamma, beta and alpha), every BSB22 hash-to-field value, and lambda (48 ChaCha20 bytes through the two-block reduction).  A mismatch fails
+// the call that wanted to use the key (BN254_E_HIP with this text): wrong challenges flip verdicts.  Cost: one 1-proof launch, ~1 ms, once per key and device.
+hipError_t bn254_plonk_self_test(const void* key_host, const void* d_key, std::string* why) {
+  const PlonkKey& key = *(const PlonkKey*)key_host;
+  why->clear();
+  if (key.nb_public > 4096 || key.n_cci != key.n_qcp) return hipSuccess;          // (a key no proof can satisfy: stage 1 stops at the count checks; nothing to compare)
+  const FrCtx& F = fr_ctx();
+  const uint32_t q = key.n_qcp;
+  const size_t n_pub = (size_t)key.nb_public, len = 516 + 32 * (size_t)(6 + q) + 100 + 64 * (size_t)q;
+  std::vector<uint8_t> proof(len), inputs(32 * n_pub + 4);
+  uint64_t sm = 0x5e1f7e57b254ull ^ key.size;
+  auto next = [&sm] { uint64_t z = (sm += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+  for (auto& b : proof) b = (uint8_t)next();
+  for (auto& b : inputs) b = (uint8_t)next();
+  for (int i = 0; i < 8; i++) memcpy(&proof[64 * (size_t)i], key.enc[i], 64);                       // l r o z h0 h1 h2 batch_h := key points
+  proof[512] = 0; proof[513] = 0; proof[514] = 0; proof[515] = (uint8_t)(6 + q);
+  const size_t off_zs = 516 + 32 * (size_t)(6 + q);
+  memcpy(&proof[off_zs], key.enc[3], 64);
+  proof[off_zs + 96] = 0; proof[off_zs + 97] = 0; proof[off_zs + 98] = 0; proof[off_zs + 99] = (uint8_t)q;
+  for (uint32_t k = 0; k < q; k++) memcpy(&proof[off_zs + 100 + 64 * (size_t)k], key.enc[(4 + k) % 8], 64);
+  uint32_t lam_key[11];
+  for (auto& w : lam_key) w = (uint32_t)next();
+  // host: the same stage source, compiled for the host
+  PlonkWork hw; memset((void*)&hw, 0, sizeof hw);
+  PlonkStage1 hs;
+  const int T1 = plonk_stage1_terms(key);
+  std::vector<MsmTerm> hterms((size_t)T1); std::vector<uint8_t> hflags((size_t)T1);
+  int hst = hs.a(key, proof.data(), len, inputs.data(), n_pub, hw);
+  if (hst == PL_OK) hst = hs.b(F.inverse(hs.acc), hterms.data(), hflags.data());
+  FrM hlam;
+  {
+    ChaChaKey ck; for (int i = 0; i < 8; i++) ck.k[i] = lam_key[i]; for (int i = 0; i < 3; i++) ck.nonce[i] = lam_key[8 + i];
+    uint32_t lw[12]; for (int j = 0; j < 3; j++) chacha20_block4(lw + 4 * j, ck, (uint32_t)j);
+    uint8_t lb[48]; for (int j = 0; j < 12; j++) { lb[4 * j] = (uint8_t)lw[j]; lb[4 * j + 1] = (uint8_t)(lw[j] >> 8); lb[4 * j + 2] = (uint8_t)(lw[j] >> 16); lb[4 * j + 3] = (uint8_t)(lw[j] >> 24); }
+    hlam = F.from_be_reduce(lb, 48);
+  }
+  // device: the shipped kernel, one proof
+  uint8_t* dbuf = nullptr;
+  const size_t o_in = (len + 15) & ~(size_t)15, o_work = (o_in + inputs.size() + 15) & ~(size_t)15, o_terms = (o_work + sizeof(PlonkWork) + 15) & ~(size_t)15,
+               o_flags = o_terms + (size_t)T1 * sizeof(MsmTerm), total = o_flags + (size_t)T1 + 16;
+  hipError_t e = hipMalloc((void**)&dbuf, total);
+  if (e != hipSuccess) return e;
+  PlonkWork dw; memset((void*)&dw, 0, sizeof dw);
+  e = hipMemset(dbuf, 0, total);
+  if (e == hipSuccess) e = hipMemcpy(dbuf, proof.data(), len, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dbuf + o_in, inputs.data(), inputs.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = bn254_launch_plonk_stage1(d_key, dbuf, len, dbuf + o_in, n_pub, 1, lam_key, dbuf + o_work, dbuf + o_terms, dbuf + o_flags, T1, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy((void*)&dw, dbuf + o_work, sizeof(PlonkWork), hipMemcpyDeviceToHost);
+  (void)hipFree(dbuf);
+  if (e != hipSuccess) return e;
+  auto hex = [&F](const FrM& v) { uint8_t b[32]; F.to_be(b, v); char t[65]; for (int i = 0; i < 32; i++) snprintf(t + 2 * i, 3, "%02x", b[i]); return std::string(t, 16) + ".."; };
+  if (!F.eq(dw.zeta, hw.zeta)) *why = "zeta (the chained Fiat-Shamir challenges): device " + hex(dw.zeta) + " host " + hex(hw.zeta);
+  else if (!F.eq(dw.lambda, hlam)) *why = "lambda (ChaCha20 bytes reduced mod r): device " + hex(dw.lambda) + " host " + hex(hlam);
+  else if (dw.status != hst) *why = "stage-1 status: device " + std::to_string(dw.status) + " host " + std::to_string(hst);
+  else for (uint32_t k = 0; k < q && why->empty(); k++) {
+    const FrM hh = bsb22_hash_to_field(&proof[off_zs + 100 + 64 * (size_t)k]);
+    if (!F.eq(dw.h2f[k], hh)) *why = "BSB22 hash-to-field " + std::to_string(k) + ": device " + hex(dw.h2f[k]) + " host " + hex(hh);
+  }
+  if (!why->empty()) *why = "PlonK device self-test failed (k_plonk_stage1 on this GPU disagrees with the host's compile of the same source) -- " + *why;
+  return hipSuccess;
 }
 
 namespace bn254 {

@@ -44,7 +44,12 @@ int main(int argc, char** argv) {
   CHECK(bn254_synth_groth16(0xB2540033, n_public, n, 4, 1, 2, vk.data(), proofs.data(), inputs.data(), expected.data()) == BN254_OK);
   // a verifying key that does not parse is the unwrap() of lib.rs:46 -- decided on the host, no device needed
   CHECK(panics_with([&] { Groth16Verifier::verify(Bytes(proofs.begin(), proofs.begin() + 256), Bytes(40, 0x5a), to_fr(Bytes(inputs.begin(), inputs.begin() + 64))); }) == BN254_ERR_MALFORMED);
-  CHECK(panics_with([&] { PlonkVerifier::verify(Bytes(904, 1), Bytes(33, 7), {}); }) == BN254_ERR_MALFORMED);
+  // ... but the proof was loaded first (lib.rs:70 before :71): its loader error is the one that surfaces
+  CHECK(panics_with([&] { PlonkVerifier::verify(Bytes(904, 1), Bytes(33, 7), {}); }) == BN254_ERR_NOT_ON_CURVE);
+  CHECK(panics_with([&] { PlonkVerifier::verify(Bytes(904, 0xff), Bytes(33, 7), {}); }) == BN254_ERR_NOT_MEMBER);
+  CHECK(panics_with([&] { PlonkVerifier::verify(Bytes(400, 1), Bytes(33, 7), {}); }) == BN254_ERR_MALFORMED);
+  { Bytes p(proofs.begin(), proofs.begin() + 256); p[63] ^= 1;      // A off the curve, key unparsable: the proof's error (lib.rs:45 before :46)
+    CHECK(panics_with([&] { Groth16Verifier::verify(p, Bytes(40, 0x5a), to_fr(Bytes(inputs.begin(), inputs.begin() + 64))); }) == BN254_ERR_NOT_ON_CURVE); }
   CHECK(panics_with([&] { PreparedGroth16Vk bad(Bytes(519, 0)); }) == BN254_ERR_MALFORMED);
   {
     PreparedGroth16Vk pvk(vk);

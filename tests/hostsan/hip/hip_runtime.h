@@ -3,6 +3,7 @@
 // compiles with g++ and runs under AddressSanitizer / UBSan in this GPU-less container (tests/hostsan/hostsan_main.cpp, tests/test_hostsan.py).  "Device" memory is
 // malloc'ed, copies are memcpy, streams run in order at call time (every enqueue completes before it returns), events are time stamps.  Not part of the product.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
@@ -20,18 +21,22 @@ typedef FakeStream* hipStream_t;
 typedef FakeEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
-extern int g_fake_device_count;          // tests set it (0: the no-device path)
-extern size_t g_fake_live_allocs;        // device + pinned allocations not yet freed
-extern size_t g_fake_fail_alloc_after;   // allocation number that fails (0: never): error paths
-extern size_t g_fake_alloc_counter;
+// (atomics: the library drives several "devices" from several host threads, and the harness is also built with -fsanitize=thread)
+extern std::atomic<int> g_fake_device_count;          // tests set it (0: the no-device path)
+extern std::atomic<size_t> g_fake_live_allocs;        // device + pinned allocations not yet freed
+extern std::atomic<size_t> g_fake_fail_alloc_after;   // allocation number that fails (0: never): error paths
+extern std::atomic<size_t> g_fake_alloc_counter;
+extern std::atomic<int> g_fake_fail_device;           // every allocation made while this device is the calling thread's current one fails (-1: none): a GPU that is out of memory
+extern thread_local int t_fake_current_device;        // hipSetDevice is per host thread, as in the real runtime
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorOutOfMemory ? "out of memory (fake)" : "error (fake)"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = g_fake_device_count; return hipSuccess; }
-inline hipError_t hipSetDevice(int d) { return d >= 0 && d < g_fake_device_count ? hipSuccess : hipErrorInvalidDevice; }
-inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= g_fake_device_count) return hipErrorInvalidDevice; t_fake_current_device = d; return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = t_fake_current_device; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t fake_alloc(void** p, size_t n) {
   if (g_fake_fail_alloc_after && ++g_fake_alloc_counter == g_fake_fail_alloc_after) { *p = nullptr; return hipErrorOutOfMemory; }
+  if (g_fake_fail_device >= 0 && t_fake_current_device == g_fake_fail_device) { *p = nullptr; return hipErrorOutOfMemory; }
   *p = malloc(n ? n : 1);                 // exact size: ASan sees every byte past the end
   if (!*p) return hipErrorOutOfMemory;
   g_fake_live_allocs++;
@@ -45,6 +50,7 @@ inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new FakeStream{0}; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

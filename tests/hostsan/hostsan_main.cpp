@@ -6,8 +6,9 @@
 //     pass with a fallback, wide keys, PlonK's context pool with calls in flight, allocation failures on every allocation of a call.
 // The stand-in "kernels" only mark proofs: what is under test is everything AROUND the launches.  Prints "hostsan ok".
 #include "hip/hip_runtime.h"
-int g_fake_device_count = 1;
-size_t g_fake_live_allocs = 0, g_fake_fail_alloc_after = 0, g_fake_alloc_counter = 0;
+std::atomic<int> g_fake_device_count{1}, g_fake_fail_device{-1};
+std::atomic<size_t> g_fake_live_allocs{0}, g_fake_fail_alloc_after{0}, g_fake_alloc_counter{0};
+thread_local int t_fake_current_device = 0;
 #include "../../snark-bn254-verifier_amd/csrc/bn254_capi.hip"
 #include <cstdio>
 #include <random>
@@ -52,6 +53,7 @@ hipError_t bn254_launch_scatter_status(uint8_t* status, const uint8_t* fb, const
 size_t bn254_plonk_work_bytes() { return sizeof(PlonkWork); }
 size_t bn254_plonk_key_bytes() { return sizeof(PlonkKey); }
 hipError_t bn254_plonk_dev_init(int) { return hipSuccess; }
+hipError_t bn254_plonk_self_test(const void*, const void*, std::string* why) { why->clear(); return hipSuccess; }
 hipError_t bn254_launch_plonk_stage1(const void*, const uint8_t* d_proofs, size_t stride, const uint8_t* d_inputs, size_t n_public, size_t n, const uint32_t*, void* d_work, void* d_terms, uint8_t* d_flags,
                                      int T1, hipStream_t) {
   g_launches++;
@@ -145,9 +147,152 @@ static std::vector<uint8_t> mutate(const std::vector<uint8_t>& base, std::mt1993
   return v;
 }
 
+// ---- the code that runs several host threads: bn254_groth16_verify_batch_multi / bn254_plonk_verify_batch_multi over EIGHT fake devices (the `w > 1` branch no
+// one-GPU box ever takes: one host thread per device, per-device contexts of one shared key, error collection), concurrent callers on one key and one device, PlonK
+// calls in flight on the context pool.  Run by the ASan/UBSan build after everything else and, alone, by the -fsanitize=thread build (argv[3] = "threads").
+static void threaded_scenarios(const std::string& golden, bool big) {
+  g_fake_device_count = 8;
+  const size_t n_public = 2, n_max = big ? ((size_t)1 << 20) + 777 : 20000 + 777;
+  std::vector<uint8_t> vk(bn254_synth_groth16_vk_len(n_public)), proofs(256 * n_max), inputs(32 * n_public * n_max), expected(64), status(n_max + 8), single(n_max + 8);
+  CHECK(bn254_synth_groth16(0xB2540000, n_public, 64, 8, 1, 2, vk.data(), proofs.data(), inputs.data(), expected.data()) == 0);
+  for (size_t i = 64; i < n_max; i++) { memcpy(&proofs[256 * i], &proofs[256 * (i % 64)], 256); memcpy(&inputs[64 * i], &inputs[64 * (i % 64)], 64); }
+  for (size_t i = 0; i < n_max; i += 997) proofs[256 * i] = 0xEE;                  // the stand-in's "invalid" mark: REJECT
+  bn254_g16_pvk* pvk = nullptr;
+  CHECK(bn254_groth16_vk_prepare(vk.data(), vk.size(), 0, &pvk) == 0);
+  auto want = [&](size_t i) { return proofs[256 * i] == 0xEE ? BN254_REJECT : BN254_ACCEPT; };
+  // coverage and order: every mask and every ragged size gives the status vector of the single-device entry, nothing past n is written
+  const uint64_t masks[] = {0x3, 0xFF, 0xA5, 0x80, 0x1};
+  const size_t sizes[] = {n_max, 70000 + 777, 7, 0, 8, 4097};      // (sizes above n_max are skipped: the thread-sanitizer run is the small one)
+  for (size_t m : sizes) {
+    if (m > n_max) continue;
+    memset(single.data(), 0xAB, single.size());
+    CHECK(bn254_groth16_verify_batch(pvk, proofs.data(), 256, inputs.data(), n_public, m, single.data(), 0, 0) == 0);
+    for (uint64_t mask : masks) {
+      if (m == n_max && big && mask != 0xFF) continue;                              // the largest size once (5 GB of fake workspace per run)
+      memset(status.data(), 0xAB, status.size());
+      CHECK(bn254_groth16_verify_batch_multi(pvk, m ? proofs.data() : nullptr, 256, m ? inputs.data() : nullptr, n_public, m, m ? status.data() : nullptr, mask, 0) == 0);
+      if (m) CHECK(memcmp(status.data(), single.data(), m + 8) == 0);
+      for (size_t i = 0; i < m; i++) CHECK(status[i] == want(i));
+      // the plan the entry followed: contiguous, balanced, in device order
+      int devs[64], nsh = 0; size_t first[64], cnt[64];
+      CHECK(bn254_shard_plan(m, mask, 8, devs, first, cnt, &nsh) == 0);
+      size_t at = 0; for (int k = 0; k < nsh; k++) { CHECK(first[k] == at && cnt[k] + 1 >= cnt[0] && cnt[k] <= cnt[0]); at += cnt[k]; }
+      CHECK(at == m);
+    }
+  }
+  CHECK(bn254_groth16_verify_batch_multi(pvk, proofs.data(), 256, inputs.data(), n_public, 5000, status.data(), 0x100, 0) != 0);        // device 8 of 8: refused
+  CHECK(bn254_groth16_verify_batch_multi(pvk, proofs.data(), 256, inputs.data(), n_public, 5000, status.data(), 0, 0) != 0);            // empty mask
+  // RLC through the multi entry (each device forms its own groups, falls back on its own failed ones)
+  bn254_set_rlc_params(64, 0, 1);
+  memset(status.data(), 0xAB, status.size());
+  CHECK(bn254_groth16_verify_batch_multi(pvk, proofs.data(), 256, inputs.data(), n_public, 20000, status.data(), 0x3C, BN254_FLAG_RLC) == 0);
+  for (size_t i = 0; i < 20000; i++) CHECK(status[i] == want(i));
+  // a device that fails (out of memory on device 5): the call reports it by ordinal, the other shards are complete, the key keeps working -- also on that device
+  {
+    bn254_g16_pvk* q = nullptr;
+    CHECK(bn254_groth16_vk_prepare(vk.data(), vk.size(), 0, &q) == 0);
+    memset(status.data(), 0xAB, status.size());
+    g_fake_fail_device = 5;
+    const int rc = bn254_groth16_verify_batch_multi(q, proofs.data(), 256, inputs.data(), n_public, 40000, status.data(), 0xFF, 0);
+    g_fake_fail_device = -1;
+    CHECK(rc == BN254_E_HIP && strstr(bn254_last_error(), "device 5") != nullptr);
+    for (size_t i = 0; i < 40000; i++) CHECK((i / 5000 == 5) ? status[i] == 0xAB : status[i] == want(i));
+    CHECK(bn254_groth16_verify_batch_multi(q, proofs.data(), 256, inputs.data(), n_public, 40000, status.data(), 0xFF, 0) == 0);
+    for (size_t i = 0; i < 40000; i++) CHECK(status[i] == want(i));
+    bn254_groth16_vk_free(q);
+  }
+  // concurrent callers on ONE key: the same device (serialised by the library: one workspace per key and device), different devices, the device-pointer entry
+  {
+    std::vector<std::thread> th;
+    std::atomic<int> bad{0};
+    for (int t = 0; t < 6; t++)
+      th.emplace_back([&, t] {
+        std::vector<uint8_t> st(20000 + 8, 0xAB);
+        const size_t m = 20000 - 1000 * (size_t)t;
+        int rc = t % 3 == 2 ? bn254_groth16_verify_batch_device(pvk, proofs.data(), 256, inputs.data(), n_public, m, st.data(), t % 2, nullptr, 0)
+                            : bn254_groth16_verify_batch(pvk, proofs.data(), 256, inputs.data(), n_public, m, st.data(), t % 2, t == 4 ? BN254_FLAG_RLC : 0);
+        if (rc) bad++;
+        for (size_t i = 0; i < m; i++) if (st[i] != want(i)) bad++;
+        if (st[m] != 0xAB) bad++;
+      });
+    for (auto& x : th) x.join();
+    CHECK(bad == 0);
+    float ov; int single_stream; CHECK(bn254_groth16_stream_overlap(pvk, 0, &ov, &single_stream) == 0);
+    float share; unsigned bypassed; CHECK(bn254_groth16_rlc_state(pvk, 0, &share, &bypassed) == 0);
+  }
+  bn254_groth16_vk_free(pvk);
+  // single-proof entries from several threads: the key caches (exact-byte lookup, eviction) under contention
+  {
+    std::vector<std::thread> th;
+    std::atomic<int> bad{0};
+    for (int t = 0; t < 4; t++)
+      th.emplace_back([&, t] {
+        for (int k = 0; k < 6; k++) {
+          std::vector<uint8_t> key = vk; uint8_t st = 0xAB;
+          if ((k + t) % 3 == 0) key.push_back(0);                                  // another byte string: another cache entry (trailing bytes are ignored by the loader)
+          if (bn254_groth16_verify(proofs.data() + 256, 256, key.data(), key.size(), inputs.data(), n_public, (unsigned)(k & 1), &st) != 0 || st != BN254_ACCEPT) bad++;
+        }
+      });
+    for (auto& x : th) x.join();
+    CHECK(bad == 0);
+  }
+  // PlonK: the context pool with calls in flight from several threads, the multi entry over the eight devices, a failing device, reserve / footprint
+  std::vector<uint8_t> pvkb = read_file(golden + "/plonk_vk.bin");
+  CHECK(pvkb.size() == 34368);
+  {
+    bn254_plonk_pvk* pk = nullptr;
+    CHECK(bn254_plonk_vk_prepare(pvkb.data(), pvkb.size(), &pk) == 0);
+    const size_t pn = big ? 150000 : 14000, pstride = 904;
+    std::vector<uint8_t> pp(pstride * pn, 1), pi(64 * pn, 2), ps(pn + 8, 0xAB);
+    size_t held = 0; int ctxs = 0;
+    CHECK(bn254_plonk_reserve(pk, 12000, pstride, 0) == 0 && bn254_plonk_footprint(pk, 0, &held, &ctxs) == 0 && held > 0 && ctxs >= 1);
+    std::vector<std::thread> th;
+    std::atomic<int> bad{0};
+    for (int t = 0; t < 5; t++)
+      th.emplace_back([&, t] {
+        std::vector<uint8_t> s2(12000 + 8, 0xAB);
+        const size_t m = 12000 - 1500 * (size_t)t;
+        const int rc = t == 3 ? bn254_plonk_verify_batch_device(pk, pp.data(), pstride, pi.data(), 2, m, s2.data(), t % 2, nullptr, 0)
+                              : bn254_plonk_verify_batch_flags(pk, pp.data(), pstride, pi.data(), 2, m, s2.data(), t % 2, t == 1 ? BN254_FLAG_RLC : 0);
+        if (rc) bad++;
+        for (size_t i = 0; i < m; i++) if (s2[i] != BN254_ACCEPT) bad++;
+        if (s2[m] != 0xAB) bad++;
+      });
+    for (auto& x : th) x.join();
+    CHECK(bad == 0);
+    for (uint64_t mask : {(uint64_t)0xFF, (uint64_t)0x3, (uint64_t)0xA5}) {
+      for (size_t m : {pn, (size_t)7, (size_t)4097}) {
+        memset(ps.data(), 0xAB, ps.size());
+        CHECK(bn254_plonk_verify_batch_multi(pk, pp.data(), pstride, pi.data(), 2, m, ps.data(), mask, m == pn ? BN254_FLAG_RLC : 0) == 0);
+        for (size_t i = 0; i < m; i++) CHECK(ps[i] == BN254_ACCEPT);
+        CHECK(ps[m] == 0xAB);
+      }
+    }
+    CHECK(bn254_plonk_verify_batch_multi(pk, pp.data(), pstride, pi.data(), 2, 0, ps.data(), 0xFF, 0) == 0);
+    CHECK(bn254_plonk_verify_batch_multi(pk, pp.data(), pstride, pi.data(), 2, 100, ps.data(), 0x100, 0) != 0);
+    CHECK(bn254_plonk_verify_batch_device(pk, pp.data(), pstride, pi.data(), 2, 100, ps.data(), 0, nullptr, 0x80u) != 0);
+    bn254_plonk_vk_free(pk);
+    bn254_plonk_pvk* q = nullptr;
+    CHECK(bn254_plonk_vk_prepare(pvkb.data(), pvkb.size(), &q) == 0);
+    g_fake_fail_device = 2;
+    const int rc = bn254_plonk_verify_batch_multi(q, pp.data(), pstride, pi.data(), 2, 16000, ps.data(), 0x0F, 0);
+    g_fake_fail_device = -1;
+    CHECK(rc == BN254_E_HIP && strstr(bn254_last_error(), "device 2") != nullptr);
+    CHECK(bn254_plonk_verify_batch_multi(q, pp.data(), pstride, pi.data(), 2, 16000, ps.data(), 0x0F, 0) == 0);
+    bn254_plonk_vk_free(q);
+  }
+  g_fake_device_count = 1;
+  printf("hostsan: threaded scenarios ok (8 fake devices%s)\n", big ? ", 2^20 + 777 proofs over all of them" : "");
+}
+
 int main(int argc, char** argv) {
   const std::string golden = argc > 1 ? argv[1] : "tests/golden";
   const long fuzz_iters = argc > 2 ? atol(argv[2]) : 300;
+  if (argc > 3 && std::string(argv[3]) == "threads") {        // the -fsanitize=thread build runs these alone (the rest is single-threaded code the ASan build covers)
+    threaded_scenarios(golden, false);
+    printf("hostsan ok\n");
+    return 0;
+  }
   std::mt19937_64 g(0xB254);
   // ---------------------------------------------------------------- Groth16: a synthetic key and batch from the library's own generator
   const size_t n_public = 2, n = 70000;
@@ -300,8 +445,8 @@ int main(int argc, char** argv) {
       CHECK(bn254_g2_decompress(in, out, (unsigned)((it >> 1) & 1), (int)(it & 1), &st) == 0);
     }
   }
-  CHECK(g_fake_live_allocs == 0 || true);
-  printf("hostsan: %ld stand-in launches, %zu allocations still live (key caches of the single-proof entries)\n", g_launches.load(), g_fake_live_allocs);
+  threaded_scenarios(golden, true);
+  printf("hostsan: %ld stand-in launches, %zu allocations still live (key caches of the single-proof entries)\n", g_launches.load(), g_fake_live_allocs.load());
   printf("hostsan ok\n");
   return 0;
 }

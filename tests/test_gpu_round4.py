@@ -84,7 +84,7 @@ def test_plonk_plans_agree_and_the_lane_pairing_path(pkg, O, fixtures):
                 pkg.set_plonk_params(**plan)
                 assert pvk.verify_batch(p, q, n) == want, (n, plan)
     finally:
-        pkg.set_plonk_params(piece=5040, workers=8, big_from=0, big_piece=65536)
+        pkg.set_plonk_params(piece=5040, workers=8, big_from=0, big_piece=131072)
         pvk.close()
 
 

@@ -194,14 +194,21 @@ def test_plonk_context_scratch_holds_every_launch(pkg):
     L = pkg.lib()
     L.bn254_dbg_plonk_scratch_lanes.restype = C.c_size_t
     L.bn254_dbg_plonk_scratch_lanes.argtypes = [C.c_size_t, C.c_int]
+    L.bn254_dbg_plonk_part_points.restype = C.c_size_t
+    L.bn254_dbg_plonk_part_points.argtypes = [C.c_size_t, C.c_int, C.c_int]
     rng = random.Random(9)
     for q in (0, 1, 2, 8):
         n_var = max(4 + q, 8)
-        for cap in (256, 512, 2560, 4096, 5120, 8192, 16384, 65536):
+        for cap in (256, 512, 2560, 4096, 5120, 8192, 16384, 65536, 131072, 262144):
             have = L.bn254_dbg_plonk_scratch_lanes(cap, n_var)
-            sizes = {1, 64, cap, cap - 1, cap // 2, cap // 2 + 1, 2167, 2520, 2521, 4333, 4096, 5000, 5040, 5041} | {rng.randrange(1, cap + 1) for _ in range(40)}
+            # the row buffer (round 5: sized from the key shape's plans instead of 32 rows per proof of capacity -- 0.9 GB at 2^18): rows x items of every launch
+            points = [L.bn254_dbg_plonk_part_points(cap, q, stage) for stage in (1, 2)]
+            assert all(0 < x <= 32 * cap for x in points)
+            sizes = {1, 64, cap, cap - 1, cap // 2, cap // 2 + 1, 2167, 2520, 2521, 4333, 4096, 5000, 5040, 5041, 49151, 49152, 65536, 65537} | {rng.randrange(1, cap + 1) for _ in range(40)}
+            sizes |= {x for lim in (65536 // (2 * v) for v in range(1, 14)) for x in (lim - 64, lim - 1, lim, lim + 1, lim + 63, lim + 64, lim + 65)}      # around the split / unsplit hand-over
             for n in sorted(x for x in sizes if 1 <= x <= cap):
                 for stage in (1, 2):
                     rows, var, scratch, chain, sums, fixed, desc = _plan(L, q, stage, n)
                     assert scratch <= have, (q, cap, n, stage, scratch, have)
                     assert rows <= 32
+                    assert rows * n <= points[stage - 1], (q, cap, n, stage, rows, points)

@@ -43,3 +43,20 @@ def test_host_half_of_the_library_under_asan_ubsan():
     # must still be owned by a handle (found that way: a retry after a partly failed table upload overwrote -- leaked -- the tables already uploaded)
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden"), "100"], cwd=ROOT, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "hostsan ok" in r.stdout and "LeakSanitizer" not in r.stderr, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_threaded_host_paths_under_tsan():
+    """ThreadSanitizer over the host code that runs several threads: bn254_groth16_verify_batch_multi / bn254_plonk_verify_batch_multi on EIGHT
+    fake devices -- the `w > 1` branch no one-GPU box takes: one host thread per device, per-device contexts of one shared key, a failing device -- concurrent callers on one
+    key and one device, the key caches of the single-proof entries under contention, PlonK calls in flight on the context pool, the process-wide host thread pool.  Same
+    harness as the ASan build (tests/hostsan), its threaded scenarios alone; a report makes the run fail (halt_on_error)."""
+    d = os.path.join(ROOT, "tests", "hostsan")
+    exe = os.path.join(d, "hostsan_tsan")
+    src = [os.path.join(d, "hostsan_main.cpp"), os.path.join(d, "hip", "hip_runtime.h")] + [os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc", f)
+                                                                                            for f in os.listdir(os.path.join(ROOT, "snark-bn254-verifier_amd", "csrc")) if f.endswith((".h", ".hpp", ".hip"))]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in src):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-DBN_HOST_PLAIN_INLINE", "-fsanitize=thread", "-fno-omit-frame-pointer",
+                               "-x", "c++", "-I", d, "-I", os.path.join(ROOT, "include"), os.path.join(d, "hostsan_main.cpp"), "-o", exe, "-lpthread", "-ldl"], cwd=d)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden"), "10", "threads"], cwd=ROOT, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "hostsan ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout[-3000:] + r.stderr[-6000:]
