@@ -243,9 +243,11 @@ int bn254_groth16_last_kernel_ms(const bn254_g16_pvk* pvk, int device, float ms[
 int bn254_groth16_rlc_state(const bn254_g16_pvk* pvk, int device, float* fallback_share, unsigned* bypassed_calls);   /* BN254_FLAG_RLC, adaptive use */
 /* A large batch runs as two sub-batches on two streams; the HIP runtime maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
  * streams that share a queue run one after the other.  The library does not touch the environment (GPU_MAX_HW_QUEUES=8 is a deployment setting);
- * it measures: the first two-stream batch of a (key, device) is bracketed with events, a later call reads them.  overlap = sum of the two sub-batches' durations /
- * their union (~2 side by side, ~1 one after the other; -1 not measured yet); single_stream = 1: the streams were found serialised and batches that fit one launch
- * now run as one sub-batch.  bn254_last_diagnostic (thread-local, like bn254_last_error) carries the one-line explanation when that happens. */
+ * it measures: a two-stream batch of a (key, device) is bracketed with events, a later call reads them.  overlap = sum of the two sub-batches' durations /
+ * their union (~2 side by side, ~1 one after the other; -1 not measured yet).  One measurement decides nothing (another tenant's kernels, a tool that serialises dispatches):
+ * three in a row must read "one after the other" before single_stream = 1 (batches that fit one launch then run as one sub-batch), one that reads "side by side" settles it
+ * the other way; on single_stream every 256th batch runs two sub-batches again and is measured, so a transient cause does not pin the key to the slower plan.  The one-line
+ * explanation is kept per (key, device): this call copies it to the calling thread's bn254_last_diagnostic(). */
 int bn254_groth16_stream_overlap(const bn254_g16_pvk* pvk, int device, float* overlap, int* single_stream);
 const char* bn254_last_diagnostic(void);
 /* Knobs of BN254_FLAG_RLC (process-wide, atomics; a negative argument leaves that knob alone): the batch size from which the flag is honoured

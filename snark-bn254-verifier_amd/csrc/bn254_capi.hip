@@ -116,7 +116,14 @@ struct DevState {
   // do the sub-batch streams overlap?  ov_ev: start / end of part 0 and of part 1 of the first two-stream batch; ov_state 0: not measured, 1: events recorded,
   // 2: measured (ov_ratio = sum of the two durations / their union: ~2 side by side, ~1 one after the other); single_stream: fall back to one sub-batch per launch
   hipEvent_t ov_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int ov_state = 0; float ov_ratio = -1.f; bool single_stream = false;
+  // the decision is not taken from one measurement (another tenant's kernels, a profiler that serialises dispatches): OV_AGREE consecutive measurements must say
+  // "serialised" before the plan changes, a measurement that says "side by side" resets the count; once on one sub-batch per launch, every OV_REPROBE-th batch runs two
+  // again and is measured, so that a transient cause does not pin the key to the slower plan for its lifetime.  `diag`: the explanation, per (key, device), handed out by
+  // bn254_groth16_stream_overlap through bn254_last_diagnostic() of the calling thread
+  int ov_serial_votes = 0; unsigned ov_batches = 0; bool ov_probe = false; std::string diag;
 };
+#define OV_AGREE 3
+#define OV_REPROBE 256
 struct bn254_g16_pvk {
   G16Prepared host;
   mutable G16PreparedRlc rlc_host;       // built on the first BN254_FLAG_RLC batch (under mu)
@@ -630,20 +637,32 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
         hipEventElapsedTime(&s1, d->ov_ev[0], d->ov_ev[2]) == hipSuccess && hipEventElapsedTime(&e1, d->ov_ev[0], d->ov_ev[3]) == hipSuccess) {
       const float lo_ = s1 < 0 ? s1 : 0, hi_ = e1 > a0 ? e1 : a0;
       d->ov_ratio = (a0 + a1) / (hi_ - lo_ > 1e-6f ? hi_ - lo_ : 1e-6f);
-      d->ov_state = 2;
       static const bool fallback = [] { const char* e = getenv("BN254_STREAM_FALLBACK"); return !e || atoi(e) != 0; }();
       if (d->ov_ratio < 1.15f) {
-        d->single_stream = fallback;
-        g_diag = "the two sub-batch streams of a Groth16 batch ran one after the other on this device (overlap " + std::to_string(d->ov_ratio) +
-                 "): the process's streams share a hardware queue -- set GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises (INTEGRATION.md)" +
-                 (fallback ? "; using one sub-batch per launch" : "");
+        d->ov_serial_votes++;
+        if (d->ov_serial_votes >= OV_AGREE || d->ov_probe) {
+          d->single_stream = fallback;
+          d->diag = "the two sub-batch streams of a Groth16 batch ran one after the other on this device (overlap " + std::to_string(d->ov_ratio) + ", " +
+                    std::to_string(d->ov_serial_votes) + " measurements in a row): the process's streams share a hardware queue -- set GPU_MAX_HW_QUEUES=8 before the HIP runtime "
+                    "initialises (INTEGRATION.md)" + (fallback ? "; using one sub-batch per launch, re-measured every " + std::to_string(OV_REPROBE) + " batches" : "");
+        }
+      } else {
+        d->ov_serial_votes = 0;
+        if (d->single_stream) d->diag = "the sub-batch streams overlap again (" + std::to_string(d->ov_ratio) + "): back to two sub-batches side by side";
+        d->single_stream = false;
       }
+      // keep measuring until the question is settled either way: OV_AGREE agreeing answers
+      d->ov_state = (d->ov_serial_votes > 0 && d->ov_serial_votes < OV_AGREE && !d->single_stream) ? 0 : 2;
     } else d->ov_state = 2;
+    d->ov_probe = false;
   }
+  // on one sub-batch per launch: every OV_REPROBE-th batch tries two streams again and is measured
+  bool probe_now = false;
+  if (d->single_stream && d->ov_state == 2 && ++d->ov_batches % OV_REPROBE == 0) { probe_now = true; d->ov_probe = true; d->ov_state = 0; }
   for (size_t off = 0; off < n; off += chunk) {
     size_t m = n - off < chunk ? n - off : chunk;
     G16ChunkPlan plan;
-    if (!g16_plan_chunk(plan, m, pvk->host.key_inputs(), n_public, n_streams, d->single_stream)) return set_err(BN254_E_BAD_ARG, "batch cannot be planned");
+    if (!g16_plan_chunk(plan, m, pvk->host.key_inputs(), n_public, n_streams, d->single_stream && !probe_now)) return set_err(BN254_E_BAD_ARG, "batch cannot be planned");
     const bool wide = plan.wide, concurrent = plan.concurrent, split_small = plan.split_small;
     const int parts = plan.parts;
     // the buffers were sized by ensure_dev (bn254_groth16_reserve or the entry point itself): this path only enqueues, after checking the plan against them
@@ -652,7 +671,9 @@ static int g16_enqueue_exact(const bn254_g16_pvk* pvk, DevState* d, const void* 
       if (plan.part[pi].count > d->msm_part_cap) return set_err(BN254_E_BAD_ARG, "workspace of a key with many public inputs is smaller than the batch: bn254_groth16_reserve first");
     if (concurrent || split_small) { int rc = ensure_aux(*d, concurrent ? parts - 1 : 2); if (rc) return rc; }
     if (concurrent) HIPCK(hipEventRecord(d->fork_ev, user));
-    const bool measure_overlap = concurrent && parts >= 2 && d->ov_state == 0;        // the first two sub-batches of the first batch that runs several
+    // the first two sub-batches of a batch that runs several, while the question is open -- and only when the two are of (nearly) equal size: a short second part
+    // beside a long first one reads as "no overlap" whatever the queues do
+    const bool measure_overlap = concurrent && parts >= 2 && d->ov_state == 0 && plan.part[1].count * 10 >= plan.part[0].count * 9;
     if (measure_overlap) for (auto& e : d->ov_ev) if (!e) HIPCK(hipEventCreate(&e));
     for (int pi = 0; pi < parts; pi++) {
       const size_t lo = plan.part[pi].first, hi = lo + plan.part[pi].count;
@@ -885,8 +906,9 @@ int bn254_groth16_stream_overlap(const bn254_g16_pvk* pvk, int device, float* ov
   if (!pvk || !overlap) return set_err(BN254_E_BAD_ARG, "bad argument");
   DevState* d = dev_state(pvk, device);
   std::lock_guard<std::mutex> lk(d->mu);
-  *overlap = d->ov_state == 2 ? d->ov_ratio : -1.f;
+  *overlap = d->ov_ratio;            // -1 until the first measurement has been read
   if (single_stream) *single_stream = d->single_stream ? 1 : 0;
+  g_diag = d->diag;                  // the explanation belongs to the (key, device); the caller's thread receives it here
   return BN254_OK;
 }
 

@@ -53,10 +53,11 @@ struct MsmShape {
 };
 // cost model of the planner: multiply-adds of one lane per loop body of k_g1_msm_rows as counted in the gfx950 code object (tools/count_mads.py `components`): a two-bit
 // step (2 doublings + 1 addition from the lane's table), a doubling, a complete mixed addition (fixed-base byte window / unit term), the lane's 15-entry table
-#define MSM_COST_STEP 4461
-#define MSM_COST_DBL 1243
-#define MSM_COST_MIXED 1815
-#define MSM_COST_TABLE 24149
+// (round 5, the sum-of-products G1 formulas of bn254_curve.h; until round 4: 4461 / 1243 / 1815 / 24149)
+#define MSM_COST_STEP 4079
+#define MSM_COST_DBL 1169
+#define MSM_COST_MIXED 1580
+#define MSM_COST_TABLE 21404
 #define MSM_COST_JADD (MSM_COST_STEP - 2 * MSM_COST_DBL)     // the addition of a step without its two doublings: a joint row's cost per term and step
 // Rows for `n_pad` items (a multiple of 64: a wavefront never straddles two rows) within `lane_budget` lanes (one wavefront per SIMD: 65536).
 //   * While twice the variable terms fit the budget the launch is latency-bound -- it lasts as long as its LONGEST row -- and every variable term is SPLIT over a

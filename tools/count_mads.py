@@ -25,6 +25,13 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(ROOT, "snark-bn254-verifier_amd", "libbn254_verify_amd.so")
 MAD = re.compile(r"^\s*v_mad_[iu]64_[iu]32\b")
 VALU = re.compile(r"^\s*v_")
+# multiply-adds of the G1 loop bodies the models recognise by size (bn254_curve.h, round 5: the sum-of-products form of RCB16 -- a complete addition 1765, a mixed
+# addition 1580, a doubling 1169; until round 4: 2000 / 1815 / 1243)
+R_ADD = (1700, 1800)       # complete projective addition
+R_MIXED = (1500, 1650)     # complete mixed addition
+R_DBL = (1100, 1250)       # complete doubling
+R_STEP = (3950, 4200)      # a two-bit step: two doublings + one addition
+def _in(c, r): return r[0] <= c <= r[1]
 
 # exponent bit patterns (snark-bn254-verifier_amd/csrc/bn254_constants.h): fp_pow_bits squares once per bit after the first and multiplies
 # on set bits; the multiplication sits in a conditional region inside the loop
@@ -129,14 +136,14 @@ def model_components(name, ins):
         # Two copies of the variable-term code, in address order: the JOINT rows (a loop over the row's terms that holds a table head + the 3 x 3 table loop, then
         # the step loop: a conditional pair of doublings + one addition per term and step) and the single-term rows (table, step loop, trailing doublings); then
         # the mixed additions of the fixed windows.
-        steps = sorted((h, c) for h, l, c in groups if 4300 <= c <= 4600)
+        steps = sorted((h, c) for h, l, c in groups if _in(c, R_STEP))
         assert len(steps) == 2, ("k_g1_msm_rows: a joint and a single step loop expected", groups)
-        joint_tab = [(h, c) for h, l, c in groups if 7500 <= c <= 8800]
+        joint_tab = [(h, c) for h, l, c in groups if 6600 <= c <= 7800]
         assert len(joint_tab) == 1 and joint_tab[0][0] < steps[0][0], ("k_g1_msm_rows: the joint rows' table loop expected first", groups)
         for h, l, c in groups:
             if (h, c) == steps[0] or (h, c) == joint_tab[0]:
                 continue
-            key = "step" if (h, c) == steps[1] else "table_add" if 1950 <= c <= 2050 else "dbl" if 1150 <= c <= 1350 else "mixed" if 1700 <= c <= 1900 else None
+            key = "step" if (h, c) == steps[1] else "table_add" if _in(c, R_ADD) else "dbl" if _in(c, R_DBL) else "mixed" if _in(c, R_MIXED) else None
             if key == "table_add" and comp.get(key) == c:
                 continue                                  # the 3 x 3 table loops (two copies, outer loops that hold nothing but the inner one)
             assert key and key not in comp, ("k_g1_msm_rows: loop layout changed", c, comp)
@@ -147,7 +154,7 @@ def model_components(name, ins):
         comp["unit"] = comp["mixed"]                      # the unit term: one mixed addition outside the loops
         comp["table_head"] = rest - comp["unit"]          # multiples of P and phi(P): 2 doublings, 2 mixed additions, beta x
         comp["joint_add"] = steps[0][1] - 2 * comp["dbl"]     # a joint row's step: one pair of doublings + this per term
-        assert abs(joint_tab[0][1] - comp["table_add"] - comp["table_head"]) <= 64 and 1900 <= comp["joint_add"] <= 2050, (joint_tab, comp)
+        assert abs(joint_tab[0][1] - comp["table_add"] - comp["table_head"]) <= 64 and _in(comp["joint_add"], R_ADD), (joint_tab, comp)
         full = comp["table_head"] + 9 * comp["table_add"] + 64 * comp["step"]
         return {"static_mads": len(mads), "components": comp, "mads_per_proof_launch": float(full), "unmodelled": [],
                 "model": "row kernel: multiply-adds per loop body (complete addition %(table_add)d x9 for the window table, two-bit step %(step)d, doubling %(dbl)d, mixed addition "
@@ -156,7 +163,7 @@ def model_components(name, ins):
                          "launch is priced from its plan" % comp}
     if name == "k_g1_sum_affine":
         # two loops hold a complete addition each: the rows of a lane, the butterfly steps over a quad of lanes (four lanes per item for small batches)
-        add = [c for h, l, c in groups if 1900 <= c <= 2050]
+        add = [c for h, l, c in groups if _in(c, R_ADD)]
         assert len(add) == 2 and abs(add[0] - add[1]) <= 2, ("k_g1_sum_affine: loop layout changed", groups)
         e = model_kernel("k_g1_sum_affine_inv", ins)      # the inversion's rounds
         base = e["mads_per_proof_launch"] - add[0] - add[1]
@@ -189,10 +196,10 @@ def model_kernel(name, ins):
         # the public-input MSM of the 2-input path: n_public x 32 byte windows, a table addition unless the byte is zero.  The software-pipelined loop (the next
         # window's table entry in flight during the addition) is laid out with several back edges over ONE copy of the addition: the union of those regions
         # executes n_public x 32 times, however the compiler nests them
-        w = [(h, l[-1]) for h, l, c in groups if 1700 <= c <= 1900]
+        w = [(h, l[-1]) for h, l, c in groups if _in(c, R_MIXED)]
         if w:
             prepare_windows = (min(a for a, _ in w), max(b for _, b in w))
-            assert 1700 <= count_in(mads, *prepare_windows) <= 1900, ("k_g16_prepare: more than one addition in the window loops", w)
+            assert _in(count_in(mads, *prepare_windows), R_MIXED), ("k_g16_prepare: more than one addition in the window loops", w)
             weight_ranges.append((prepare_windows[0], prepare_windows[1], N_PUBLIC * 32.0 * 255.0 / 256.0))
             notes.append("byte-window loop: %d inputs x 32 windows, table addition (%d mads) unless the byte is zero" % (N_PUBLIC, count_in(mads, *prepare_windows)))
     for h, latches, c in groups:
@@ -210,7 +217,7 @@ def model_kernel(name, ins):
             # comb tables (bn254_kernels.hip): 20 columns x 16 inputs per lane; the compiler lays the column loop out as a doubling region followed
             # by the input loop, so the two pieces are weighted directly: 19 doublings (none in the top column), 320 table additions unless the
             # 13-bit column digit is zero
-            if 3000 <= c <= 3150:
+            if 2650 <= c <= 3150:
                 # round 4: ONE software-pipelined loop over the 320 (column, input) pairs: a doubling in front of a column's first addition (19 of the 320
                 # trips), a table addition unless the 13-bit column digit is zero -- two forward-branched regions inside the loop
                 weight_ranges.append((h, latches[-1], 320.0))
@@ -218,33 +225,33 @@ def model_kernel(name, ins):
                 for a, text, tgt in ins:
                     if h <= a <= latches[-1] and tgt is not None and a < tgt <= latches[-1] + 64 and text.startswith("s_cbranch"):
                         m = count_in(mads, a + 1, tgt - 1)
-                        if 1150 <= m <= 1350: regs.append((a + 1, tgt - 1, 19.0 / 320.0, "19 doublings (%d mads each)" % m))
-                        elif 1700 <= m <= 1900: regs.append((a + 1, tgt - 1, 8191.0 / 8192.0, "320 table additions (%d mads each) unless the column digit is zero" % m))
+                        if _in(m, R_DBL): regs.append((a + 1, tgt - 1, 19.0 / 320.0, "19 doublings (%d mads each)" % m))
+                        elif _in(m, R_MIXED): regs.append((a + 1, tgt - 1, 8191.0 / 8192.0, "320 table additions (%d mads each) unless the column digit is zero" % m))
                 assert len(regs) == 2, ("k_g16_msm_partial_comb: a doubling and an addition region expected in the loop", regs)
                 for lo_, hi_, f_, note_ in regs:
                     weight_ranges.append((lo_, hi_, f_)); notes.append(note_)
-            elif 1700 <= c <= 1900:
+            elif _in(c, R_MIXED):
                 weight_ranges.append((h, latches[-1], 320.0 * 8191.0 / 8192.0)); notes.append("320 table additions (%d mads each) unless the column digit is zero" % c)
-            elif 1150 <= c <= 1350 and not any(r[0] <= h and latches[-1] <= r[1] or h <= r[0] and r[1] <= latches[-1] for r in weight_ranges if r[2] == 19.0):
+            elif _in(c, R_DBL) and not any(r[0] <= h and latches[-1] <= r[1] or h <= r[0] and r[1] <= latches[-1] for r in weight_ranges if r[2] == 19.0):
                 weight_ranges.append((h, latches[-1], 19.0)); notes.append("19 doublings (%d mads each)" % c)
             elif own > 0:
                 unmodelled.append("loop +0x%x..+0x%x (%d mads) of k_g16_msm_partial_comb not recognised" % (h - ins[0][0], latches[-1] - ins[0][0], c))
-        elif 1700 <= c <= 1900 and not inner:
+        elif _in(c, R_MIXED) and not inner:
             weight_ranges.append((h, latches[-1], 32.0 * 255.0 / 256.0))
             notes.append("byte-window loop: 32 windows per scalar, table addition (%d mads) unless the byte is zero" % c)
-        elif 1700 <= c <= 1900 and inner:
+        elif _in(c, R_MIXED) and inner:
             t, why = TRIPS_BY_KERNEL.get((name, "window_outer"), (1, "UNMODELLED outer window loop"))
             weight_ranges.append((h, latches[-1], float(t))); notes.append("outer window loop x%g: %s" % (t, why))
-        elif name == "k_g1_scalar_mul" and 1950 <= c <= 2050 and not inner:
+        elif name == "k_g1_scalar_mul" and _in(c, R_ADD) and not inner:
             weight_ranges.append((h, latches[-1], 9.0)); notes.append("table of the two-bit windows: 9 sums i P1 + j P2 (%d mads each)" % c)
         elif name == "k_g1_scalar_mul" and 40 <= c <= 60 and not inner:
             weight_ranges.append((h, latches[-1], 3.0)); notes.append("table rows i P1, j P2 stored (x3)")
-        elif name == "k_g1_scalar_mul" and 1150 <= c <= 1350 and not inner:
+        elif name == "k_g1_scalar_mul" and _in(c, R_DBL) and not inner:
             weight_ranges.append((h, latches[-1], 64.0)); notes.append("64 doublings of the high half (%d mads each; split launch, high lanes only)" % c)
-        elif 4300 <= c <= 4600 or (name in ("k_rlc_scale", "k_g1_scalar_mul") and 3000 <= c <= 3400):
+        elif _in(c, R_STEP) or (name in ("k_rlc_scale", "k_g1_scalar_mul") and 2700 <= c <= 3400):
             t, why = TRIPS_BY_KERNEL.get((name, "scalar_mul"), (1, "UNMODELLED scalar multiplication loop"))
             if name == "k_g1_scalar_mul":
-                split = any(1150 <= g[2] <= 1350 and not [x for x in groups if x is not g and g[0] <= x[0] and x[1][-1] <= g[1][-1]] for g in groups)
+                split = any(_in(g[2], R_DBL) and not [x for x in groups if x is not g and g[0] <= x[0] and x[1][-1] <= g[1][-1]] for g in groups)
                 w2 = c >= 4300          # two doublings + one addition per step (bn254_rlc.h::g1_mul_glv_w2): two bits of each half
                 t = (32 if split else 64) if w2 else (64 if split else 128)
                 why = "%s%d steps per lane%s" % ("two-bit windows: " if w2 else "", t, " (split launch: low / high half of the GLV halves)" if split else "")

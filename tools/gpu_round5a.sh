@@ -12,4 +12,7 @@ timeout -k 10 600 python tools/bench_plonk_piece.py --sizes 65536,131072,262144,
 cat $O/plonk_piece_sweep.txt | cut -c1-420
 timeout -k 10 300 python tools/bench_plonk_piece.py --sizes 131072,262144 --flags 2 --steps 2 > $O/plonk_piece_sweep_rlc.txt 2> $O/plonk_piece_sweep_rlc.err || fail sweep_rlc $O/plonk_piece_sweep_rlc.err
 cat $O/plonk_piece_sweep_rlc.txt | cut -c1-200
+for v in MUL_L MUL_T3 MUL_T3B MUL_T3D MUL_T3E; do timeout -k 10 120 tools/kbench/obj_$v/kb >> $O/kbench_f12_mul.txt 2>&1 || fail "kbench $v" $O/kbench_f12_mul.txt; done
+for v in MUL_L MUL_T3 MUL_T3B MUL_T3D MUL_T3E; do timeout -k 10 120 tools/kbench/obj_$v/kb >> $O/kbench_f12_mul.txt 2>&1 || fail "kbench $v" $O/kbench_f12_mul.txt; done
+cat $O/kbench_f12_mul.txt
 echo "round 5a done"

@@ -222,6 +222,189 @@ __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
   c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
   sth(ws, e_dst, 0, c0); sth(ws, e_dst, 1, c1);
 }
+#elif defined(V_MUL_T3)
+// the "third form" of the general Fp12 product.  Karatsuba over Fp6 as in the product's k_f12_mul (three Fp6 products, each nine Fp2
+// products in three sums: the same multiply-adds), but a0 and a1 stay in registers from their ONE load, v0 = a0 b0 waits in LDS (54 KB per block), v1 = a1 b1 in
+// registers, and only b0 is read a second time (for b0 + b1): 432 (a) + 432 (b) + 216 (b0 again) bytes read + 432 written = 1512 B per proof against the 2451 B the
+// counters show for k_f12_mul (which re-reads a and b for the sums and passes v1 through the workspace).
+__device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
+__device__ __forceinline__ void sth(const Ws& w, int e, int h, const Fp6& a) { st2(w, e + 2 * h, a.c0); st2(w, e + 4 + 2 * h, a.c1); st2(w, e + 8 + 2 * h, a.c2); }
+__device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
+  Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
+  Fp6 r;
+  r.c0 = fp2_dotk(kp(x.c0, y.c0), kp(x.c1, Y2), kp(x.c2, Y1));
+  r.c1 = fp2_dotk(kp(x.c0, y.c1), kp(x.c1, y.c0), kp(x.c2, Y2));
+  r.c2 = fp2_dotk(kp(x.c0, y.c2), kp(x.c1, y.c1), kp(x.c2, y.c0));
+  return r;
+}
+__device__ __forceinline__ void lput(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lget(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  __shared__ int32_t lds[54 * 256];
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 0;
+  Fp6 a0 = ldh(ws, e_a, 0), a1 = ldh(ws, e_a, 1);
+  { Fp6 v0 = fp6_mul_k(a0, ldh(ws, e_b, 0)); lput(lds, 0, v0.c0); lput(lds, 1, v0.c1); lput(lds, 2, v0.c2); }
+  BN_SCHED_FENCE();
+  Fp6 b1 = ldh(ws, e_b, 1);
+  const Fp6 v1 = fp6_mul_k(a1, b1);
+  BN_SCHED_FENCE();
+  Fp6 s;
+  {
+    const Fp6 sa = fp6_add(a0, a1);
+    const Fp6 sb = fp6_add(ldh(ws, e_b, 0), b1);      // b0: the one second read
+    s = fp6_mul_k(sa, sb);
+  }
+  BN_SCHED_FENCE();
+  Fp6 v0; v0.c0 = lget(lds, 0); v0.c1 = lget(lds, 1); v0.c2 = lget(lds, 2);
+  Fp6 c0, c1;
+  c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
+  c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
+  sth(ws, e_dst, 0, c0); sth(ws, e_dst, 1, c1);
+}
+#elif defined(V_MUL_T3D)
+// ... ordered so that v0, v1 and s are never live together: v0 -> LDS; v1; c0 = v0 + xi-shift(v1) leaves at once, t = v0 + v1 replaces v0 in LDS; then s, c1 = s - t.
+// Same 1512 B, the register peak is a0, a1, one half of b and the product in flight (what k_f12_mul's first Fp6 product already holds).
+__device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
+__device__ __forceinline__ void sth(const Ws& w, int e, int h, const Fp6& a) { st2(w, e + 2 * h, a.c0); st2(w, e + 4 + 2 * h, a.c1); st2(w, e + 8 + 2 * h, a.c2); }
+__device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
+  Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
+  Fp6 r;
+  r.c0 = fp2_dotk(kp(x.c0, y.c0), kp(x.c1, Y2), kp(x.c2, Y1));
+  r.c1 = fp2_dotk(kp(x.c0, y.c1), kp(x.c1, y.c0), kp(x.c2, Y2));
+  r.c2 = fp2_dotk(kp(x.c0, y.c2), kp(x.c1, y.c1), kp(x.c2, y.c0));
+  return r;
+}
+__device__ __forceinline__ void lput(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lget(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  __shared__ int32_t lds[54 * 256];
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 24;
+  Fp6 a0 = ldh(ws, e_a, 0), a1 = ldh(ws, e_a, 1);
+  { Fp6 v0 = fp6_mul_k(a0, ldh(ws, e_b, 0)); lput(lds, 0, v0.c0); lput(lds, 1, v0.c1); lput(lds, 2, v0.c2); }
+  BN_SCHED_FENCE();
+  Fp6 b1 = ldh(ws, e_b, 1);
+  {
+    const Fp6 v1 = fp6_mul_k(a1, b1);
+    BN_SCHED_FENCE();
+    Fp6 v0; v0.c0 = lget(lds, 0); v0.c1 = lget(lds, 1); v0.c2 = lget(lds, 2);
+    Fp6 c0;
+    c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
+    sth(ws, e_dst, 0, c0);
+    lput(lds, 0, fp2_add(v0.c0, v1.c0)); lput(lds, 1, fp2_add(v0.c1, v1.c1)); lput(lds, 2, fp2_add(v0.c2, v1.c2));
+  }
+  BN_SCHED_FENCE();
+  Fp6 s;
+  {
+    a0 = fp6_add(a0, a1);
+    b1 = fp6_add(ldh(ws, e_b, 0), b1);      // b0: the one second read
+    s = fp6_mul_k(a0, b1);
+  }
+  BN_SCHED_FENCE();
+  Fp6 c1;
+  c1.c0 = fp2_sub(s.c0, lget(lds, 0)); c1.c1 = fp2_sub(s.c1, lget(lds, 1)); c1.c2 = fp2_sub(s.c2, lget(lds, 2));
+  sth(ws, e_dst, 1, c1);
+}
+#elif defined(V_MUL_T3E)
+// ... T3D with a0 read again for the sum as well (1728 B): the register peak of every Fp6 product is its two operands, as in k_f12_mul -- no spill.
+__device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
+__device__ __forceinline__ void sth(const Ws& w, int e, int h, const Fp6& a) { st2(w, e + 2 * h, a.c0); st2(w, e + 4 + 2 * h, a.c1); st2(w, e + 8 + 2 * h, a.c2); }
+__device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
+  Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
+  Fp6 r;
+  r.c0 = fp2_dotk(kp(x.c0, y.c0), kp(x.c1, Y2), kp(x.c2, Y1));
+  r.c1 = fp2_dotk(kp(x.c0, y.c1), kp(x.c1, y.c0), kp(x.c2, Y2));
+  r.c2 = fp2_dotk(kp(x.c0, y.c2), kp(x.c1, y.c1), kp(x.c2, y.c0));
+  return r;
+}
+__device__ __forceinline__ void lput(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lget(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  __shared__ int32_t lds[54 * 256];
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 24;
+  { Fp6 v0 = fp6_mul_k(ldh(ws, e_a, 0), ldh(ws, e_b, 0)); lput(lds, 0, v0.c0); lput(lds, 1, v0.c1); lput(lds, 2, v0.c2); }
+  BN_SCHED_FENCE();
+  Fp6 a1 = ldh(ws, e_a, 1), b1 = ldh(ws, e_b, 1);
+  {
+    const Fp6 v1 = fp6_mul_k(a1, b1);
+    BN_SCHED_FENCE();
+    Fp6 v0; v0.c0 = lget(lds, 0); v0.c1 = lget(lds, 1); v0.c2 = lget(lds, 2);
+    Fp6 c0;
+    c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
+    sth(ws, e_dst, 0, c0);
+    lput(lds, 0, fp2_add(v0.c0, v1.c0)); lput(lds, 1, fp2_add(v0.c1, v1.c1)); lput(lds, 2, fp2_add(v0.c2, v1.c2));
+  }
+  BN_SCHED_FENCE();
+  Fp6 s;
+  {
+    a1 = fp6_add(ldh(ws, e_a, 0), a1);      // a0, b0: read a second time
+    b1 = fp6_add(ldh(ws, e_b, 0), b1);
+    s = fp6_mul_k(a1, b1);
+  }
+  BN_SCHED_FENCE();
+  Fp6 c1;
+  c1.c0 = fp2_sub(s.c0, lget(lds, 0)); c1.c1 = fp2_sub(s.c1, lget(lds, 1)); c1.c2 = fp2_sub(s.c2, lget(lds, 2));
+  sth(ws, e_dst, 1, c1);
+}
+#elif defined(V_MUL_T3B)
+// ... the same with v1 in LDS as well and blocks of 128 lanes (2 x 27 KB per block): nothing but operands and the product in flight lives in registers
+__device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
+__device__ __forceinline__ void sth(const Ws& w, int e, int h, const Fp6& a) { st2(w, e + 2 * h, a.c0); st2(w, e + 4 + 2 * h, a.c1); st2(w, e + 8 + 2 * h, a.c2); }
+__device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
+  Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
+  Fp6 r;
+  r.c0 = fp2_dotk(kp(x.c0, y.c0), kp(x.c1, Y2), kp(x.c2, Y1));
+  r.c1 = fp2_dotk(kp(x.c0, y.c1), kp(x.c1, y.c0), kp(x.c2, Y2));
+  r.c2 = fp2_dotk(kp(x.c0, y.c2), kp(x.c1, y.c1), kp(x.c2, y.c0));
+  return r;
+}
+__device__ __forceinline__ void lput(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lget(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+__global__ void __launch_bounds__(256, 1) k_op(int32_t* base, uint32_t n) {
+  __shared__ int32_t lds[108 * 256];
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 0;
+  Fp6 a0 = ldh(ws, e_a, 0), a1 = ldh(ws, e_a, 1);
+  Fp6 b0 = ldh(ws, e_b, 0), b1 = ldh(ws, e_b, 1);
+  { Fp6 v0 = fp6_mul_k(a0, b0); lput(lds, 0, v0.c0); lput(lds, 1, v0.c1); lput(lds, 2, v0.c2); }
+  BN_SCHED_FENCE();
+  { Fp6 v1 = fp6_mul_k(a1, b1); lput(lds, 3, v1.c0); lput(lds, 4, v1.c1); lput(lds, 5, v1.c2); }
+  BN_SCHED_FENCE();
+  Fp6 s = fp6_mul_k(fp6_add(a0, a1), fp6_add(b0, b1));
+  BN_SCHED_FENCE();
+  Fp6 v0; v0.c0 = lget(lds, 0); v0.c1 = lget(lds, 1); v0.c2 = lget(lds, 2);
+  Fp6 v1; v1.c0 = lget(lds, 3); v1.c1 = lget(lds, 4); v1.c2 = lget(lds, 5);
+  Fp6 c0, c1;
+  c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
+  c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
+  sth(ws, e_dst, 0, c0); sth(ws, e_dst, 1, c1);
+}
 #elif defined(V_MUL_STREAM)
 // the STREAMING SCHOOLBOOK form of the general Fp12 product.  a is loaded once and stays in registers (108); for every output coefficient
 // r_j = sum_t (xi if t > j) a_t b_((j - t) mod 6) the six coefficients of b are read again (from the caches: 6 x 432 B per lane) and the six Fp2 products are ONE sum
