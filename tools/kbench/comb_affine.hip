@@ -36,7 +36,10 @@ __global__ void k_fill(int32_t* tab, size_t entries) {
 }
 
 // ---- today's loop (bn254_kernels.hip::k_g16_msm_partial_comb without the digit array) ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) k_cur(const int32_t* __restrict__ tab, uint32_t n, int chunks, int32_t* __restrict__ part) {
+#ifndef LBW
+#define LBW 2
+#endif
+__global__ void __launch_bounds__(256, LBW) k_cur(const int32_t* __restrict__ tab, uint32_t n, int chunks, int32_t* __restrict__ part) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
   if (g >= n * (uint32_t)chunks) return;
   const uint32_t c = g / n, i = g - c * n;

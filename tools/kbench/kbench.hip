@@ -366,6 +366,54 @@ __global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
   c1.c0 = fp2_sub(s.c0, lget(lds, 0)); c1.c1 = fp2_sub(s.c1, lget(lds, 1)); c1.c2 = fp2_sub(s.c2, lget(lds, 2));
   sth(ws, e_dst, 1, c1);
 }
+#elif defined(V_MUL_T3F)
+// ... T3E that tolerates dst == a or dst == b (k_f12_mul's callers alias): c0 is held back in registers until a0 and b0 have been read the second time.
+__device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
+__device__ __forceinline__ void sth(const Ws& w, int e, int h, const Fp6& a) { st2(w, e + 2 * h, a.c0); st2(w, e + 4 + 2 * h, a.c1); st2(w, e + 8 + 2 * h, a.c2); }
+__device__ __forceinline__ Fp6 fp6_mul_k(const Fp6& x, const Fp6& y) {
+  Fp2 Y1 = fp2_mul_xi(y.c1), Y2 = fp2_mul_xi(y.c2);
+  Fp6 r;
+  r.c0 = fp2_dotk(kp(x.c0, y.c0), kp(x.c1, Y2), kp(x.c2, Y1));
+  r.c1 = fp2_dotk(kp(x.c0, y.c1), kp(x.c1, y.c0), kp(x.c2, Y2));
+  r.c2 = fp2_dotk(kp(x.c0, y.c2), kp(x.c1, y.c1), kp(x.c2, y.c0));
+  return r;
+}
+__device__ __forceinline__ void lput(int32_t* lds, int slot, const Fp2& a) {
+#pragma unroll
+  for (int l = 0; l < 9; l++) { lds[(slot * 18 + l) * 256 + threadIdx.x] = a.c0.v[l]; lds[(slot * 18 + 9 + l) * 256 + threadIdx.x] = a.c1.v[l]; }
+}
+__device__ __forceinline__ Fp2 lget(const int32_t* lds, int slot) { Fp2 r;
+#pragma unroll
+  for (int l = 0; l < 9; l++) { r.c0.v[l] = lds[(slot * 18 + l) * 256 + threadIdx.x]; r.c1.v[l] = lds[(slot * 18 + 9 + l) * 256 + threadIdx.x]; }
+  return r; }
+__global__ void __launch_bounds__(256, 2) k_op(int32_t* base, uint32_t n) {
+  __shared__ int32_t lds[54 * 256];
+  WS_SETUP
+  const int e_a = 0, e_b = 12, e_dst = 0;      // dst aliases a, as in exp-by-u
+  { Fp6 v0 = fp6_mul_k(ldh(ws, e_a, 0), ldh(ws, e_b, 0)); lput(lds, 0, v0.c0); lput(lds, 1, v0.c1); lput(lds, 2, v0.c2); }
+  BN_SCHED_FENCE();
+  Fp6 a1 = ldh(ws, e_a, 1), b1 = ldh(ws, e_b, 1);
+  Fp6 c0;
+  {
+    const Fp6 v1 = fp6_mul_k(a1, b1);
+    BN_SCHED_FENCE();
+    // one coefficient of v0 at a time: c0 = v0 + (xi v1.c2, v1.c0, v1.c1), t = v0 + v1 back into the same LDS slots
+    { const Fp2 x = lget(lds, 0); c0.c0 = fp2_add(x, fp2_mul_xi(v1.c2)); lput(lds, 0, fp2_add(x, v1.c0)); }
+    { const Fp2 x = lget(lds, 1); c0.c1 = fp2_add(x, v1.c0); lput(lds, 1, fp2_add(x, v1.c1)); }
+    { const Fp2 x = lget(lds, 2); c0.c2 = fp2_add(x, v1.c1); lput(lds, 2, fp2_add(x, v1.c2)); }
+  }
+  BN_SCHED_FENCE();
+  // a0, b0 a second time, straight into the sums; only then may dst (= a or b) be written
+  a1 = fp6_add(ldh(ws, e_a, 0), a1);
+  b1 = fp6_add(ldh(ws, e_b, 0), b1);
+  sth(ws, e_dst, 0, c0);
+  BN_SCHED_FENCE();
+  const Fp6 s = fp6_mul_k(a1, b1);
+  BN_SCHED_FENCE();
+  Fp6 c1;
+  c1.c0 = fp2_sub(s.c0, lget(lds, 0)); c1.c1 = fp2_sub(s.c1, lget(lds, 1)); c1.c2 = fp2_sub(s.c2, lget(lds, 2));
+  sth(ws, e_dst, 1, c1);
+}
 #elif defined(V_MUL_T3B)
 // ... the same with v1 in LDS as well and blocks of 128 lanes (2 x 27 KB per block): nothing but operands and the product in flight lives in registers
 __device__ __forceinline__ Fp6 ldh(const Ws& w, int e, int h) { Fp6 r; r.c0 = ld2(w, e + 2 * h); r.c1 = ld2(w, e + 4 + 2 * h); r.c2 = ld2(w, e + 8 + 2 * h); return r; }
