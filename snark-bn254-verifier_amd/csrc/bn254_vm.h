@@ -382,34 +382,40 @@ BN_HD bool vm_g2_ate_check(W& w, int e_t, int e_b) {
   return !fp2_is_zero(Z) & fp2_eq(X, fp2_mul(sx, Z)) & fp2_eq(Y, fp2_mul(sy, Z));
 }
 
-// ---- general Fp12 product dst <- a * b (dst may alias a or b), Karatsuba over Fp6; temporaries: 4 parking slots + 2 workspace Fp2 ----------------------
+// ---- general Fp12 product dst <- a * b (dst may alias a or b), Karatsuba over Fp6; temporaries: 3 parking slots ----------------------
 // tower halves in k-order storage: c0 = (k0, k2, k4), c1 = (k1, k3, k5)
 template <class W> BN_HD Fp6 vld_half(W& w, int e, int h) { Fp6 r; r.c0 = vld2(w, e + 2 * h); r.c1 = vld2(w, e + 4 + 2 * h); r.c2 = vld2(w, e + 8 + 2 * h); return r; }
 template <class W> BN_HD void vst_half(W& w, int e, int h, const Fp6& a) { vst2(w, e + 2 * h, a.c0); vst2(w, e + 4 + 2 * h, a.c1); vst2(w, e + 8 + 2 * h, a.c2); }
 // conj_b: multiply by conj(b) = b^(p^6) (the inverse of b on the cyclotomic subgroup): the odd half of b is negated on load
 template <class W>
 BN_HD void vm_f12_mul(W& w, int e_dst, int e_a, int e_b, bool conj_b = false) {
-  // v0 = a0 b0 and the first coefficient of v1 = a1 b1 wait in the parking slots (LDS), the rest of v1 in a workspace temporary
+  // Round 5 (tools/kbench MUL_T3F: 632 against 695 us per 2^20 products): v0 = a0 b0 waits in the parking slots (LDS); v1 = a1 b1 stays in registers just long enough to
+  // form c0 = v0 + (xi v1.c2, v1.c0, v1.c1) -- held back in registers -- and t = v0 + v1, which takes v0's place in the parking slots; a0 and b0 are then read a SECOND
+  // time straight into the operand sums a0 + a1, b0 + b1 (a1 and b1 are still in registers), and only after that is the first half of dst written, so dst may alias a or
+  // b; finally s = (a0 + a1)(b0 + b1) and c1 = s - t.  Until round 4 both halves of a and of b were read twice and two thirds of v1 went through a workspace temporary:
+  // 2451 B of HBM traffic per product (counters) against 1728 B now (1296 B is the floor: operands once, result once).
   { Fp6 v0 = fp6_mul(vld_half(w, e_a, 0), vld_half(w, e_b, 0)); w.park(0, v0.c0); w.park(1, v0.c1); w.park(2, v0.c2); }
+  BN_SCHED_FENCE();
+  Fp6 a1 = vld_half(w, e_a, 1), b1 = vld_half(w, e_b, 1);
+  if (conj_b) b1 = fp6_neg(b1);
+  Fp6 c0;
   {
-    Fp6 b1 = vld_half(w, e_b, 1); if (conj_b) b1 = fp6_neg(b1);
-    Fp6 v1 = fp6_mul(vld_half(w, e_a, 1), b1);
-    w.park(3, v1.c0); vst2(w, VE_TMPB + 2, v1.c1); vst2(w, VE_TMPB + 4, v1.c2);
+    const Fp6 v1 = fp6_mul(a1, b1);
+    BN_SCHED_FENCE();
+    { const Fp2 x = w.unpark(0); c0.c0 = fp2_add(x, fp2_mul_xi(v1.c2)); w.park(0, fp2_add(x, v1.c0)); }
+    { const Fp2 x = w.unpark(1); c0.c1 = fp2_add(x, v1.c0); w.park(1, fp2_add(x, v1.c1)); }
+    { const Fp2 x = w.unpark(2); c0.c2 = fp2_add(x, v1.c1); w.park(2, fp2_add(x, v1.c2)); }
   }
-  Fp6 s;
-  {
-    Fp6 sa = fp6_add(vld_half(w, e_a, 0), vld_half(w, e_a, 1));
-    Fp6 b1 = vld_half(w, e_b, 1); if (conj_b) b1 = fp6_neg(b1);
-    Fp6 sb = fp6_add(vld_half(w, e_b, 0), b1);
-    s = fp6_mul(sa, sb);
-  }
-  Fp6 v0, v1;
-  v0.c0 = w.unpark(0); v0.c1 = w.unpark(1); v0.c2 = w.unpark(2);
-  v1.c0 = w.unpark(3); v1.c1 = vld2(w, VE_TMPB + 2); v1.c2 = vld2(w, VE_TMPB + 4);
-  Fp6 c0, c1;
-  c0.c0 = fp2_add(v0.c0, fp2_mul_xi(v1.c2)); c0.c1 = fp2_add(v0.c1, v1.c0); c0.c2 = fp2_add(v0.c2, v1.c1);
-  c1.c0 = fp2_sub2(s.c0, v0.c0, v1.c0); c1.c1 = fp2_sub2(s.c1, v0.c1, v1.c1); c1.c2 = fp2_sub2(s.c2, v0.c2, v1.c2);
-  vst_half(w, e_dst, 0, c0); vst_half(w, e_dst, 1, c1);
+  BN_SCHED_FENCE();
+  a1 = fp6_add(vld_half(w, e_a, 0), a1);
+  b1 = fp6_add(vld_half(w, e_b, 0), b1);
+  vst_half(w, e_dst, 0, c0);
+  BN_SCHED_FENCE();
+  const Fp6 s = fp6_mul(a1, b1);
+  BN_SCHED_FENCE();
+  Fp6 c1;
+  c1.c0 = fp2_sub(s.c0, w.unpark(0)); c1.c1 = fp2_sub(s.c1, w.unpark(1)); c1.c2 = fp2_sub(s.c2, w.unpark(2));
+  vst_half(w, e_dst, 1, c1);
 }
 // ---- Granger-Scott squaring dst <- src^2 on the cyclotomic subgroup (dst may alias src) ---------------------------------------------
 template <class W>
