@@ -755,7 +755,7 @@ PL_HD void put_unit(MsmTerm& t, const G1Aff& p, bool neg, uint8_t* flag) {
 struct PlonkWork {
   int status;                 // PL_OK while the proof is still alive, else the final status
   PlonkProof pr;
-  FrM zeta, zu_coeff_dummy;   // (second member unused; keeps the struct trivially copyable)
+  FrM zeta, lin_opening;      // lin_opening: the value stage 1 computed for the opening of the linearised polynomial (what claimed[0] must equal); the self-test builds a proof that passes from it
   FrM lambda;
   // k_plonk_stage1 runs a proof on two lanes of two wavefronts: what the helper lane hands to the chain lane (the parsed proof travels in `pr`)
   int parse_status;
@@ -932,6 +932,7 @@ PL_HD int PlonkStage1::b(const FrM& acc_inv, MsmTerm* terms, uint8_t* tflags, co
   cl = F.mul(F.mul(cl, alpha), zu);
   PL_DUMP(20, a2l1); PL_DUMP(21, cl);
   cl = F.neg(F.add(F.sub(cl, a2l1), pi));
+  wk.lin_opening = cl;
   PL_DUMP(22, cl); PL_DUMP(23, pr.claimed[0]); PL_DUMP(24, pr.claimed[1]); PL_DUMP(25, pr.claimed[5]); PL_DUMP(26, pr.zs_value);
   {
     // Fr == compares stored words: a claimed value that is not reduced (>= r) can never equal the reduced left-hand side

@@ -19,7 +19,7 @@ def main():
     bench.plonk_config(pkg, args.batch, 2, 1, 0, in_flight=False)      # warms the GPU: the peak probe reads low on idle clocks
     bench.measure_valu_peak(pkg)
     r = bench.plonk_config(pkg, args.batch, args.steps, args.warmup, args.cpu_sample, in_flight=args.batch <= 8192 and not args.no_in_flight)
-    r.update({"metric": "PlonK verifies/sec at batch=%d (host buffers in, status bytes out)" % args.batch, "n_gpus": 1, "warmup": args.warmup,
+    r.update({"metric": "PlonK verifies/sec at batch=%d (proofs resident in HBM; `host_buffers` beside it)" % args.batch, "n_gpus": 1, "warmup": args.warmup,
               "higher_is_better": True, "dtype": "int64", "data": "reference fixtures + mutations", "config": {"workload": r["workload"]}})
     print(json.dumps(r))
 

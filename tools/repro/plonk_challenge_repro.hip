@@ -42,6 +42,32 @@ __global__ void __launch_bounds__(64) k_gamma(const PlonkKey* key, const uint8_t
 }
 __global__ void __launch_bounds__(64) k_digest(const uint8_t* digest, FrM* out) { out[threadIdx.x] = fr_ctx().from_be_reduce(digest + 32 * threadIdx.x, 32); }
 
+// K_PI: the public-input sum of PlonkStage1::b (verify.rs:109-137) -- per input three products and FrCtx::from_be32 of 32 bytes that sit in LDS (as in k_plonk_stage1,
+// which stages every proof's inputs there) or in global memory: the site at which the round-5 rebuild of the bad flags goes wrong inside the full kernel
+template <bool FROM_LDS>
+__global__ void __launch_bounds__(64) k_pi(const uint8_t* inputs, int n_pub, FrM zs, FrM iv, FrM gen, FrM* out) {
+  extern __shared__ uint8_t dyn[];
+  uint8_t* mine = dyn + 16 + 64 * LANE_STRIDE + threadIdx.x * (32 * 8 + 4);
+  if (FROM_LDS) for (int k = 0; k < 32 * n_pub; k++) mine[k] = inputs[k];
+  __syncthreads();
+  const uint8_t* in = FROM_LDS ? mine : inputs;
+  const FrCtx& F = fr_ctx();
+  FrM pi = {{0, 0, 0, 0}}, accw = F.one;
+  for (int i = 0; i < n_pub; i++) {
+    FrM x = F.mul(F.mul(F.mul(zs, iv), accw), F.from_be32(in + 32 * i));
+    accw = F.mul(accw, gen);
+    pi = F.add(pi, x);
+    iv = F.mul(iv, iv);
+  }
+  out[threadIdx.x] = pi;
+}
+static FrM host_pi(const uint8_t* in, int n_pub, FrM zs, FrM iv, FrM gen) {
+  const FrCtx& F = fr_ctx();
+  FrM pi = {{0, 0, 0, 0}}, accw = F.one;
+  for (int i = 0; i < n_pub; i++) { FrM x = F.mul(F.mul(F.mul(zs, iv), accw), F.from_be32(in + 32 * i)); accw = F.mul(accw, gen); pi = F.add(pi, x); iv = F.mul(iv, iv); }
+  return pi;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 static void hexs(char* o, const FrM& v) { uint8_t b[32]; fr_ctx().to_be(b, v); for (int i = 0; i < 32; i++) sprintf(o + 2 * i, "%02x", b[i]); }
 int main(int argc, char** argv) {
@@ -93,6 +119,7 @@ int main(int argc, char** argv) {
     int bad = 0, first = -1, dbad = 0; for (int i = 0; i < 64; i++) { if (!F.eq(o[i], hs.gamma)) { bad++; if (first < 0) first = i; } dbad += memcmp(&dg[32 * i], hdg, 32) != 0; }
     report("K_GAMMA", bad, o[first < 0 ? 0 : first], hs.gamma);
     printf("K_GAMMA   digest differs in %d lanes\n", dbad); bad_total += dbad;
+    printf("K_GAMMA   digest = "); for (int i = 0; i < 32; i++) printf("%02x", hdg[i]); printf("\n");
   }
   {
     for (int i = 0; i < 64; i++) memcpy(&dg[32 * i], hdg, 32);
@@ -101,6 +128,21 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize()); CK(hipMemcpy(o.data(), dout, 64 * sizeof(FrM), hipMemcpyDeviceToHost));
     int bad = 0, first = -1; for (int i = 0; i < 64; i++) if (!F.eq(o[i], hs.gamma)) { bad++; if (first < 0) first = i; }
     report("K_DIGEST", bad, o[first < 0 ? 0 : first], hs.gamma);
+  }
+  {
+    const int np = 8;
+    std::vector<uint8_t> pin(32 * np); for (auto& b : pin) b = (uint8_t)next();
+    uint8_t* dpin; CK(hipMalloc(&dpin, pin.size())); CK(hipMemcpy(dpin, pin.data(), pin.size(), hipMemcpyHostToDevice));
+    const FrM zs = hs.zeta_n, iv = hs.zh_zeta, gen = key.generator;
+    const FrM want = host_pi(pin.data(), np, zs, iv, gen);
+    const size_t lds2 = lds + 64 * (32 * 8 + 4);
+    for (int from_lds = 1; from_lds >= 0; from_lds--) {
+      if (from_lds) hipLaunchKernelGGL(k_pi<true>, dim3(1), dim3(64), lds2, 0, dpin, np, zs, iv, gen, dout);
+      else hipLaunchKernelGGL(k_pi<false>, dim3(1), dim3(64), lds2, 0, dpin, np, zs, iv, gen, dout);
+      CK(hipDeviceSynchronize()); CK(hipMemcpy(o.data(), dout, 64 * sizeof(FrM), hipMemcpyDeviceToHost));
+      int bad = 0, first = -1; for (int i = 0; i < 64; i++) if (!F.eq(o[i], want)) { bad++; if (first < 0) first = i; }
+      report(from_lds ? "K_PI lds" : "K_PI glob", bad, o[first < 0 ? 0 : first], want);
+    }
   }
   printf("%s\n", bad_total ? "MISMATCH" : "all kernels agree with the host");
   return bad_total ? 1 : 0;
