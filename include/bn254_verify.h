@@ -182,9 +182,9 @@ int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* pr
  *          d_status (a PlonK batch is several passes on several contexts driven by host threads, and BN254_FLAG_RLC has to read a counter back between two stages).
  * _multi   several GPUs of the node: the contiguous shards of bn254_shard_plan, one host thread per device through the host-buffer entry.
  * reserve  allocates NOW what a batch of up to n proofs needs on `device` (contexts of the plan, their buffers; proof_stride > 0: also the pinned staging of the host-buffer
- *          entry for records of that stride), so that the batch itself neither allocates nor frees.  Footprint per context (SP1 key shape, 6.6 KB per proof of capacity plus
- *          1.8 KB per proof and variable MSM term): 0.45 GB for passes of 8192 proofs, 2.7 GB for 131 072, 5.4 GB for 262 144; a batch above 65 536 proofs uses up to
- *          eight contexts of its pass size.  bn254_plonk_footprint reports what a key holds on a device right now. */
+ *          entry for records of that stride), so that the batch itself neither allocates nor frees.  Footprint per context, measured for the SP1 key shape (about 10 KB per proof of capacity plus
+ *          1.8 KB per proof and variable MSM term): 0.16 GB for passes of up to 5040 proofs, 1.7 GB for 65 536, 3.5 GB for 131 072, 6.9 GB for 262 144; a batch above
+ *          65 536 proofs uses up to eight contexts of its pass size (two for 262 144 proofs).  bn254_plonk_footprint reports what a key holds on a device right now. */
 int bn254_plonk_verify_batch_device(const bn254_plonk_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_public_inputs, size_t n_public, size_t n,
                                     void* d_status, int device, void* hip_stream, unsigned flags);
 int bn254_plonk_verify_batch_multi(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n,

@@ -173,14 +173,16 @@ def model_components(name, ins):
     if name == "k_miller_run_fixed2":
         assert len(groups) == 1, ("k_miller_run_fixed2: one step loop expected", groups)
         h, l, c = groups[0]
-        # the compiler peels the steps without a squaring (the first step and the 23 additions) into a second copy of the two line products behind the loop:
-        # the loop body is squaring + two lines, the code behind it two lines
-        lines = len(mads) - c
-        sq = [(0, 0, c - lines)]
-        assert 3500 <= sq[0][2] <= 4500 and 7000 <= lines <= 8000, ("k_miller_run_fixed2: layout changed", c, lines)
-        total = 64 * sq[0][2] + 88 * lines
-        return {"static_mads": len(mads), "components": {"sqr": sq[0][2], "two_lines": lines}, "mads_per_proof_launch": float(total), "mads_per_proof_batch": float(total), "per_pass": True,
-                "unmodelled": [], "model": "Miller loop of two table-driven pairs in one launch: squaring of f (%d multiply-adds) x64 + two line products (%d) x88" % (sq[0][2], lines)}
+        # ONE copy of each piece: the two line products of a step form the loop body (address range head .. latch), the squaring of f sits outside that range and
+        # is entered from the latch when the next step is a doubling step (64 of the 88 steps).  Until round 4 this model read the layout the other way round
+        # ("loop body = squaring + two lines, the code behind = a peeled copy of the two lines") and priced the kernel at 908 632 multiply-adds per proof; the two
+        # pieces are the straight-line kernels k_f12_sqr (7425) and k_f12_mul_line_fixed2 (11 413), whose static counts need no model, and a pass executes
+        # 64 x 7425 + 88 x 11 413 = 1 479 544 of them (profiles/r05_plonk262144_onepass_kernel_stats.csv: 15.2 ms per 262 144 proofs = 0.77 of the peak, as k_miller_run).
+        lines, sqr = c, len(mads) - c
+        assert 7000 <= sqr <= 8000 and 10500 <= lines <= 12500, ("k_miller_run_fixed2: layout changed", c, sqr, lines)
+        total = 64 * sqr + 88 * lines
+        return {"static_mads": len(mads), "components": {"sqr": sqr, "two_lines": lines}, "mads_per_proof_launch": float(total), "mads_per_proof_batch": float(total), "per_pass": True,
+                "unmodelled": [], "model": "Miller loop of two table-driven pairs in one launch: squaring of f (%d multiply-adds) x64 + two line products (%d) x88" % (sqr, lines)}
     return None
 
 
