@@ -3,9 +3,12 @@
 # one GPU, rocprofv3 kernel traces (Groth16 headline, PlonK 4096 / 65536) and PMC passes (SQ activity, HBM traffic) for both paths.
 # Outputs under gpurun_out/r05/; tools/summarize_r05.py turns them into profiles/r05_*
 set -o pipefail
+# Two calls (a call is limited to 20 minutes): `PART=a bash tools/gpu_round5.sh` (tests, smoke, bench lines, kernel traces), `PART=b bash tools/gpu_round5.sh` (the counter passes).
 R=$PWD; O=$R/gpurun_out/r05
-rm -rf $O; mkdir -p $O
+mkdir -p $O
+PART=${PART:-a}
 fail() { echo "FAILED: $1"; tail -20 $2; exit 1; }
+if [ "$PART" = a ]; then
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1 || fail pytest $O/pytest_gpu.log
 tail -2 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || fail smoke $O/smoke.log
@@ -25,6 +28,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk -o run -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk64k -o run -- python3 $R/tools/bench_plonk.py --batch 65536 --steps 3 --warmup 1 --cpu-sample 0 > $O/prof_plonk64k.json 2> $O/prof_plonk64k.err || fail "rocprof plonk 64k" $O/prof_plonk64k.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_plonk256k -o run -- python3 $R/tools/bench_plonk.py --batch 262144 --steps 2 --warmup 1 --cpu-sample 0 --no-in-flight > $O/prof_plonk256k.json 2> $O/prof_plonk256k.err || fail "rocprof plonk 256k" $O/prof_plonk256k.err
 echo "kernel traces done"
+cd $R
+find $O -name "*kernel_trace.csv" -size +30M -delete
+fi
+if [ "$PART" = b ]; then
+cd /tmp && export TMPDIR=/tmp
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_INT64" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $c | cut -d' ' -f1)
   BN254_STREAMS=1 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-rlc --no-configs --batch-log2 18 > $O/pmc_$tag.json 2> $O/pmc_$tag.err || fail "pmc $tag" $O/pmc_$tag.err
@@ -32,5 +40,5 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
   echo "pmc $tag done"
 done
 cd $R
-find $O -name "*kernel_trace.csv" -size +30M -delete
-echo "round 5 GPU script done"
+fi
+echo "round 5 GPU script part $PART done"
