@@ -92,7 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-log2", type=int, default=20, help="the (global) batch = 2^this proofs (default: BASELINE 2^20), sharded over the GPUs")
+    ap.add_argument("--batch-log2", type=int, default=None, help="the (global) batch = 2^this proofs (default: BASELINE 2^20; 2^18 with --plonk), sharded over the GPUs")
+    ap.add_argument("--plonk", action="store_true", help="the PlonK path instead (BASELINE configs[3] at scale): one call of 2^batch-log2 proofs sharded over the GPUs like the "
+                    "Groth16 batch (contiguous ranges, resident buffers, all_gather of the status bytes); prints its own line, not the headline metric")
     ap.add_argument("--weak", action="store_true", help="weak scaling: 2^batch-log2 proofs PER GPU (the global batch grows with --gpus)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations, N = 1 only)")
     ap.add_argument("--n-public", type=int, default=2)
@@ -103,7 +105,10 @@ def parse_args(argv=None):
     ap.add_argument("--host-buffers", action="store_true", help="also time the host-buffer entry (PCIe-inclusive), reported beside `value`")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="REHEARSAL of --gpus N on ONE GPU: N rank processes, all on cuda:0, gloo for the status gather and the "
                     "reductions (RCCL refuses two ranks on one device); the line says so and its value is not a scaling number")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.batch_log2 is None:
+        a.batch_log2 = 18 if a.plonk else 20
+    return a
 
 
 def free_port():
@@ -802,6 +807,96 @@ def single_proof_config(pkg):
     return out
 
 
+def run_rank_plonk(args, pkg, backend, rank, world, local_rank, rehearse):
+    """--plonk: ONE PlonK call of 2^batch_log2 proofs (plonk_workload: the reference's fixtures + mutations, every 8th proof invalid) sharded over the ranks by
+    sharding.shard_bounds, each rank's shard resident in its GPU's HBM and verified by bn254_plonk_verify_batch_device; the status bytes are gathered like the Groth16
+    ones.  Same timing contract as run_rank (barrier + synchronize on both sides, max over ranks, value = proofs of all ranks / time)."""
+    import torch
+    import torch.distributed as dist
+    sharding = importlib.import_module("snark-bn254-verifier_amd.sharding")
+    n_total = (1 << args.batch_log2) * (world if args.weak else 1)
+    lo, hi = sharding.shard_bounds(n_total, world, rank)
+    n = hi - lo
+    t0 = time.time()
+    vk, pb, ib, proofs, inputs = plonk_workload(n_total)
+    gen_s = time.time() - t0
+    dev = torch.device("cuda", local_rank)
+    pvk = pkg.PreparedPlonkVk(vk)
+    pvk.reserve(n, device=local_rank)
+    d_p = torch.frombuffer(bytearray(pb[lo * 904:hi * 904]), dtype=torch.uint8).to(dev)
+    d_q = torch.frombuffer(bytearray(ib[lo * 64:hi * 64]), dtype=torch.uint8).to(dev)
+    d_st = torch.full((max(n, 1),), 0xEE, dtype=torch.uint8, device=dev)[:n]
+    stream = torch.cuda.current_stream(dev)
+    grouped = dist.is_available() and dist.is_initialized()
+
+    def step():
+        if n:
+            pvk.verify_batch_device(d_p.data_ptr(), d_q.data_ptr(), d_st.data_ptr(), n, proof_stride=904, device=local_rank, stream=stream.cuda_stream,
+                                    flags=pkg.FLAG_RLC if args.rlc else 0)
+        if rehearse:
+            return sharding.gather_status(d_st.cpu(), n_total, world)
+        return sharding.gather_status(d_st, n_total, world)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if grouped:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t_start = time.perf_counter()
+    full = None
+    for _ in range(args.steps):
+        full = step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if rank == 0:
+        measure_valu_peak(pkg, local_rank)
+    if grouped:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if backend == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # correctness of the timed work: the shard's bytes (ACCEPT exactly where the workload left the inputs alone; the first 16 against the oracle), and the gathered vector
+    st = bytes(d_st.cpu().numpy().tobytes())
+    assert all((st[i - lo] == pkg.ACCEPT) == (i % 8 != 7) for i in range(lo, hi)), "rank %d: PlonK statuses differ from the workload's" % rank
+    from oracle import oracle as O
+    m = min(16, n)
+    assert st[:m] == bytes(O.plonk_verify(proofs[lo + i], vk, [int.from_bytes(inputs[lo + i][:32], "big"), int.from_bytes(inputs[lo + i][32:], "big")]) for i in range(m)), \
+        "rank %d: PlonK statuses differ from the oracle" % rank
+    assert full.numel() == n_total and bytes(full[lo:hi].cpu().numpy().tobytes()) == st, "gathered statuses are wrong"
+    if rank != 0:
+        return None
+    value = n_total * args.steps / elapsed
+    stage_ms, _lanes = pvk.last_timing(local_rank)
+    km = (_load_json("kernel_mads.json") or {}).get("kernels", {})
+    acct = _plonk_accounting(pkg, km, n, stage_ms)
+    whole = acct["whole"]
+    if whole:
+        ach = whole["mads_per_proof"] * value / world
+        whole.update({"achieved": ach / 1e12, **_peak_fields(), "unit": "T mad/s", **_fracs(ach)})
+    out = {"metric": "PlonK verifies/sec (2 pub-inputs) at batch=2^%d%s%s" % (args.batch_log2, " per GPU" if args.weak else "", ", RLC batch mode" if args.rlc else ""),
+           "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+           "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3] at scale: %s of 2^%d PlonK proofs%s (904 bytes; the reference's fixtures + mutations, 1/8 invalid), 2 public inputs, "
+                                  "resident in HBM" % ("batches" if args.weak else "ONE batch", args.batch_log2,
+                                                       " per GPU" if args.weak else (" sharded over %d GPUs (contiguous ranges)" % world if world > 1 else "")),
+                      "batch_per_gpu": n, "global_batch": n_total, "n_public": 2, "mode": "rlc (one pairing check per 64 proofs, exact fallback)" if args.rlc else "exact",
+                      "parallelism": "independent contiguous proof shards x%d + all_gather of status bytes" % world, "gen_seconds": round(gen_s, 1),
+                      "context_footprint": dict(zip(("bytes", "contexts"), pvk.footprint(local_rank)))},
+           "stages_ms": stage_ms, "roofline": acct["roofline"], "pairing_check": acct["pairing"], "valu_whole_path": whole,
+           "status_check": "every status byte of every shard == the workload's (ACCEPT unless the inputs were mutated); first 16 of each shard == oracle; gathered vector checked"}
+    if world == 1 and not args.no_cpu_baseline:
+        m = min(512, n)
+        t = time.perf_counter()
+        ref = bytes(O.plonk_verify(proofs[i], vk, [int.from_bytes(inputs[i][:32], "big"), int.from_bytes(inputs[i][32:], "big")]) for i in range(m))
+        cdt = time.perf_counter() - t
+        assert ref == st[:m]
+        out["cpu_baseline"] = {"value": m / cdt, "unit": "proofs/s", "cores": 1, "kind": "port", "sample": "first %d proofs of the batch, %.1f s; the oracle's PlonK verifier (C restatement)" % (m, cdt)}
+    return out
+
+
 def other_configs(args, pkg, local_rank, resident_value, keep):
     """The `configs` block of the bench line."""
     cfg = {}
@@ -857,6 +952,16 @@ def main(argv=None):
         keep["expected0"] = r[3]
         return r
 
+    if args.plonk:
+        out = run_rank_plonk(args, pkg, "gloo" if rehearse else "nccl", rank, world, local_rank, rehearse)
+        if rank == 0:
+            if rehearse:
+                out["rehearsal"] = "REHEARSAL: %d rank processes on ONE GPU (cuda:0), gloo for the status gather -- not a scaling number" % world
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     lines = []
     out = run_rank(args, make, "gloo" if rehearse else "nccl", rank, world, local_rank, synth, emit=lines.append)
     if rank == 0:

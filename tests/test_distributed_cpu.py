@@ -201,3 +201,22 @@ def test_bench_self_launches_its_ranks():
         pytest.skip("GPU present: covered by the GPU run")
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+
+
+def test_bench_plonk_mode_arguments_and_shards():
+    """`bench.py --plonk` (the PlonK call sharded like the Groth16 batch): 2^18 proofs unless told otherwise, the headline stays 2^20; the ranks' contiguous ranges of
+    the PlonK workload tile it exactly (what run_rank_plonk uploads per rank), for ragged counts too."""
+    import bench
+    assert bench.parse_args([]).batch_log2 == 20 and not bench.parse_args([]).plonk
+    a = bench.parse_args(["--plonk", "--gpus", "8"])
+    assert a.plonk and a.batch_log2 == 18 and a.gpus == 8
+    assert bench.parse_args(["--plonk", "--batch-log2", "12"]).batch_log2 == 12
+    sharding = importlib.import_module("snark-bn254-verifier_amd.sharding")
+    vk, pb, ib, proofs, inputs = bench.plonk_workload(37)
+    for world in (1, 2, 3, 8):
+        got_p, got_i = b"", b""
+        for r in range(world):
+            lo, hi = sharding.shard_bounds(37, world, r)
+            got_p += pb[lo * 904:hi * 904]; got_i += ib[lo * 64:hi * 64]
+        assert got_p == pb and got_i == ib
+    assert all(len(p) == 904 for p in proofs) and sum(inputs[i] != inputs[i % 4] for i in range(37)) == 37 // 8

@@ -97,6 +97,66 @@ def _compare_mutated_keys(pkg, O, count, seed):
     return seen, statuses
 
 
+
+def _plonk_key_mutations(vk, rng, count):
+    """(label, key bytes) for the PlonK key (plonk/converter.rs:24-119): truncations, bit flips in the eight compressed points, in the scalars in front of them, in the
+    Qcp count / KZG points behind them and in the trailing index list, flag bits, coordinates >= p"""
+    out = []
+    n = len(vk)
+    for k in range(count):
+        b = bytearray(vk)
+        kind = k % 8
+        if kind == 0:
+            b = b[:rng.randrange(0, n)]
+        elif kind == 1:
+            b[rng.randrange(112, 372)] ^= 1 << rng.randrange(8)
+        elif kind == 2:
+            j = rng.randrange(8); b[112 + 32 * j:144 + 32 * j] = b"\xff" * 32
+        elif kind == 3:
+            j = rng.randrange(8); b[112 + 32 * j] = (b[112 + 32 * j] & 0x3F) | (rng.randrange(4) << 6)
+        elif kind == 4:
+            b[rng.randrange(368, 372 + 64 + 160)] ^= 1 << rng.randrange(8)
+        elif kind == 5:
+            b[rng.randrange(0, 112)] ^= 1 << rng.randrange(8)
+        elif kind == 6:
+            b[rng.randrange(n - 64, n)] ^= 1 << rng.randrange(8)
+        else:
+            b[rng.randrange(372, 372 + 64 + 160)] = rng.randrange(256)
+        out.append(("p%d/%d" % (k, kind), bytes(b)))
+    return out
+
+
+def _compare_mutated_plonk_keys(pkg, O, fixtures, count, seed):
+    """Every (mutated key, fixture proof): the product's status byte == the oracle's.  Keys that do not load answer on the host; keys that load need the GPU (-m gpu)."""
+    gpu = _have_gpu()
+    fx, vk = fixtures
+    base = [(bytes.fromhex(f["raw_proof"]), [int(x) for x in f["public_inputs"]]) for f in fx.values() if f["variant"] == "plonk"]
+    off_curve = bytearray(base[0][0]); off_curve[63] ^= 1
+    proofs = [base[0], base[1], (bytes(off_curve), base[0][1])]
+    rng = random.Random(seed)
+    seen = {"host": 0, "device": 0}
+    statuses = set()
+    L = pkg.lib()
+    for label, key in _plonk_key_mutations(vk, rng, count):
+        h = C.c_void_p()
+        loads = L.bn254_plonk_vk_prepare(key, len(key), C.byref(h)) == 0
+        if loads:
+            L.bn254_plonk_vk_free(h)
+        for pi, (pr, xs) in enumerate(proofs):
+            want = O.plonk_verify(pr, key, xs)
+            st = C.c_uint8(0xEE)
+            ib = b"".join(be(x) for x in xs)
+            rc = L.bn254_plonk_verify(pr, len(pr), key, len(key), ib, len(xs), C.byref(st))
+            if loads and not gpu:
+                assert rc in (E_NO_DEVICE, E_HIP), (label, pi, rc, st.value)        # the key prepared: the call needs the GPU, and says so
+                seen["device"] += 1
+                continue
+            assert rc == 0 and st.value == want, (label, pi, rc, st.value, want)
+            seen["device" if loads else "host"] += 1
+            statuses.add(st.value)
+    return seen, statuses
+
+
 def test_mutated_keys_single_proof_host_side(pkg, O):
     """200 mutated keys x {valid, off-curve, >= p} proofs through bn254_groth16_verify and the oracle.  Keys that no longer load are answered on the host: the
     proof's loader error (3, 2) if it has one -- lib.rs:45 runs before :46 -- else MALFORMED.  Keys that still load need the GPU (checked by the -m gpu twin)."""
@@ -140,6 +200,14 @@ def test_unparsable_plonk_key_keeps_the_proof_loaders_order(pkg, O, fixtures):
         assert st.value == O.plonk_verify(c, bad_key, xs), len(got)
         got.append(st.value)
     assert got == [6, 6, 2, 3, 3, 6]
+
+
+def test_mutated_plonk_keys_host_side(pkg, O, fixtures):
+    """400 mutated PlonK keys x {two valid proofs, one with a point off the curve}: a key that does not load answers on the host with the oracle's byte -- lib.rs:70
+    before :71: the proof loader's error if it has one, else the key's."""
+    seen, statuses = _compare_mutated_plonk_keys(pkg, O, fixtures, 400, 0x91A)
+    assert seen["host"] >= 300
+    assert {3, 6} <= statuses
 
 
 def test_key_without_k_points_prepares(pkg):
@@ -328,3 +396,12 @@ def test_key_elements_outside_the_r_torsion(pkg, O):
                 assert got == O.groth16_verify_many(proofs, 256, bytes(key), inputs, 2, 20, omode), (off, mode)
                 seen |= set(got)
     assert seen == {pkg.REJECT, pkg.ERR_NOT_ON_CURVE, pkg.ERR_NOT_IN_SUBGROUP, pkg.ERR_NOT_MEMBER}     # no proof verifies against a key with a foreign element; loader errors first
+
+
+@pytest.mark.gpu
+def test_mutated_plonk_keys_on_device(pkg, O, fixtures):
+    """The same comparison on the GPU: the keys that still load (flipped bits in the selector commitments, the scalars, the KZG points, the index list) run the whole
+    pipeline -- key tables built from the mutated points -- and must give the oracle's byte (OpeningPolyMismatch, PairingCheckFailed, InvalidWitness, ACCEPT ...)."""
+    seen, statuses = _compare_mutated_plonk_keys(pkg, O, fixtures, 160, 0x91B)
+    assert seen["device"] >= 100
+    assert {1, 7, 8} <= statuses, statuses
