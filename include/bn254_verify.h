@@ -284,6 +284,8 @@ int bn254_synth_groth16_range(uint64_t seed, size_t n_public, size_t first, size
  * c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1; G1: x | y; G2: x.c1 | x.c0 | y.c1 | y.c0 (gnark order). */
 /* measurement probe: lane-level v_mad_u64_u32 per second of `device` (four wavefronts per SIMD, launches of about 2 ms, 16 independent chains per lane): the VALU peak of THIS box */
 int bn254_dbg_valu_peak(int device, double* mads_per_s);
+/* the same kernel back to back for about ms_target (<= 2000) milliseconds, timed as one interval: the rate the box SUSTAINS over the length of the path's long kernels */
+int bn254_dbg_valu_peak_sustained(int device, double ms_target, double* mads_per_s);
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);                 /* n x 32 B each */
 int bn254_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device);        /* 0 mul 1 sqr 2 inv 3 cyclo_sqr(after easy part) 4 frob1 */
 int bn254_dbg_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out_gt, size_t n, int device);          /* e(P_i, Q_i), n x 384 B */

@@ -1854,6 +1854,13 @@ int bn254_dbg_valu_peak(int device, double* mads_per_s) {
   *mads_per_s = bn254_measure_valu_peak(12);
   return *mads_per_s > 0 ? BN254_OK : set_err(BN254_E_HIP, "peak measurement failed");
 }
+int bn254_dbg_valu_peak_sustained(int device, double ms_target, double* mads_per_s) {
+  if (!mads_per_s || !(ms_target > 0.0) || ms_target > 2000.0) return set_err(BN254_E_BAD_ARG, "bad argument");
+  int rc = check_device(device);
+  if (rc) return rc;
+  *mads_per_s = bn254_measure_valu_sustained(ms_target);
+  return *mads_per_s > 0 ? BN254_OK : set_err(BN254_E_HIP, "peak measurement failed");
+}
 int bn254_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int device) {
   return run_probe(32, 32, 32, a, b, out, n, device, [](const uint8_t* x, const uint8_t* y, uint8_t* o, size_t m) { return bn254_launch_dbg_fp_mul(x, y, o, m, nullptr); });
 }

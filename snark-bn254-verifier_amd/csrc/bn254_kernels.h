@@ -137,6 +137,7 @@ hipError_t bn254_coop12_miller_fixed(int32_t* ws, uint8_t* status, size_t n, int
                                      int e_p0, int e_p1, int e_p2, int inf0, int inf1, int inf2, int fuse_final_exp, const int32_t* target, int reject_code, hipStream_t s);
 static inline size_t bn254_coop_max_proofs() { return COOP12_MAX_PROOFS; }
 static inline size_t bn254_coop_max_proofs_fixed() { return COOP12_MAX_PROOFS_FIXED; }
+double bn254_measure_valu_sustained(double ms_target);   // the same kernel back to back for ms_target milliseconds, one interval
 double bn254_measure_valu_peak(int reps);   // lane-level v_mad_u64_u32 per second of the current device at four wavefronts per SIMD
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s);
 hipError_t bn254_launch_dbg_fp12_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, int32_t* ws, uint8_t* status, hipStream_t s);

@@ -932,6 +932,28 @@ double bn254_measure_valu_peak(int reps) {
   if (best > 1e29f) return 0.0;
   return (double)grid * 256.0 * (double)VALU_PEAK_ITERS * 16.0 / ((double)best * 1e-3);
 }
+// The same kernel back to back for about `ms_target` milliseconds, timed as ONE interval: the rate the box sustains over the length of the path's long kernels
+// (k_miller_run runs for 50 .. 100 ms) -- boxes whose best 2 ms launch agrees to 1 % differ by 3 % here (profiles/r05_box_variance.txt).
+double bn254_measure_valu_sustained(double ms_target) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0.0;
+  const int grid = p.multiProcessorCount * 4;
+  uint32_t* out = nullptr;
+  if (hipMalloc((void**)&out, (size_t)grid * 256 * 4) != hipSuccess) return 0.0;
+  int launches = (int)(ms_target / 2.0);
+  if (launches < 4) launches = 4;
+  if (launches > 1000) launches = 1000;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, nullptr);
+  for (int r = 0; r < launches; r++) hipLaunchKernelGGL(k_valu_peak, dim3(grid), dim3(256), 0, nullptr, out, (uint32_t)(r + 1), VALU_PEAK_ITERS);
+  (void)hipEventRecord(e1, nullptr);
+  float ms = 0.f;
+  const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+  return ok ? (double)launches * grid * 256.0 * (double)VALU_PEAK_ITERS * 16.0 / ((double)ms * 1e-3) : 0.0;
+}
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_dbg_fp_mul, dim3(grid_for(n)), dim3(256), 0, s, a, b, o, n);
   return hipGetLastError();

@@ -109,6 +109,7 @@ hipError_t bn254_launch_pairing2_fixed(int32_t*, uint8_t* status, size_t n, cons
   return hipSuccess;
 }
 double bn254_measure_valu_peak(int) { return 1.0; }
+double bn254_measure_valu_sustained(double) { return 1.0; }
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t*, const uint8_t*, uint8_t*, size_t, hipStream_t) { return hipSuccess; }
 hipError_t bn254_launch_dbg_fp12_op(int, const uint8_t*, const uint8_t*, uint8_t*, size_t, int32_t*, uint8_t*, hipStream_t) { return hipSuccess; }
 hipError_t bn254_launch_dbg_pairing(const uint8_t*, const uint8_t*, uint8_t*, size_t, int32_t*, uint8_t*, hipStream_t) { return hipSuccess; }

@@ -27,6 +27,28 @@ def test_exports_match_header(pkg):
     assert L.bn254_version().startswith(b"bn254-verify-amd")
 
 
+def test_header_is_plain_c_and_links(pkg, tmp_path):
+    """The boundary is a C ABI: include/bn254_verify.h compiles as C99 (-pedantic, no C++), a C program links against the library, and the library built here answers
+    the header's BN254_ABI_VERSION (what binding.py and the Rust crate check before they call anything else)."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "bn254_verify.h"\n#include <stdio.h>\nint main(void) { int dev[64], ns = 0; size_t first[64], count[64];\n'
+                   '  if (bn254_shard_plan(10, 0x7, 8, dev, first, count, &ns) != 0 || ns != 3) return 2;\n'
+                   '  printf("%d %s %d %d\\n", bn254_abi_version(), bn254_version(), (int)first[1], (int)(first[1] + count[1]));\n'
+                   '  return bn254_abi_version() == BN254_ABI_VERSION ? 0 : 1; }\n')
+    libdir = os.path.join(ROOT, "snark-bn254-verifier_amd")
+    exe = tmp_path / "use_header"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lbn254_verify_amd",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ver, name, lo, hi = r.stdout.split()[0], r.stdout.split()[1], r.stdout.split()[-2], r.stdout.split()[-1]
+    hdr = open(os.path.join(ROOT, "include", "bn254_verify.h")).read()
+    assert int(ver) == int(re.search(r"#define BN254_ABI_VERSION (\d+)", hdr).group(1)) and name.startswith("bn254-verify-amd")
+    sharding = __import__("importlib").import_module("snark-bn254-verifier_amd.sharding")
+    assert (int(lo), int(hi)) == sharding.shard_bounds(10, 3, 1)
+
+
 def test_status_codes_shared_with_oracle(pkg, O):
     hdr = open(os.path.join(ROOT, "include", "bn254_verify.h")).read()
     ohdr = open(os.path.join(ROOT, "oracle", "oracle.h")).read()

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""profiles/r05_box_variance.txt from the calls of tools/gpu_box_probe.sh (gpurun_out/r05v/box*.json, *_one_stream.json, *.copy_rate) and the plain 10-step lines of the
+round (box1..4: two-stream line only).  Every gpurun call gets a fresh box; the table is sorted by the two-stream step time."""
+import glob, json, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "r05v")
+
+
+def last(p):
+    d = None
+    if os.path.exists(p):
+        for l in open(p):
+            if l.startswith("{"):
+                d = json.loads(l)
+    return d
+
+
+rows = []
+for p in sorted(glob.glob(os.path.join(src, "box*.json"))):
+    if p.endswith("_one_stream.json"):
+        continue
+    d = last(p)
+    if not d:
+        continue
+    tag = os.path.basename(p)[:-5]
+    s = last(p[:-5] + "_one_stream.json")
+    c = last(p[:-5] + ".copy_rate")
+    rows.append({"tag": tag, "ms": d["ms_per_step"], "peak": d["roofline"]["peak_measured"], "frac": d["roofline"]["frac"], "miller_avg": d["roofline"]["avg_launch_ms"],
+                 "overlap": d["roofline"]["overlap"], "phases": d["phases_ms"], "one": s, "copy": c["GB_per_s_read_plus_write"] if c else None,
+                 "sust": d["roofline"].get("peak_sustained_100ms")})
+extra = [("final session (part A)", os.path.join(root, "profiles", "r05_bench.json"))]
+for tag, p in extra:
+    d = last(p)
+    if d:
+        rows.append({"tag": tag, "ms": d["ms_per_step"], "peak": d["roofline"]["peak_measured"], "frac": d["roofline"]["frac"], "miller_avg": d["roofline"]["avg_launch_ms"],
+                     "overlap": d["roofline"]["overlap"], "phases": d["phases_ms"], "one": None, "copy": None, "sust": d["roofline"].get("peak_sustained_100ms")})
+rows.sort(key=lambda r: r["ms"])
+out = []
+out.append("# Box-to-box spread of the headline, round 5 (VERDICT round 4, item 6).  Every line is `python bench.py --steps 10 --warmup 3 --no-configs --no-cpu-baseline --no-rlc` in its own\n"
+           "# gpurun call (a fresh MI355X box each time; tools/gpu_box_probe.sh for box5..: the same call also ran the batch on ONE stream -- kernels alone on the GPU, so their\n"
+           "# times are exact -- and a 1 GiB device-to-device copy).  peak = the multiply-add probe right after the timed region, best 2 ms launch (T mad/s); sustained = the same\n"
+           "# kernel back to back for 100 ms as one interval (box9.. : added during the round); copy = read + write GB/s.\n")
+out.append("%-24s %9s %8s %9s %7s %12s %8s %10s %10s %9s" % ("box", "ms/step", "peak", "sustained", "frac", "k_miller avg", "overlap", "miller ph", "finalexp", "copy GB/s"))
+for r in rows:
+    out.append("%-24s %9.2f %8.2f %9s %7.3f %12.2f %8.2f %10.2f %10.2f %9s" % (r["tag"], r["ms"], r["peak"], "%.2f" % r["sust"] if r["sust"] else "-", r["frac"], r["miller_avg"], r["overlap"], r["phases"]["phase_miller"],
+                                                                          r["phases"]["phase_finalexp"], "%.0f" % r["copy"] if r["copy"] else "-"))
+ms = [r["ms"] for r in rows]
+out.append("\nspread: %.2f .. %.2f ms per 2^20 batch (%.1f %%); multiply-add peak %.2f .. %.2f T (%.1f %%)" % (min(ms), max(ms), 100 * (max(ms) / min(ms) - 1),
+           min(r["peak"] for r in rows), max(r["peak"] for r in rows), 100 * (max(r["peak"] for r in rows) / min(r["peak"] for r in rows) - 1)))
+ones = [r for r in rows if r["one"]]
+if len(ones) >= 2:
+    ones.sort(key=lambda r: r["one"]["ms_per_step"])
+    fast, slow = ones[0], ones[-1]
+    out.append("\n# ONE stream (BN254_STREAMS=1; per-kernel ms of the first 2^19-proof sub-batch, every kernel alone on the GPU): fastest and slowest box of those probed")
+    out.append("%-20s %12s %12s %9s %9s" % ("kernel", fast["tag"], slow["tag"], "diff ms", "diff %"))
+    kf, ks = fast["one"]["kernels_ms"], slow["one"]["kernels_ms"]
+    tot_f = tot_s = 0.0
+    for k in sorted(kf, key=lambda k: -kf[k]["total_ms"]):
+        a, b = kf[k]["total_ms"], ks.get(k, {"total_ms": 0})["total_ms"]
+        tot_f += a; tot_s += b
+        out.append("%-20s %12.3f %12.3f %9.3f %9.1f" % (k, a, b, b - a, 100 * (b / a - 1) if a else 0))
+    out.append("%-20s %12.3f %12.3f %9.3f %9.1f" % ("sum", tot_f, tot_s, tot_s - tot_f, 100 * (tot_s / tot_f - 1)))
+    out.append("%-20s %12.2f %12.2f" % ("ms/step, one stream", fast["one"]["ms_per_step"], slow["one"]["ms_per_step"]))
+    out.append("%-20s %12.2f %12.2f" % ("ms/step, two streams", fast["ms"], slow["ms"]))
+    out.append("%-20s %12.2f %12.2f" % ("peak (T mad/s)", fast["one"]["roofline"]["peak_measured"], slow["one"]["roofline"]["peak_measured"]))
+    out.append("%-20s %12.0f %12.0f" % ("copy GB/s", fast["copy"], slow["copy"]))
+    if fast["one"]["roofline"].get("peak_sustained_100ms") and slow["one"]["roofline"].get("peak_sustained_100ms"):
+        out.append("%-20s %12.2f %12.2f" % ("sustained 100 ms", fast["one"]["roofline"]["peak_sustained_100ms"], slow["one"]["roofline"]["peak_sustained_100ms"]))
+out.append("""
+# Reading.  The spread is carried by the ARITHMETIC kernels, all of them and in proportion to their length: k_miller_run +3 .. +5 %, k_f12_cyclo_sqr_n +2.5 .. +4 %, k_f12_mul +1 .. +3 %
+# between the fastest and the slower boxes, while the kernels that only move data (k_f12_conj, k_vm_init: +0 .. 0.5 %) and the multiply-add probe (best 2 ms launch: within
+# 1 %; 100 ms back to back: 32.4 .. 32.9 T) hardly differ.  So it is neither the HBM clock (round 4's suspect: k_f12_mul, the one traffic-exposed kernel, moves LEAST, and the
+# copy rate of a fast box (box8: 4751 GB/s) can be below that of a slow one) nor the plain multiply-add issue rate.  Checked and excluded as well: the shader clock as sysfs
+# reports it during the run (box11: 2410 .. 2413 MHz in all 161 samples, 60 ms apart -- no throttling visible to an ordinary user; power and temperature are not readable) and
+# instruction fetch (profiles/r05_icache_counters.csv: 99.3 % hits in k_miller_run although its loop body is 0.5 MB).  What the slow kernels have in common and the probe has
+# not: two wavefronts per SIMD (256 VGPRs) instead of four.  One wavefront can issue a multiply-add only every 9.1 cycles (profiles/r01_ubench_valu.txt), the SIMD accepts one
+# every 4.5: with exactly two wavefronts every cycle in which one of them waits (s_waitcnt on the LDS parking slots or on a workspace load, a scalar instruction) is a cycle at
+# half rate, so these kernels see the latency of LDS / L2 / fabric directly, the four-wavefront probe does not.  A box whose memory side answers a few percent slower therefore
+# loses a few percent in exactly these kernels.  Three wavefronts per SIMD would need <= 168 registers: tools/kbench CYC3 (one Granger-Scott squaring, 168 VGPRs, 180
+# spilled) takes 514 us against 316 us at two.  The fractions of the bench line are taken against the peak of the box of the run; the spread is part of what 0.77 .. 0.80 means.""")
+open(os.path.join(root, "profiles", "r05_box_variance.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))
