@@ -1,6 +1,7 @@
 """GPU tests of the round-5 additions, all through the C ABI: PlonK passes above 65 536 proofs (up to 2^18 per pass) on two key shapes, the device-resident and the
 multi-device PlonK entries, bn254_plonk_reserve / bn254_plonk_footprint, the known-answer self-test the library runs on a key's first use of a device."""
 import ctypes as C
+import os
 import random
 
 import pytest
@@ -82,6 +83,12 @@ def test_plonk_device_resident_entry(pkg, O, fixtures):
     pvk = pkg.PreparedPlonkVk(vk)
     dev = torch.device("cuda:0")
     side = torch.cuda.Stream(device=dev)
+    if os.environ.get("BN254_PLONK_HOST") == "1":
+        # the diagnostic build of the stages on host threads reads the proofs on the host: the resident entry refuses it, by name (tools/gpu_variants.sh runs the suite this way)
+        d = torch.zeros(904 + 64 + 1, dtype=torch.uint8, device=dev)
+        with pytest.raises(Exception, match="BN254_PLONK_HOST"):
+            pvk.verify_batch_device(d.data_ptr(), d.data_ptr() + 904, d.data_ptr() + 968, 1, proof_stride=904, stream=side.cuda_stream)
+        return
     for n, stride, flags in ((1, 904, 0), (300, 904, 0), (7000, 904, 0), (30000, 905, 0), (70000, 904, 0), (140000, 904, pkg.FLAG_RLC)):
         p, q, want = _tile(cases, exp, n, stride)
         hp = torch.frombuffer(bytearray(p), dtype=torch.uint8).pin_memory(); hq = torch.frombuffer(bytearray(q), dtype=torch.uint8).pin_memory()

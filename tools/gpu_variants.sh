@@ -15,6 +15,7 @@ run streams4 BN254_STREAMS=4
 run steps0 BN254_MILLER_RUN_STEPS=0
 run plonk_piece BN254_PLONK_PIECE=700 BN254_PLONK_WORKERS=3 BN254_PLONK_BIG_FROM=1000000000
 run plonk_onepass BN254_PLONK_BIG_FROM=1 BN254_PLONK_BIG_PIECE=65536
+run plonk_onepass_max BN254_PLONK_BIG_FROM=1 BN254_PLONK_BIG_PIECE=262144
 run msm_budget_small BN254_MSM_LANE_BUDGET=4096
 run msm_budget_large BN254_MSM_LANE_BUDGET=1048576
 run coop_fixed_off BN254_COOP_FIXED_MAX=0
