@@ -73,9 +73,9 @@ out.append("""
 # copy rate of a fast box (box8: 4751 GB/s) can be below that of a slow one) nor the plain multiply-add issue rate.  Checked and excluded as well: the shader clock as sysfs
 # reports it during the run (box11: 2410 .. 2413 MHz in all 161 samples, 60 ms apart -- no throttling visible to an ordinary user; power and temperature are not readable) and
 # instruction fetch (profiles/r05_icache_counters.csv: 99.3 % hits in k_miller_run although its loop body is 0.5 MB).  What the slow kernels have in common and the probe has
-# not: two wavefronts per SIMD (256 VGPRs) instead of four.  One wavefront can issue a multiply-add only every 9.1 cycles (profiles/r01_ubench_valu.txt), the SIMD accepts one
-# every 4.5: with exactly two wavefronts every cycle in which one of them waits (s_waitcnt on the LDS parking slots or on a workspace load, a scalar instruction) is a cycle at
-# half rate, so these kernels see the latency of LDS / L2 / fabric directly, the four-wavefront probe does not.  A box whose memory side answers a few percent slower therefore
+# not: two wavefronts per SIMD (256 VGPRs) instead of four.  Two wavefronts of this instruction mix ask for about 1.4 x what a SIMD issues (one wavefront alone reaches 0.61 of
+# the peak, two 0.79: profiles/r05_pair_split_probe.txt), so there is little slack: waits of a wavefront (s_waitcnt on the LDS parking slots or on a workspace load) beyond
+# that margin are lost issue cycles, and these kernels see the latency of LDS / L2 / fabric where the four-wavefront probe does not.  A box whose memory side answers a few percent slower
 # loses a few percent in exactly these kernels.  Three wavefronts per SIMD would need <= 168 registers: tools/kbench CYC3 (one Granger-Scott squaring, 168 VGPRs, 180
 # spilled) takes 514 us against 316 us at two.  The fractions of the bench line are taken against the peak of the box of the run; the spread is part of what 0.77 .. 0.80 means.""")
 open(os.path.join(root, "profiles", "r05_box_variance.txt"), "w").write("\n".join(out) + "\n")
