@@ -93,10 +93,11 @@ typedef struct bn254_g16_pvk bn254_g16_pvk;
 
 /* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
  * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
- * Miller-loop line tables for the two fixed G2 arguments, fixed-base tables for vk.K (byte windows, 650 KB per input; keys with more
- * than 16 inputs: comb tables, 655 KB per input).  Host work; no GPU needed.
- * LIMITS a caller must plan for: a key with 1024 public inputs takes 2.2 s to prepare on 8 host threads and holds 671 MB of tables on the host AND on every device it is used on
- * (uploaded at the first batch or bn254_groth16_reserve); keep the handle, do not prepare per call.  A 2-input key: 9 ms, 1.3 MB. */
+ * Miller-loop line tables for the two fixed G2 arguments, fixed-base tables for vk.K (byte windows, 650 KB per input, built here).  Host work; no GPU needed.
+ * Keys with more than 16 inputs use comb tables (655 KB per input) that are NOT built here: each device builds its own copy from the key's K points on first use
+ * (bn254_groth16_reserve, or the first batch; csrc/bn254_k_comb.hip: 13 ms for 1024 inputs), so preparing a 1024-input key costs 14 ms and 74 KB of host memory
+ * (until round 5: 2.2 s on 8 host threads and 671 MB on the host).  LIMIT a caller must still plan for: 671 MB of DEVICE memory per such key and device (1.6 GB
+ * during the construction); keep the handle, do not prepare per call.  A 2-input key: 9 ms, 1.3 MB.  BN254_COMB_HOST=1 keeps the host construction. */
 int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out);
 void bn254_groth16_vk_free(bn254_g16_pvk* pvk);
 /* number of public inputs the key expects (len(vk.K) - 1); SIZE_MAX for a key without K points: no input count satisfies groth16/verify.rs:54 */
@@ -334,6 +335,9 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
 /* host-only probe of the comb tables used for keys with many public inputs (csrc/bn254_host.hpp::build_comb_table): x * P computed from P's table
  * and the column digits of the 256-bit big-endian x, as the kernels do; out64 = uncompressed point, all zero for the identity */
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]);
+/* the comb tables `device` built for a key with many public inputs (csrc/bn254_k_comb.hip) against the host construction: the tables of the first `inputs` inputs read back
+ * and compared entry by entry as field values; *mismatches = entries that differ */
+int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches);
 
 /* Revision of this header's binary interface: bumped whenever a function changes its arguments, an array argument its length or a slot its meaning (5: this round --
  * BN254_PLONK_NUM_TIMINGS has been 9 since revision 4, bn254_dbg_plonk_msm_plan writes 9 ints per row).  A binding compares it with the value it was generated for. */

@@ -153,6 +153,25 @@ template <typename T> static int upload(T** dst, const std::vector<T>& src) {
   *dst = p;
   return BN254_OK;
 }
+// The comb tables of a key with many public inputs, built on the current device from the key's K points (bn254_k_comb.hip): 80 bytes x 8192 entries per input stay, the
+// construction scratch (27 dwords per entry) is freed again.  *dst stays null unless the table is complete (as upload() above).
+static int build_comb_on_device(const G16Prepared& host, int32_t** dst) {
+  if (*dst) return BN254_OK;
+  const size_t nb = host.key_inputs(), entries = nb << G16_COMB_TEETH;
+  int32_t *kp = nullptr, *tab = nullptr, *teeth = nullptr, *plane = nullptr;
+  auto drop = [&]() { if (kp) (void)hipFree(kp); if (teeth) (void)hipFree(teeth); if (plane) (void)hipFree(plane); };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&kp, host.kpts.size() * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&tab, entries * MSM_ENTRY_DWORDS * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&teeth, nb * G16_COMB_TEETH * 2 * BN_NL * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&plane, entries * 27 * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMemcpy(kp, host.kpts.data(), host.kpts.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = bn254_launch_comb_build(kp, (uint32_t)nb, tab, teeth, plane, nullptr)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+    drop(); if (tab) (void)hipFree(tab);
+    return set_err(BN254_E_HIP, std::string("comb tables of the key: ") + hipGetErrorString(e));
+  }
+  drop();
+  *dst = tab;
+  return BN254_OK;
+}
 static DevState* dev_state(const bn254_g16_pvk* pvk, int device) {
   std::lock_guard<std::mutex> lk(pvk->mu);
   return &pvk->dev[device];   // std::map nodes never move
@@ -162,9 +181,10 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
   int rc = check_device(device);
   if (rc) return rc;
   if (!d.ready) {
-    if ((rc = upload(&d.k0, pvk->host.k0)) || (rc = upload(&d.gtab, pvk->host.gtab)) || (rc = upload(&d.dtab, pvk->host.dtab)) ||
-        (rc = upload(&d.target, pvk->host.target)) || (rc = upload(&d.msm, pvk->host.msm)))
+    if ((rc = upload(&d.k0, pvk->host.k0)) || (rc = upload(&d.gtab, pvk->host.gtab)) || (rc = upload(&d.dtab, pvk->host.dtab)) || (rc = upload(&d.target, pvk->host.target)))
       return rc;
+    if (pvk->host.msm_comb && pvk->host.msm.empty()) { if ((rc = build_comb_on_device(pvk->host, &d.msm))) return rc; }
+    else if ((rc = upload(&d.msm, pvk->host.msm))) return rc;
     HIPCK(hipEventCreateWithFlags(&d.busy_ev, hipEventDisableTiming));
     d.ready = true;
   }
@@ -1986,6 +2006,31 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
   return BN254_OK;
 }
 
+// The comb tables a device built for a key (bn254_k_comb.hip) against the host construction (build_comb_table): the tables of the first `inputs` public inputs are read
+// back and compared entry by entry as field values.  *mismatches = entries that differ (0: identical); needs a device, and a key whose tables are in comb form.
+int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches) {
+  if (!pvk || !mismatches || inputs < 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (!pvk->host.msm_comb || pvk->host.kpts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables are not device-built comb tables");
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  int rc = ensure_dev(pvk, *d, device, 1);
+  if (rc) return rc;
+  const size_t nb = pvk->host.key_inputs(), per = ((size_t)1 << G16_COMB_TEETH) * MSM_ENTRY_DWORDS;
+  if ((size_t)inputs > nb) inputs = (int)nb;
+  std::vector<int32_t> dev_tab((size_t)inputs * per), host_tab(per);
+  HIPCK(hipMemcpy(dev_tab.data(), d->msm, dev_tab.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  size_t bad = 0;
+  for (int i = 0; i < inputs; i++) {
+    G1Aff K; K.x = fp_from_limbs(pvk->host.kpts.data() + (size_t)i * 2 * BN_NL); K.y = fp_from_limbs(pvk->host.kpts.data() + (size_t)i * 2 * BN_NL + BN_NL);
+    build_comb_table(host_tab.data(), K);
+    for (size_t e = 1; e < ((size_t)1 << G16_COMB_TEETH); e++) {
+      const int32_t* a = dev_tab.data() + (size_t)i * per + e * MSM_ENTRY_DWORDS; const int32_t* b = host_tab.data() + e * MSM_ENTRY_DWORDS;
+      if (!fp_eq(fp_from_limbs(a), fp_from_limbs(b)) || !fp_eq(fp_from_limbs(a + BN_NL), fp_from_limbs(b + BN_NL)) || a[18] != 0 || a[19] != 0) bad++;
+    }
+  }
+  *mismatches = bad;
+  return BN254_OK;
+}
 // host-only probe of the comb tables of keys with many public inputs: x * P from build_comb_table(P) and the column digits the kernels use
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]) {
   if (!p64 || !x32 || !out64) return set_err(BN254_E_BAD_ARG, "bad argument");

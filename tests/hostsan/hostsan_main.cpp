@@ -108,6 +108,7 @@ hipError_t bn254_launch_pairing2_fixed(int32_t*, uint8_t* status, size_t n, cons
   for (size_t i = 0; i < n; i++) if (status[i] & BN254_ST_PENDING) status[i] = BN254_ST_ACCEPT;
   return hipSuccess;
 }
+hipError_t bn254_launch_comb_build(const int32_t*, uint32_t, int32_t*, int32_t*, int32_t*, hipStream_t) { g_launches++; return hipSuccess; }
 double bn254_measure_valu_peak(int) { return 1.0; }
 double bn254_measure_valu_sustained(double) { return 1.0; }
 hipError_t bn254_launch_dbg_fp_mul(const uint8_t*, const uint8_t*, uint8_t*, size_t, hipStream_t) { return hipSuccess; }

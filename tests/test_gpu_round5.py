@@ -144,3 +144,17 @@ def test_plonk_self_test_guards_the_device_stages(pkg, fixtures):
         assert len(st) == 1 and st[0] in (pkg.ACCEPT, 5, 6, 7, 9), st
         pvk.close()
     assert pkg.lib().bn254_abi_version() == 5
+
+
+def test_comb_tables_built_on_device_match_the_host_construction(pkg):
+    """Keys with more than 16 public inputs: the comb tables (8192 entries per input) are built by the device that uses them (csrc/bn254_k_comb.hip) from the key's K points;
+    the host keeps no copy.  Entry by entry, as field values, they must be what bn254_host.hpp::build_comb_table makes -- for a 17-input key (the smallest comb key: every
+    input checked) and the first inputs of a 300-input key; the statuses of batches on such keys against the oracle are the wide-key tests of the suite."""
+    L = pkg.lib()
+    L.bn254_dbg_comb_table_compare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    for n_public, check in ((17, 17), (300, 4)):
+        vk = pkg.synth_groth16(0xC0B0 + n_public, n_public, 1, invalid_every=0, agree=True, threads=4)[0]
+        pvk = pkg.PreparedVk(vk)
+        bad = C.c_size_t(12345)
+        assert L.bn254_dbg_comb_table_compare(pvk._h, 0, check, C.byref(bad)) == 0, L.bn254_last_error()
+        assert bad.value == 0, (n_public, bad.value)
