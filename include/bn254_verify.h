@@ -95,9 +95,9 @@ typedef struct bn254_g16_pvk bn254_g16_pvk;
  * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
  * Miller-loop line tables for the two fixed G2 arguments, fixed-base tables for vk.K (byte windows, 650 KB per input, built here).  Host work; no GPU needed.
  * Keys with more than 16 inputs use comb tables (655 KB per input) that are NOT built here: each device builds its own copy from the key's K points on first use
- * (bn254_groth16_reserve, or the first batch; csrc/bn254_k_comb.hip: 13 ms for 1024 inputs), so preparing a 1024-input key costs 14 ms and 74 KB of host memory
- * (until round 5: 2.2 s on 8 host threads and 671 MB on the host).  LIMIT a caller must still plan for: 671 MB of DEVICE memory per such key and device (1.6 GB
- * during the construction); keep the handle, do not prepare per call.  A 2-input key: 9 ms, 1.3 MB.  BN254_COMB_HOST=1 keeps the host construction. */
+ * (bn254_groth16_reserve, or the first batch; csrc/bn254_k_comb.hip: 17 ms for 1024 inputs), so preparing a 1024-input key costs 14 ms and 74 KB of host memory
+ * (until round 5: 2.2 s on 8 host threads and 671 MB on the host).  LIMIT a caller must still plan for: 671 MB of DEVICE memory per such key and device (+ 226 MB of
+ * scratch during the construction); keep the handle, do not prepare per call.  A 2-input key: 9 ms, 1.3 MB.  BN254_COMB_HOST=1 keeps the host construction. */
 int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out);
 void bn254_groth16_vk_free(bn254_g16_pvk* pvk);
 /* number of public inputs the key expects (len(vk.K) - 1); SIZE_MAX for a key without K points: no input count satisfies groth16/verify.rs:54 */

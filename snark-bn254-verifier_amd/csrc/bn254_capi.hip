@@ -158,17 +158,24 @@ template <typename T> static int upload(T** dst, const std::vector<T>& src) {
 static int build_comb_on_device(const G16Prepared& host, int32_t** dst) {
   if (*dst) return BN254_OK;
   const size_t nb = host.key_inputs(), entries = nb << G16_COMB_TEETH;
+  const size_t slice = nb < 256 ? nb : 256;                       // inputs per construction pass: bounds the scratch (27 dwords per entry) at 226 MB whatever the key
   int32_t *kp = nullptr, *tab = nullptr, *teeth = nullptr, *plane = nullptr;
   auto drop = [&]() { if (kp) (void)hipFree(kp); if (teeth) (void)hipFree(teeth); if (plane) (void)hipFree(plane); };
   hipError_t e;
   if ((e = hipMalloc((void**)&kp, host.kpts.size() * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&tab, entries * MSM_ENTRY_DWORDS * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&teeth, nb * G16_COMB_TEETH * 2 * BN_NL * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&plane, entries * 27 * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMemcpy(kp, host.kpts.data(), host.kpts.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = bn254_launch_comb_build(kp, (uint32_t)nb, tab, teeth, plane, nullptr)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+      (e = hipMalloc((void**)&teeth, slice * G16_COMB_TEETH * 2 * BN_NL * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&plane, (slice << G16_COMB_TEETH) * 27 * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMemcpy(kp, host.kpts.data(), host.kpts.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) {
     drop(); if (tab) (void)hipFree(tab);
     return set_err(BN254_E_HIP, std::string("comb tables of the key: ") + hipGetErrorString(e));
   }
+  for (size_t i0 = 0; i0 < nb && e == hipSuccess; i0 += slice) {
+    const size_t m = nb - i0 < slice ? nb - i0 : slice;            // the passes run one after the other on the null stream and share the scratch
+    e = bn254_launch_comb_build(kp + i0 * 2 * BN_NL, (uint32_t)m, tab + (i0 << G16_COMB_TEETH) * MSM_ENTRY_DWORDS, teeth, plane, nullptr);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   drop();
+  if (e != hipSuccess) { (void)hipFree(tab); return set_err(BN254_E_HIP, std::string("comb tables of the key: ") + hipGetErrorString(e)); }
   *dst = tab;
   return BN254_OK;
 }

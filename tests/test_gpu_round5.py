@@ -149,10 +149,10 @@ def test_plonk_self_test_guards_the_device_stages(pkg, fixtures):
 def test_comb_tables_built_on_device_match_the_host_construction(pkg):
     """Keys with more than 16 public inputs: the comb tables (8192 entries per input) are built by the device that uses them (csrc/bn254_k_comb.hip) from the key's K points;
     the host keeps no copy.  Entry by entry, as field values, they must be what bn254_host.hpp::build_comb_table makes -- for a 17-input key (the smallest comb key: every
-    input checked) and the first inputs of a 300-input key; the statuses of batches on such keys against the oracle are the wide-key tests of the suite."""
+    input checked) and a 300-input key (two construction passes); the statuses of batches on such keys against the oracle are the wide-key tests of the suite."""
     L = pkg.lib()
     L.bn254_dbg_comb_table_compare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
-    for n_public, check in ((17, 17), (300, 4)):
+    for n_public, check in ((17, 17), (300, 300)):          # 300 inputs: two construction passes (256 + 44)
         vk = pkg.synth_groth16(0xC0B0 + n_public, n_public, 1, invalid_every=0, agree=True, threads=4)[0]
         pvk = pkg.PreparedVk(vk)
         bad = C.c_size_t(12345)
