@@ -140,7 +140,7 @@ int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
 
 /* Groth16Verifier::verify (lib.rs:44-49) as one call: one proof, one status byte, vk given as bytes on every call like the
  * reference.  The prepared form of the last four keys (exact byte match, per mode) is kept, so only the first call with a key pays
- * its preparation (9 ms of an 11 ms call; 2 ms afterwards); BN254_KEY_CACHE=0 in the environment switches the cache off.
+ * its preparation (9 ms of an 11 ms call; 2 ms afterwards); BN254_KEY_CACHE=0 in the environment switches the cache off, BN254_KEY_CACHE=N (1 .. 64) keeps the last N keys (default 4).
  * bn254_plonk_verify does the same.  Runs on the GPU (device 0). */
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
@@ -335,6 +335,8 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
 /* host-only probe of the comb tables used for keys with many public inputs (csrc/bn254_host.hpp::build_comb_table): x * P computed from P's table
  * and the column digits of the 256-bit big-endian x, as the kernels do; out64 = uncompressed point, all zero for the identity */
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]);
+/* prepared keys the single-proof entries keep (BN254_KEY_CACHE in the environment: unset 4, 0 off, N up to 64) */
+int bn254_dbg_key_cache_slots(void);
 /* the comb tables `device` built for a key with many public inputs (csrc/bn254_k_comb.hip) against the host construction: the tables of the first `inputs` inputs read back
  * and compared entry by entry as field values; *mismatches = entries that differ */
 int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches);

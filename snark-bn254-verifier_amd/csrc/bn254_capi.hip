@@ -560,21 +560,24 @@ template <class F> static void plonk_parallel(size_t n, unsigned hw, F&& f) {
 
 // ---- prepared keys of the single-proof entry points (bn254_groth16_verify, bn254_plonk_verify): the last KEY_CACHE_SLOTS keys by exact bytes.
 // Entries are shared_ptrs: an evicted key is freed when its last in-flight call returns.  The cache object itself is never destroyed (keys hold
-// device memory; freeing it from a static destructor would race the HIP runtime's own teardown).  BN254_KEY_CACHE=0 switches it off.
+// device memory; freeing it from a static destructor would race the HIP runtime's own teardown).  BN254_KEY_CACHE=0 switches it off, BN254_KEY_CACHE=N (1 .. 64) sets the
+// number of keys kept (a caller that rotates through more keys than slots pays the preparation, ~9 ms of an 11 ms call, on every miss).
 #define KEY_CACHE_SLOTS 4
+#define KEY_CACHE_MAX_SLOTS 64
 template <class T, void (*FREE)(T*)>
 class KeyCache {
  public:
   std::shared_ptr<T> find(const uint8_t* vk, size_t len, unsigned mode) {
-    if (!enabled()) return nullptr;
+    if (!slots()) return nullptr;
     std::lock_guard<std::mutex> lk(mu_);
     for (auto& e : e_)
       if (e.h && e.mode == mode && e.bytes.size() == len && memcmp(e.bytes.data(), vk, len) == 0) { e.tick = ++clock_; return e.h; }
     return nullptr;
   }
+  static int capacity() { return slots(); }
   std::shared_ptr<T> insert(const uint8_t* vk, size_t len, unsigned mode, T* raw) {
     std::shared_ptr<T> h(raw, [](T* p) { FREE(p); });
-    if (!enabled()) return h;
+    if (!slots()) return h;
     std::lock_guard<std::mutex> lk(mu_);
     Entry* v = &e_[0];
     for (auto& e : e_) { if (!e.h) { v = &e; break; } if (e.tick < v->tick) v = &e; }
@@ -583,9 +586,10 @@ class KeyCache {
   }
 
  private:
-  static bool enabled() { static const bool on = [] { const char* e = getenv("BN254_KEY_CACHE"); return !e || atoi(e) != 0; }(); return on; }
+  // unset: KEY_CACHE_SLOTS; 0: off; N: N slots (at most KEY_CACHE_MAX_SLOTS)
+  static int slots() { static const int n = [] { const char* e = getenv("BN254_KEY_CACHE"); long v = e ? atol(e) : KEY_CACHE_SLOTS; return (int)(v < 0 ? 0 : (v > KEY_CACHE_MAX_SLOTS ? KEY_CACHE_MAX_SLOTS : v)); }(); return n; }
   struct Entry { std::vector<uint8_t> bytes; unsigned mode = 0; std::shared_ptr<T> h; uint64_t tick = 0; };
-  std::mutex mu_; Entry e_[KEY_CACHE_SLOTS]; uint64_t clock_ = 0;
+  std::mutex mu_; std::vector<Entry> e_ = std::vector<Entry>((size_t)(slots() > 0 ? slots() : 1)); uint64_t clock_ = 0;
 };
 static KeyCache<bn254_g16_pvk, bn254_groth16_vk_free>& g16_key_cache() { static auto* c = new KeyCache<bn254_g16_pvk, bn254_groth16_vk_free>(); return *c; }
 static KeyCache<bn254_plonk_pvk, bn254_plonk_vk_free>& plonk_key_cache() { static auto* c = new KeyCache<bn254_plonk_pvk, bn254_plonk_vk_free>(); return *c; }
@@ -596,6 +600,7 @@ extern "C" {
 const char* bn254_last_error(void) { return g_err.c_str(); }
 const char* bn254_version(void) { return "bn254-verify-amd 0.5 (gfx950)"; }
 int bn254_abi_version(void) { return BN254_ABI_VERSION; }
+int bn254_dbg_key_cache_slots(void) { return KeyCache<bn254_g16_pvk, bn254_groth16_vk_free>::capacity(); }
 const char* bn254_status_string(int s) {
   switch (s) {
     case BN254_REJECT: return "reject"; case BN254_ACCEPT: return "accept"; case BN254_ERR_NOT_MEMBER: return "coordinate not a field member";

@@ -49,6 +49,18 @@ def test_header_is_plain_c_and_links(pkg, tmp_path):
     assert (int(lo), int(hi)) == sharding.shard_bounds(10, 3, 1)
 
 
+def test_key_cache_capacity_from_the_environment(pkg):
+    """The single-proof entries keep the last prepared keys by exact bytes: 4 by default, BN254_KEY_CACHE=0 none, =N that many (capped at 64) -- read once per process."""
+    import subprocess, sys
+    code = ("import ctypes as C, os; L = C.CDLL(os.path.join(%r, 'snark-bn254-verifier_amd', 'libbn254_verify_amd.so')); print(L.bn254_dbg_key_cache_slots())" % ROOT)
+    for env, want in ((None, 4), ("0", 0), ("1", 1), ("9", 9), ("1000", 64), ("-3", 0)):
+        e = dict(os.environ); e.pop("BN254_KEY_CACHE", None)
+        if env is not None:
+            e["BN254_KEY_CACHE"] = env
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
+        assert r.returncode == 0 and int(r.stdout.strip()) == want, (env, r.stdout, r.stderr[-500:])
+
+
 def test_status_codes_shared_with_oracle(pkg, O):
     hdr = open(os.path.join(ROOT, "include", "bn254_verify.h")).read()
     ohdr = open(os.path.join(ROOT, "oracle", "oracle.h")).read()
