@@ -158,3 +158,20 @@ def test_comb_tables_built_on_device_match_the_host_construction(pkg):
         bad = C.c_size_t(12345)
         assert L.bn254_dbg_comb_table_compare(pvk._h, 0, check, C.byref(bad)) == 0, L.bn254_last_error()
         assert bad.value == 0, (n_public, bad.value)
+
+
+def test_bench_plonk_mode_prints_the_contract_line():
+    """`python bench.py --plonk` (one PlonK call sharded like the Groth16 batch; here 2^12 proofs on one GPU): ONE JSON line with the fields of the bench contract, the PlonK
+    metric name, a roofline and a CPU baseline; its own checks (every status byte against the workload, the first 16 against the oracle, the gathered vector) have passed
+    when it prints."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--plonk", "--batch-log2", "12", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("PlonK verifies/sec") and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 1e5 and d["config"]["global_batch"] == 4096
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
