@@ -93,11 +93,12 @@ typedef struct bn254_g16_pvk bn254_g16_pvk;
 
 /* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
  * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
- * Miller-loop line tables for the two fixed G2 arguments, fixed-base tables for vk.K (byte windows, 650 KB per input, built here).  Host work; no GPU needed.
- * Keys with more than 16 inputs use comb tables (655 KB per input) that are NOT built here: each device builds its own copy from the key's K points on first use
- * (bn254_groth16_reserve, or the first batch; csrc/bn254_k_comb.hip: 17 ms for 1024 inputs), so preparing a 1024-input key costs 14 ms and 74 KB of host memory
- * (until round 5: 2.2 s on 8 host threads and 671 MB on the host).  LIMIT a caller must still plan for: 671 MB of DEVICE memory per such key and device (+ 226 MB of
- * scratch during the construction); keep the handle, do not prepare per call.  A 2-input key: 9 ms, 1.3 MB.  BN254_COMB_HOST=1 keeps the host construction. */
+ * Miller-loop line tables for the two fixed G2 arguments.  Host work; no GPU needed: 3 ms for a 2-input key, 4 ms for 16 inputs, 14 ms for 1024.
+ * The fixed-base tables for vk.K (byte windows, 650 KB per input; keys with more than 16 inputs: comb tables, 655 KB per input) are NOT built here: each device builds its
+ * own copy from the key's K points on first use (bn254_groth16_reserve, or the first batch; csrc/bn254_k_comb.hip: 2 ms for 2 inputs, 17 ms for 1024), and the host keeps
+ * 72 bytes per input (until round 5 the host built them: 9 ms for 2 inputs, 0.18 s for 16, 2.2 s for 1024 on 8 threads, and held the copy).  LIMIT a caller must still plan
+ * for: 671 MB of DEVICE memory per 1024-input key and device (+ 226 MB of scratch during the construction); keep the handle, do not prepare per call.
+ * BN254_TABLES_HOST=1 keeps the host construction. */
 int bn254_groth16_vk_prepare(const uint8_t* vk, size_t vk_len, unsigned mode, bn254_g16_pvk** out);
 void bn254_groth16_vk_free(bn254_g16_pvk* pvk);
 /* number of public inputs the key expects (len(vk.K) - 1); SIZE_MAX for a key without K points: no input count satisfies groth16/verify.rs:54 */
@@ -140,7 +141,7 @@ int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
 
 /* Groth16Verifier::verify (lib.rs:44-49) as one call: one proof, one status byte, vk given as bytes on every call like the
  * reference.  The prepared form of the last four keys (exact byte match, per mode) is kept, so only the first call with a key pays
- * its preparation (9 ms of an 11 ms call; 2 ms afterwards); BN254_KEY_CACHE=0 in the environment switches the cache off, BN254_KEY_CACHE=N (1 .. 64) keeps the last N keys (default 4).
+ * its preparation (5 ms of a 7 ms call; 2 ms afterwards); BN254_KEY_CACHE=0 in the environment switches the cache off, BN254_KEY_CACHE=N (1 .. 64) keeps the last N keys (default 4).
  * bn254_plonk_verify does the same.  Runs on the GPU (device 0). */
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
@@ -337,9 +338,10 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]);
 /* prepared keys the single-proof entries keep (BN254_KEY_CACHE in the environment: unset 4, 0 off, N up to 64) */
 int bn254_dbg_key_cache_slots(void);
-/* the comb tables `device` built for a key with many public inputs (csrc/bn254_k_comb.hip) against the host construction: the tables of the first `inputs` inputs read back
+/* the fixed-base tables `device` built for a key (csrc/bn254_k_comb.hip: comb tables for more than 16 public inputs, byte windows otherwise) against the host construction: the tables of the first `inputs` inputs read back
  * and compared entry by entry as field values; *mismatches = entries that differ */
 int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches);
+int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches);   /* the same for the byte-window tables of a PlonK key's points (all of them) */
 
 /* Revision of this header's binary interface: bumped whenever a function changes its arguments, an array argument its length or a slot its meaning (5: this round --
  * BN254_PLONK_NUM_TIMINGS has been 9 since revision 4, bn254_dbg_plonk_msm_plan writes 9 ints per row).  A binding compares it with the value it was generated for. */

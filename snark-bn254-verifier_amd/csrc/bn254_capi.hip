@@ -153,29 +153,32 @@ template <typename T> static int upload(T** dst, const std::vector<T>& src) {
   *dst = p;
   return BN254_OK;
 }
-// The comb tables of a key with many public inputs, built on the current device from the key's K points (bn254_k_comb.hip): 80 bytes x 8192 entries per input stay, the
-// construction scratch (27 dwords per entry) is freed again.  *dst stays null unless the table is complete (as upload() above).
-static int build_comb_on_device(const G16Prepared& host, int32_t** dst) {
+// The fixed-base tables of a key, built on the current device from the key's points (bn254_k_comb.hip; form 0: comb tables, 1: byte windows; pts: 18 dwords per point):
+// 80 bytes x 8192 (8160) entries per point stay, the construction scratch (27 dwords per entry, passes of 256 points: 226 MB at most) is freed again.  *dst stays null unless
+// the table is complete (as upload() above).
+static int build_tables_on_device(int form, const std::vector<int32_t>& pts, int32_t** dst) {
   if (*dst) return BN254_OK;
-  const size_t nb = host.key_inputs(), entries = nb << G16_COMB_TEETH;
-  const size_t slice = nb < 256 ? nb : 256;                       // inputs per construction pass: bounds the scratch (27 dwords per entry) at 226 MB whatever the key
-  int32_t *kp = nullptr, *tab = nullptr, *teeth = nullptr, *plane = nullptr;
-  auto drop = [&]() { if (kp) (void)hipFree(kp); if (teeth) (void)hipFree(teeth); if (plane) (void)hipFree(plane); };
+  const size_t np = pts.size() / (2 * BN_NL);
+  const size_t per_point = (form == 0 ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 255) * MSM_ENTRY_DWORDS;   // dwords of finished table per point
+  const size_t teeth = bn254_tab_build_teeth(form), entries = bn254_tab_build_entries(form);
+  const size_t slice = np < 256 ? np : 256;
+  int32_t *kp = nullptr, *tab = nullptr, *tplane = nullptr, *taff = nullptr, *plane = nullptr;
+  auto drop = [&]() { if (kp) (void)hipFree(kp); if (tplane) (void)hipFree(tplane); if (taff) (void)hipFree(taff); if (plane) (void)hipFree(plane); };
   hipError_t e;
-  if ((e = hipMalloc((void**)&kp, host.kpts.size() * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&tab, entries * MSM_ENTRY_DWORDS * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&teeth, slice * G16_COMB_TEETH * 2 * BN_NL * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&plane, (slice << G16_COMB_TEETH) * 27 * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMemcpy(kp, host.kpts.data(), host.kpts.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) {
+  if ((e = hipMalloc((void**)&kp, pts.size() * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&tab, np * per_point * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&tplane, slice * teeth * 27 * sizeof(int32_t))) != hipSuccess || (e = hipMalloc((void**)&taff, slice * teeth * 2 * BN_NL * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&plane, slice * entries * 27 * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMemcpy(kp, pts.data(), pts.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) {
     drop(); if (tab) (void)hipFree(tab);
-    return set_err(BN254_E_HIP, std::string("comb tables of the key: ") + hipGetErrorString(e));
+    return set_err(BN254_E_HIP, std::string("fixed-base tables of the key: ") + hipGetErrorString(e));
   }
-  for (size_t i0 = 0; i0 < nb && e == hipSuccess; i0 += slice) {
-    const size_t m = nb - i0 < slice ? nb - i0 : slice;            // the passes run one after the other on the null stream and share the scratch
-    e = bn254_launch_comb_build(kp + i0 * 2 * BN_NL, (uint32_t)m, tab + (i0 << G16_COMB_TEETH) * MSM_ENTRY_DWORDS, teeth, plane, nullptr);
+  for (size_t i0 = 0; i0 < np && e == hipSuccess; i0 += slice) {
+    const size_t m = np - i0 < slice ? np - i0 : slice;            // the passes run one after the other on the null stream and share the scratch
+    e = bn254_launch_tab_build(form, kp + i0 * 2 * BN_NL, (uint32_t)m, tab + i0 * per_point, tplane, taff, plane, nullptr);
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   drop();
-  if (e != hipSuccess) { (void)hipFree(tab); return set_err(BN254_E_HIP, std::string("comb tables of the key: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(tab); return set_err(BN254_E_HIP, std::string("fixed-base tables of the key: ") + hipGetErrorString(e)); }
   *dst = tab;
   return BN254_OK;
 }
@@ -190,7 +193,7 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
   if (!d.ready) {
     if ((rc = upload(&d.k0, pvk->host.k0)) || (rc = upload(&d.gtab, pvk->host.gtab)) || (rc = upload(&d.dtab, pvk->host.dtab)) || (rc = upload(&d.target, pvk->host.target)))
       return rc;
-    if (pvk->host.msm_comb && pvk->host.msm.empty()) { if ((rc = build_comb_on_device(pvk->host, &d.msm))) return rc; }
+    if (!pvk->host.kpts.empty() && pvk->host.msm.empty()) { if ((rc = build_tables_on_device(pvk->host.msm_comb ? 0 : 1, pvk->host.kpts, &d.msm))) return rc; }
     else if ((rc = upload(&d.msm, pvk->host.msm))) return rc;
     HIPCK(hipEventCreateWithFlags(&d.busy_ev, hipEventDisableTiming));
     d.ready = true;
@@ -319,7 +322,8 @@ struct PlonkLease {   // the contexts of one call
 struct bn254_plonk_pvk {
   PlonkKey key;
   std::vector<int32_t> tab0, tab1, one;
-  std::vector<int32_t> fixed_tabs;     // bn254_host.hpp::build_window_table of every key point that enters an MSM (bn254_plonk.hpp::plonk_table_point)
+  std::vector<int32_t> fixed_tabs;     // bn254_host.hpp::build_window_table of every key point that enters an MSM (bn254_plonk.hpp::plonk_table_point) -- BN254_TABLES_HOST=1 only
+  std::vector<int32_t> fixed_pts;      // those points as affine digits (18 dwords each): the tables are built on the device that uses them (bn254_k_comb.hip)
   MsmShape shape1, shape2, shape2_rlc; // term kinds of the two MSM launches (plonk_msm1_shape / plonk_msm2_shape; _rlc: the weighted form of BN254_FLAG_RLC)
   mutable std::mutex mu;               // protects the map below (lookup / insertion / first upload); batches take contexts from the device's pool
   mutable std::map<int, PlonkDev> dev;
@@ -347,7 +351,9 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
   if (rc) return rc;
   PlonkDev& d = pvk->dev[device];
   if (!d.ready) {
-    if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one)) || (rc = upload(&d.fixed_tabs, pvk->fixed_tabs))) return rc;
+    if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
+    if (!pvk->fixed_pts.empty() && pvk->fixed_tabs.empty()) { if ((rc = build_tables_on_device(1, pvk->fixed_pts, &d.fixed_tabs))) return rc; }
+    else if ((rc = upload(&d.fixed_tabs, pvk->fixed_tabs))) return rc;
     // the key and the field constants for the device-side stages
     if (sizeof(PlonkKey) != bn254_plonk_key_bytes()) return set_err(BN254_E_HIP, "PlonK key layout differs between the translation units");
     HIPCK(bn254_plonk_dev_init(device));
@@ -1314,12 +1320,18 @@ int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** o
   {
     const int nt = plonk_num_tables(p->key);
     const size_t per = (size_t)32 * 255 * MSM_ENTRY_DWORDS;
+    if (!bn254_tables_on_host()) {
+      // built on the device that uses them (bn254_k_comb.hip): the host keeps the points
+      p->fixed_pts.resize((size_t)nt * 2 * BN_NL);
+      for (int i = 0; i < nt; i++) { const G1Aff& q = plonk_table_point(p->key, i); fp_to_limbs(p->fixed_pts.data() + (size_t)i * 2 * BN_NL, q.x); fp_to_limbs(p->fixed_pts.data() + (size_t)i * 2 * BN_NL + BN_NL, q.y); }
+    } else {
     p->fixed_tabs.assign((size_t)nt * per, 0);
     unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > (unsigned)nt) hw = (unsigned)nt;
     std::vector<std::thread> th;
     for (unsigned t_ = 0; t_ < hw; t_++)
       th.emplace_back([&, t_]() { for (int i = (int)t_; i < nt; i += (int)hw) build_window_table(p->fixed_tabs.data() + (size_t)i * per, plonk_table_point(p->key, i)); });
     for (auto& x : th) x.join();
+    }
   }
   plonk_msm1_shape(p->key, p->shape1); plonk_msm2_shape(p->key, p->shape2); plonk_msm2_shape(p->key, p->shape2_rlc, true);
   *out = p;
@@ -2018,30 +2030,42 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
   return BN254_OK;
 }
 
-// The comb tables a device built for a key (bn254_k_comb.hip) against the host construction (build_comb_table): the tables of the first `inputs` public inputs are read
-// back and compared entry by entry as field values.  *mismatches = entries that differ (0: identical); needs a device, and a key whose tables are in comb form.
-int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches) {
-  if (!pvk || !mismatches || inputs < 1) return set_err(BN254_E_BAD_ARG, "bad argument");
-  if (!pvk->host.msm_comb || pvk->host.kpts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables are not device-built comb tables");
-  DevState* d = dev_state(pvk, device);
-  std::lock_guard<std::mutex> lk(d->mu);
-  int rc = ensure_dev(pvk, *d, device, 1);
-  if (rc) return rc;
-  const size_t nb = pvk->host.key_inputs(), per = ((size_t)1 << G16_COMB_TEETH) * MSM_ENTRY_DWORDS;
-  if ((size_t)inputs > nb) inputs = (int)nb;
+// The fixed-base tables a device built for a key (bn254_k_comb.hip) against the host constructions (build_comb_table / build_window_table): the tables of the first `inputs`
+// points are read back and compared entry by entry as field values.  *mismatches = entries that differ (0: identical); needs a device.
+static int compare_tables(int form, const std::vector<int32_t>& pts, const int32_t* d_tab, int inputs, size_t* mismatches) {
+  const size_t np = pts.size() / (2 * BN_NL), n_entries = form == 0 ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 255, per = n_entries * MSM_ENTRY_DWORDS;
+  if ((size_t)inputs > np) inputs = (int)np;
   std::vector<int32_t> dev_tab((size_t)inputs * per), host_tab(per);
-  HIPCK(hipMemcpy(dev_tab.data(), d->msm, dev_tab.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(dev_tab.data(), d_tab, dev_tab.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
   size_t bad = 0;
   for (int i = 0; i < inputs; i++) {
-    G1Aff K; K.x = fp_from_limbs(pvk->host.kpts.data() + (size_t)i * 2 * BN_NL); K.y = fp_from_limbs(pvk->host.kpts.data() + (size_t)i * 2 * BN_NL + BN_NL);
-    build_comb_table(host_tab.data(), K);
-    for (size_t e = 1; e < ((size_t)1 << G16_COMB_TEETH); e++) {
+    G1Aff K; K.x = fp_from_limbs(pts.data() + (size_t)i * 2 * BN_NL); K.y = fp_from_limbs(pts.data() + (size_t)i * 2 * BN_NL + BN_NL);
+    if (form == 0) build_comb_table(host_tab.data(), K); else build_window_table(host_tab.data(), K);
+    for (size_t e = form == 0 ? 1 : 0; e < n_entries; e++) {
       const int32_t* a = dev_tab.data() + (size_t)i * per + e * MSM_ENTRY_DWORDS; const int32_t* b = host_tab.data() + e * MSM_ENTRY_DWORDS;
       if (!fp_eq(fp_from_limbs(a), fp_from_limbs(b)) || !fp_eq(fp_from_limbs(a + BN_NL), fp_from_limbs(b + BN_NL)) || a[18] != 0 || a[19] != 0) bad++;
     }
   }
   *mismatches = bad;
   return BN254_OK;
+}
+int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches) {
+  if (!pvk || !mismatches || inputs < 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (pvk->host.kpts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables were not built on the device");
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  int rc = ensure_dev(pvk, *d, device, 1);
+  if (rc) return rc;
+  return compare_tables(pvk->host.msm_comb ? 0 : 1, pvk->host.kpts, d->msm, inputs, mismatches);
+}
+int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches) {
+  if (!pvk || !mismatches) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (pvk->fixed_pts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables were not built on the device");
+  PlonkDev* d;
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  int rc = plonk_ensure_dev(pvk, device, &d);
+  if (rc) return rc;
+  return compare_tables(1, pvk->fixed_pts, d->fixed_tabs, (int)(pvk->fixed_pts.size() / (2 * BN_NL)), mismatches);
 }
 // host-only probe of the comb tables of keys with many public inputs: x * P from build_comb_table(P) and the column digits the kernels use
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]) {

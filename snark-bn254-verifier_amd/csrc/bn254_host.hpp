@@ -161,13 +161,18 @@ struct G16Prepared {
   std::vector<int32_t> target;           // 108
   std::vector<int32_t> msm;              // (n_k - 1) * 32 * 255 * MSM_ENTRY_DWORDS; keys with many inputs (msm_comb): (n_k - 1) * (1 << G16_COMB_TEETH) = 8192 entries of MSM_ENTRY_DWORDS each
   bool msm_comb = false;                 // the table is in comb form (build_comb_table): read by k_g16_msm_partial_comb only
-  std::vector<int32_t> kpts;             // comb form built on the device (bn254_k_comb.hip; the default): K[1 ..] as affine digits, 18 dwords each -- `msm` then stays empty on the host
+  std::vector<int32_t> kpts;             // tables built on the device (bn254_k_comb.hip; the default): K[1 ..] as affine digits, 18 dwords each -- `msm` then stays empty on the host
   G1Aff alpha, k0_pt; G2Aff b_arg;       // kept for the RLC tables (prepare_g16_rlc): alpha, K[0] and the G2 argument of the target pairing
 };
 inline void put_fp2(int32_t* o, const Fp2& a) { fp_to_limbs(o, a.c0); fp_to_limbs(o + BN_NL, a.c1); }
 inline void put_fp12(int32_t* o, const Fp12& a) {  // w-power (k) order, as the workspace stores Fp12 values (bn254_vm.h)
   put_fp2(o, K0(a)); put_fp2(o + 2 * BN_NL, K1(a)); put_fp2(o + 4 * BN_NL, K2(a));
   put_fp2(o + 6 * BN_NL, K3(a)); put_fp2(o + 8 * BN_NL, K4(a)); put_fp2(o + 10 * BN_NL, K5(a));
+}
+// the fixed-base tables are built on the host (and uploaded) instead of on the device: the construction of rounds 1-4, kept for comparison
+inline bool bn254_tables_on_host() {
+  static const bool v = [] { const char* a = getenv("BN254_TABLES_HOST"); const char* b = getenv("BN254_COMB_HOST"); return (a && atoi(a) != 0) || (b && atoi(b) != 0); }();
+  return v;
 }
 // batch conversion of projective points to affine with one inversion (Montgomery's trick); none may be the identity
 inline void g1_batch_to_affine(G1Aff* out, const G1Proj* in, size_t n) {
@@ -264,10 +269,9 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
   const char* ce = getenv("BN254_WIDE_COMB");
   out.msm_comb = nb > (size_t)G16_WIDE_MSM_MIN_INPUTS && !(ce && atoi(ce) == 0);
   const size_t per_base = (out.msm_comb ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 255) * MSM_ENTRY_DWORDS;
-  // comb tables are built on the device that uses them (bn254_k_comb.hip: a few milliseconds instead of 2.2 s of host threads and a 671 MB upload for 1024 inputs);
-  // BN254_COMB_HOST=1 keeps the host construction (the tests compare the two)
-  const char* he = getenv("BN254_COMB_HOST");
-  if (out.msm_comb && !(he && atoi(he) != 0)) {
+  // the tables are built on the device that uses them (bn254_k_comb.hip: milliseconds instead of 2.2 s of host threads and a 671 MB upload for 1024 inputs, 0.18 s for 16);
+  // BN254_TABLES_HOST=1 (or its round-5 name BN254_COMB_HOST=1) keeps the host construction
+  if (nb > 0 && !bn254_tables_on_host()) {
     out.kpts.resize(nb * 2 * BN_NL);
     for (size_t i = 0; i < nb; i++) { fp_to_limbs(out.kpts.data() + i * 2 * BN_NL, vk.k[i + 1].x); fp_to_limbs(out.kpts.data() + i * 2 * BN_NL + BN_NL, vk.k[i + 1].y); }
     return true;

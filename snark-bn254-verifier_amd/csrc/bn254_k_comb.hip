@@ -1,107 +1,132 @@
-// bn254_k_comb.hip -- the comb tables of a key with many public inputs (BASELINE configs[4]: 1024 inputs), built ON THE DEVICE that will use them.
-//   Until round 5 the host built them (bn254_host.hpp::build_comb_table: 8191 additions and a batch inversion per input, 2.2 s on 16 threads for 1024 inputs) and every
-//   device got a 671 MB copy.  The work is 8.4 M independent point additions: here it is three kinds of launches, a few milliseconds, and the host keeps 72 bytes per input.
-//   Table of input i (groth16/verify.rs:53-63 multiplies K[i + 1] by a 256-bit scalar x): entry[idx] = sum over the set bits t of idx of 2^(20 t) K[i + 1], idx = 1 .. 8191,
-//   as an affine point of MSM_ENTRY_DWORDS dwords -- what k_g16_msm_partial_comb (bn254_kernels.hip) reads; entry 0 is never read and holds the base point.
-//   k_comb_teeth      lane = input: the 13 teeth 2^(20 t) K, each taken to affine (its own inversion: 13 per lane, the launch is latency-bound either way)
-//   k_comb_level      level t = 0 .. 12, lane = (input, offset < 2^t): entry[2^t + offset] = entry[offset] + tooth_t (projective, digit planes [27][inputs * 8192])
-//   k_comb_normalize  lane = 8 consecutive entries: one inversion for the eight (prefix products in registers), affine digits to the table
+// bn254_k_comb.hip -- the fixed-base tables of a key (the multiples of the points that enter a multi-scalar multiplication with per-proof scalars), built ON THE DEVICE that
+// will use them.  Until round 5 the host built them (bn254_host.hpp::build_comb_table / build_window_table: 8191 / 8160 additions and a batch inversion per point -- 2.2 s on 8
+// threads for a key with 1024 public inputs, 0.18 s for one with 16) and every device got a copy (671 MB for 1024 inputs).  The work is independent point additions: here it is
+// three kinds of launches, milliseconds, and the host keeps 72 bytes per point.
+//   Two table forms, both arrays of affine points of MSM_ENTRY_DWORDS dwords:
+//   comb     (keys with more than 16 public inputs; read by k_g16_msm_partial_comb): entry[idx] = sum over the set bits t of idx of 2^(20 t) P, idx = 1 .. 8191 (13 teeth 20
+//            bits apart); entry 0 is never read and holds P.  One block of 8192 entries per point.
+//   windows  (byte windows: keys with up to 16 inputs, the key points of the PlonK MSMs, read by msm_entry(tab, (point * 32 + w) * 255 + d - 1)): entry[w][d - 1] =
+//            d 2^(8 w) P, d = 1 .. 255, w = 0 .. 31.  32 blocks of 256 construction entries per point (d = 0 is a placeholder that is not written out), teeth 2^k P, k = 0 .. 255.
+//   In both forms a block's entry e is the sum over the set bits t of e of the block's tooth t, so one construction serves:
+//   k_tab_teeth       lane = point: the teeth as projective points (digit planes), `spacing` doublings apart
+//   k_tab_normalize   lane = 8 consecutive construction entries: one inversion for the eight (prefix products in registers), affine digits out -- used for the teeth (18 dwords
+//                     each) and, last, for the table itself
+//   k_tab_level       level t, lane = (block, offset < 2^t): entry[2^t + offset] = entry[offset] + tooth_t of the block (projective, digit planes [27][blocks * entries])
 #include <hip/hip_runtime.h>
 #include "bn254_devws.h"
 #include "bn254_kernels.h"
 
 namespace bn254 {
 
-#define COMB_ENTRIES (1u << G16_COMB_TEETH)
-#define COMB_GROUP 8
+#define TAB_GROUP 8
 
-__device__ __forceinline__ G1Aff comb_ld_aff(const int32_t* __restrict__ p) {
+__device__ __forceinline__ G1Aff tab_ld_aff(const int32_t* __restrict__ p) {
   G1Aff a;
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { a.x.v[l] = p[l]; a.y.v[l] = p[BN_NL + l]; }
   BN_SETB(a.x, 1.01, 0.5); BN_SETB(a.y, 1.01, 0.5);
   return a;
 }
-__device__ __forceinline__ void comb_st_aff(int32_t* p, const G1Aff& a) {
+__device__ __forceinline__ void tab_st_aff(int32_t* p, const G1Aff& a) {     // the digits bn254_host.hpp::fp_to_limbs writes
   const Fp x = fp_reduce(fp_norm(a.x)), y = fp_reduce(fp_norm(a.y));
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { p[l] = x.v[l]; p[BN_NL + l] = y.v[l]; }
 }
-// projective points of the construction: digit plane l of coordinate c at plane[(c * 9 + l) * total + e] -- consecutive lanes, consecutive entries
-__device__ __forceinline__ G1Proj comb_ld_proj(const int32_t* __restrict__ plane, size_t total, size_t e) {
+// projective points of the construction: digit l of coordinate c at plane[(c * 9 + l) * total + e] -- consecutive lanes, consecutive entries
+__device__ __forceinline__ G1Proj tab_ld_proj(const int32_t* __restrict__ plane, size_t total, size_t e) {
   G1Proj p;
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { p.x.v[l] = plane[(size_t)l * total + e]; p.y.v[l] = plane[(size_t)(BN_NL + l) * total + e]; p.z.v[l] = plane[(size_t)(2 * BN_NL + l) * total + e]; }
   BN_SETB(p.x, 1.01, 0.5); BN_SETB(p.y, 1.01, 0.5); BN_SETB(p.z, 1.01, 0.5);
   return p;
 }
-__device__ __forceinline__ void comb_st_proj(int32_t* plane, size_t total, size_t e, const G1Proj& p) {
+__device__ __forceinline__ void tab_st_proj(int32_t* plane, size_t total, size_t e, const G1Proj& p) {
   const Fp x = fp_reduce(p.x), y = fp_reduce(p.y), z = fp_reduce(p.z);
 #pragma unroll
   for (int l = 0; l < BN_NL; l++) { plane[(size_t)l * total + e] = x.v[l]; plane[(size_t)(BN_NL + l) * total + e] = y.v[l]; plane[(size_t)(2 * BN_NL + l) * total + e] = z.v[l]; }
 }
 
-__global__ void __launch_bounds__(64) k_comb_teeth(const int32_t* __restrict__ kpts, uint32_t nb, int32_t* __restrict__ teeth) {
+// teeth of point i: tooth k = 2^(spacing k) P_i, k < teeth, at construction index i * teeth + k of `plane` (total = points * teeth)
+__global__ void __launch_bounds__(64) k_tab_teeth(const int32_t* __restrict__ pts, uint32_t points, int teeth, int spacing, int32_t* __restrict__ plane) {
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  if (i >= nb) return;
-  G1Proj t = g1_from_affine(comb_ld_aff(kpts + (size_t)i * 2 * BN_NL));
-  for (int k = 0; k < G16_COMB_TEETH; k++) {
-    comb_st_aff(teeth + ((size_t)i * G16_COMB_TEETH + k) * 2 * BN_NL, g1_to_affine(t));
-    for (int d = 0; d < G16_COMB_COLS; d++) t = g1_dbl(t);
+  if (i >= points) return;
+  const size_t total = (size_t)points * (size_t)teeth;
+  G1Proj t = g1_from_affine(tab_ld_aff(pts + (size_t)i * 2 * BN_NL));
+  for (int k = 0; k < teeth; k++) {
+    tab_st_proj(plane, total, (size_t)i * teeth + k, t);
+    if (k + 1 < teeth) for (int d = 0; d < spacing; d++) t = g1_dbl(t);
   }
 }
-__global__ void __launch_bounds__(256) k_comb_level(const int32_t* __restrict__ teeth, int32_t* __restrict__ plane, uint32_t nb, int level) {
+// level t of every block: entry[2^t + off] = entry[off] + tooth (off = 0: the tooth itself); teeth_aff: 18 dwords per tooth, tooth `level` of block b at b * teeth_per_block + level
+__global__ void __launch_bounds__(256) k_tab_level(const int32_t* __restrict__ teeth_aff, int32_t* __restrict__ plane, size_t blocks, int log2_entries, int teeth_per_block, int level) {
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t per = (size_t)1 << level;
-  if (g >= (size_t)nb * per) return;
-  const size_t i = g >> level, off = g & (per - 1), total = (size_t)nb * COMB_ENTRIES;
-  const G1Aff tooth = comb_ld_aff(teeth + (i * G16_COMB_TEETH + level) * 2 * BN_NL);
+  if (g >= blocks * per) return;
+  const size_t b = g >> level, off = g & (per - 1), total = blocks << log2_entries, base = b << log2_entries;
+  const G1Aff tooth = tab_ld_aff(teeth_aff + (b * (size_t)teeth_per_block + level) * 2 * BN_NL);
   G1Proj r = g1_from_affine(tooth);
-  if (off != 0) r = g1_add_mixed(comb_ld_proj(plane, total, i * COMB_ENTRIES + off), tooth);
-  comb_st_proj(plane, total, i * COMB_ENTRIES + per + off, r);
-  if (level == 0) comb_st_proj(plane, total, i * COMB_ENTRIES, r);        // entry 0 (never read): a finite point, so that the shared inversion below stays non-zero
+  if (off != 0) r = g1_add_mixed(tab_ld_proj(plane, total, base + off), tooth);
+  tab_st_proj(plane, total, base + per + off, r);
+  if (level == 0) tab_st_proj(plane, total, base, r);                    // entry 0 of the block (never read): a finite point, so that the shared inversion below stays non-zero
 }
-__global__ void __launch_bounds__(256) k_comb_normalize(const int32_t* __restrict__ plane, size_t total, int32_t* __restrict__ out) {
+// construction entries e = 8 g .. 8 g + 7 to affine.  out_stride: dwords per output entry (2 x 9 digits, the rest zero).  skip_zero = 0: entry e goes to out[e]; skip_zero = 1
+// (byte windows): entry d of block b goes to out[b * (entries - 1) + d - 1], d = 0 is not written.
+__global__ void __launch_bounds__(256) k_tab_normalize(const int32_t* __restrict__ plane, size_t total, int32_t* __restrict__ out, int out_stride, int log2_entries, int skip_zero) {
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t e0 = g * COMB_GROUP;
-  if (e0 >= total) return;                                               // total is a multiple of COMB_GROUP (8192 entries per input)
+  const size_t e0 = g * TAB_GROUP;
+  if (e0 >= total) return;
   // Montgomery's trick over the group: pre[k] = z_0 ... z_(k-1); one inversion; entry k gets inv(z_k) = inv(z_0 ... z_k) * pre[k]
-  Fp pre[COMB_GROUP];
+  Fp pre[TAB_GROUP];
   Fp acc = fp_one();
 #pragma unroll
-  for (int k = 0; k < COMB_GROUP; k++) {
-    Fp z;
+  for (int k = 0; k < TAB_GROUP; k++) {
+    Fp z = fp_one();
+    if (e0 + k < total) {
 #pragma unroll
-    for (int l = 0; l < BN_NL; l++) z.v[l] = plane[(size_t)(2 * BN_NL + l) * total + e0 + k];
-    BN_SETB(z, 1.01, 0.5);
+      for (int l = 0; l < BN_NL; l++) z.v[l] = plane[(size_t)(2 * BN_NL + l) * total + e0 + k];
+      BN_SETB(z, 1.01, 0.5);
+    }
     pre[k] = acc;
     acc = fp_mul(acc, z);
   }
   Fp inv = fp_inv(acc);
+  const size_t mask = ((size_t)1 << log2_entries) - 1;
 #pragma unroll
-  for (int k = COMB_GROUP - 1; k >= 0; k--) {
-    const G1Proj p = comb_ld_proj(plane, total, e0 + k);
+  for (int k = TAB_GROUP - 1; k >= 0; k--) {
+    if (e0 + k >= total) continue;                                         // (its z was taken as one: nothing to undo)
+    const size_t e = e0 + k;
+    const G1Proj p = tab_ld_proj(plane, total, e);
     const Fp zi = fp_mul(inv, pre[k]);
     inv = fp_mul(inv, p.z);
+    if (skip_zero && (e & mask) == 0) continue;
     G1Aff a; a.x = fp_mul(p.x, zi); a.y = fp_mul(p.y, zi);
-    int32_t* o = out + (e0 + k) * MSM_ENTRY_DWORDS;
-    comb_st_aff(o, a);
-    o[2 * BN_NL] = 0; o[2 * BN_NL + 1] = 0;
+    const size_t oe = skip_zero ? (e >> log2_entries) * mask + (e & mask) - 1 : e;
+    int32_t* o = out + oe * (size_t)out_stride;
+    tab_st_aff(o, a);
+    for (int l = 2 * BN_NL; l < out_stride; l++) o[l] = 0;
   }
 }
 
 }  // namespace bn254
 
 using namespace bn254;
-// kpts: nb affine points (18 dwords each) in device memory; table: nb * 8192 * MSM_ENTRY_DWORDS dwords; scratch_teeth: nb * 13 * 18 dwords; scratch_plane: 27 * nb * 8192 dwords
-hipError_t bn254_launch_comb_build(const int32_t* kpts, uint32_t nb, int32_t* table, int32_t* scratch_teeth, int32_t* scratch_plane, hipStream_t s) {
-  if (nb == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_comb_teeth, dim3((nb + 63) / 64), dim3(64), 0, s, kpts, nb, scratch_teeth);
-  for (int level = 0; level < G16_COMB_TEETH; level++) {
-    const size_t lanes = (size_t)nb << level;
-    hipLaunchKernelGGL(k_comb_level, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, (const int32_t*)scratch_teeth, scratch_plane, nb, level);
+// pts: `points` affine points (18 dwords each) in device memory.  form 0: comb tables, points * 8192 entries; form 1: byte-window tables, points * 32 * 255 entries (both of
+// MSM_ENTRY_DWORDS dwords).  Scratch: teeth_plane = 27 * points * T dwords, teeth_aff = 18 * points * T dwords (T = 13 | 256), plane = 27 * points * E dwords (E = 8192 | 32 * 256).
+size_t bn254_tab_build_teeth(int form) { return form == 0 ? (size_t)G16_COMB_TEETH : 256; }
+size_t bn254_tab_build_entries(int form) { return form == 0 ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 256; }
+hipError_t bn254_launch_tab_build(int form, const int32_t* pts, uint32_t points, int32_t* table, int32_t* teeth_plane, int32_t* teeth_aff, int32_t* plane, hipStream_t s) {
+  if (points == 0) return hipSuccess;
+  const int teeth = (int)bn254_tab_build_teeth(form), spacing = form == 0 ? G16_COMB_COLS : 1;
+  const int log2_entries = form == 0 ? G16_COMB_TEETH : 8, teeth_per_block = form == 0 ? G16_COMB_TEETH : 8;
+  const size_t blocks = form == 0 ? (size_t)points : (size_t)points * 32;
+  hipLaunchKernelGGL(k_tab_teeth, dim3((points + 63) / 64), dim3(64), 0, s, pts, points, teeth, spacing, teeth_plane);
+  const size_t n_teeth = (size_t)points * teeth;
+  hipLaunchKernelGGL(k_tab_normalize, dim3((unsigned)(((n_teeth + TAB_GROUP - 1) / TAB_GROUP + 255) / 256)), dim3(256), 0, s, (const int32_t*)teeth_plane, n_teeth, teeth_aff, 2 * BN_NL, 0, 0);
+  for (int level = 0; level < log2_entries; level++) {
+    const size_t lanes = blocks << level;
+    hipLaunchKernelGGL(k_tab_level, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, (const int32_t*)teeth_aff, plane, blocks, log2_entries, teeth_per_block, level);
   }
-  const size_t total = (size_t)nb * COMB_ENTRIES, groups = total / COMB_GROUP;
-  hipLaunchKernelGGL(k_comb_normalize, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const int32_t*)scratch_plane, total, table);
+  const size_t total = blocks << log2_entries;
+  hipLaunchKernelGGL(k_tab_normalize, dim3((unsigned)((total / TAB_GROUP + 255) / 256)), dim3(256), 0, s, (const int32_t*)plane, total, table, (int)MSM_ENTRY_DWORDS, log2_entries, form == 0 ? 0 : 1);
   return hipGetLastError();
 }

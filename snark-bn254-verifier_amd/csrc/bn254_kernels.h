@@ -97,9 +97,12 @@ void bn254_launch_miller_run(const MillerKinds& kinds, int s_begin, int s_end, i
 // the same for two table-driven pairs and no variable pair (bn254_vm.h::vm_miller_run_fixed2)
 void bn254_launch_miller_run_fixed2(const MillerKinds& kinds, int s_begin, int s_end, int32_t* ws, uint32_t n, const uint8_t* status, unsigned grid, hipStream_t s, int e,
                                     const int32_t* tab0, int ep0, int inf0, const int32_t* tab1, int ep1, int inf1);
-// comb tables of a key with many public inputs, built on the device (bn254_k_comb.hip): kpts = nb affine points (18 dwords each, device memory), table = nb * 8192 entries of
-// MSM_ENTRY_DWORDS, scratch_teeth = nb * G16_COMB_TEETH * 18 dwords, scratch_plane = 27 * nb * 8192 dwords
-hipError_t bn254_launch_comb_build(const int32_t* kpts, uint32_t nb, int32_t* table, int32_t* scratch_teeth, int32_t* scratch_plane, hipStream_t s);
+// fixed-base tables of a key built on the device (bn254_k_comb.hip).  form 0: comb tables (points * 8192 entries), 1: byte-window tables (points * 32 * 255 entries), both of
+// MSM_ENTRY_DWORDS dwords; pts = `points` affine points (18 dwords each, device memory); scratch: teeth_plane = 27 * points * teeth dwords, teeth_aff = 18 * points * teeth
+// dwords, plane = 27 * points * entries dwords (bn254_tab_build_teeth / _entries: 13 / 8192 and 256 / 8192)
+size_t bn254_tab_build_teeth(int form);
+size_t bn254_tab_build_entries(int form);
+hipError_t bn254_launch_tab_build(int form, const int32_t* pts, uint32_t points, int32_t* table, int32_t* teeth_plane, int32_t* teeth_aff, int32_t* plane, hipStream_t s);
 // RLC batch mode (bn254_rlc.h): one launch part = n <= G16_MAX_LAUNCH proofs forming plan.groups groups
 #include "bn254_rlc_plan.h"
 struct RlcLaunchArgs {

@@ -146,18 +146,24 @@ def test_plonk_self_test_guards_the_device_stages(pkg, fixtures):
     assert pkg.lib().bn254_abi_version() == 5
 
 
-def test_comb_tables_built_on_device_match_the_host_construction(pkg):
-    """Keys with more than 16 public inputs: the comb tables (8192 entries per input) are built by the device that uses them (csrc/bn254_k_comb.hip) from the key's K points;
-    the host keeps no copy.  Entry by entry, as field values, they must be what bn254_host.hpp::build_comb_table makes -- for a 17-input key (the smallest comb key: every
-    input checked) and a 300-input key (two construction passes); the statuses of batches on such keys against the oracle are the wide-key tests of the suite."""
+def test_tables_built_on_device_match_the_host_construction(pkg, fixtures):
+    """The fixed-base tables of a key -- byte windows (32 x 255 entries per point) for keys with up to 16 public inputs and for the points of a PlonK key, comb tables (8192
+    entries per point) above 16 inputs -- are built by the device that uses them (csrc/bn254_k_comb.hip) from the key's points; the host keeps no copy.  Entry by entry, as field
+    values, they must be what bn254_host.hpp::build_window_table / build_comb_table make: a 2-input and a 16-input key, a 17-input key (the smallest comb key), a 300-input
+    key (two construction passes), the reference's PlonK key (all its table points).  The statuses of batches on such keys against the oracle are the rest of the suite."""
     L = pkg.lib()
     L.bn254_dbg_comb_table_compare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
-    for n_public, check in ((17, 17), (300, 300)):          # 300 inputs: two construction passes (256 + 44)
+    L.bn254_dbg_plonk_table_compare.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    for n_public in (2, 16, 17, 300):
         vk = pkg.synth_groth16(0xC0B0 + n_public, n_public, 1, invalid_every=0, agree=True, threads=4)[0]
         pvk = pkg.PreparedVk(vk)
         bad = C.c_size_t(12345)
-        assert L.bn254_dbg_comb_table_compare(pvk._h, 0, check, C.byref(bad)) == 0, L.bn254_last_error()
+        assert L.bn254_dbg_comb_table_compare(pvk._h, 0, n_public, C.byref(bad)) == 0, L.bn254_last_error()
         assert bad.value == 0, (n_public, bad.value)
+    ppvk = pkg.PreparedPlonkVk(fixtures[1])
+    bad = C.c_size_t(12345)
+    assert L.bn254_dbg_plonk_table_compare(ppvk._h, 0, C.byref(bad)) == 0, L.bn254_last_error()
+    assert bad.value == 0, bad.value
 
 
 def test_bench_plonk_mode_prints_the_contract_line():

@@ -13,7 +13,7 @@ torch.zeros(1, device="cuda:0"); torch.cuda.synchronize()
 n, npub = 4096, 1024
 t = time.perf_counter(); vk, proofs, inputs, exp = pkg.synth_groth16(0xB2540004, npub, n, invalid_every=16, agree=True, threads=16); gen = time.perf_counter() - t
 for mode in ("device", "host"):
-    if mode == "host": os.environ["BN254_COMB_HOST"] = "1"
+    if mode == "host": os.environ["BN254_TABLES_HOST"] = "1"
     t = time.perf_counter(); pvk = pkg.PreparedVk(vk); prep = time.perf_counter() - t
     t = time.perf_counter(); pvk.reserve(n, 0); torch.cuda.synchronize(); first = time.perf_counter() - t
     t = time.perf_counter(); st = pvk.verify_batch(proofs, inputs, n_public=npub) if hasattr(pvk, "verify_batch") else None; dt = time.perf_counter() - t
