@@ -151,6 +151,8 @@ def test_tables_built_on_device_match_the_host_construction(pkg, fixtures):
     entries per point) above 16 inputs -- are built by the device that uses them (csrc/bn254_k_comb.hip) from the key's points; the host keeps no copy.  Entry by entry, as field
     values, they must be what bn254_host.hpp::build_window_table / build_comb_table make: a 2-input and a 16-input key, a 17-input key (the smallest comb key), a 300-input
     key (two construction passes), the reference's PlonK key (all its table points).  The statuses of batches on such keys against the oracle are the rest of the suite."""
+    if os.environ.get("BN254_TABLES_HOST", "0") != "0" or os.environ.get("BN254_COMB_HOST", "0") != "0":
+        pytest.skip("the host construction is in use (tools/gpu_variants.sh runs the suite this way): nothing was built on the device")
     L = pkg.lib()
     L.bn254_dbg_comb_table_compare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     L.bn254_dbg_plonk_table_compare.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]

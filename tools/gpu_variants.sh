@@ -20,6 +20,7 @@ run msm_budget_small BN254_MSM_LANE_BUDGET=4096
 run msm_budget_large BN254_MSM_LANE_BUDGET=1048576
 run coop_fixed_off BN254_COOP_FIXED_MAX=0
 run plonk_host BN254_PLONK_HOST=1
+run tables_host BN254_TABLES_HOST=1
 fi
 if [ -z "$ONLY_LIBS" ]; then
 run rlc_g3s1 BN254_RLC_GROUP_LOG2=3 BN254_RLC_SHARE_LOG2=1 BN254_RLC_SHARE_MIN_LANES=1
