@@ -173,6 +173,8 @@ def test_bench_plonk_mode_prints_the_contract_line():
     metric name, a roofline and a CPU baseline; its own checks (every status byte against the workload, the first 16 against the oracle, the gathered vector) have passed
     when it prints."""
     import json, subprocess, sys
+    if os.environ.get("BN254_PLONK_HOST") == "1":
+        pytest.skip("the diagnostic host-thread stages refuse the device-resident entry the bench times")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--plonk", "--batch-log2", "12", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
