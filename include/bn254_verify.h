@@ -141,7 +141,7 @@ int bn254_groth16_reserve(const bn254_g16_pvk* pvk, size_t n, int device);
 
 /* Groth16Verifier::verify (lib.rs:44-49) as one call: one proof, one status byte, vk given as bytes on every call like the
  * reference.  The prepared form of the last four keys (exact byte match, per mode) is kept, so only the first call with a key pays
- * its preparation (5 ms of a 7 ms call; 2 ms afterwards); BN254_KEY_CACHE=0 in the environment switches the cache off, BN254_KEY_CACHE=N (1 .. 64) keeps the last N keys (default 4).
+ * its preparation (about 6.5 ms of an 8.5 ms call; 2 ms afterwards: profiles/r05_new_key_cost.txt); BN254_KEY_CACHE=0 in the environment switches the cache off, BN254_KEY_CACHE=N (1 .. 64) keeps the last N keys (default 4).
  * bn254_plonk_verify does the same.  Runs on the GPU (device 0). */
 int bn254_groth16_verify(const uint8_t* proof, size_t proof_len, const uint8_t* vk, size_t vk_len,
                          const uint8_t* public_inputs, size_t n_public, unsigned mode, uint8_t* status);
