@@ -766,7 +766,9 @@ static int rlc_ensure(const bn254_g16_pvk* pvk, DevState* d, size_t n, size_t n_
       if (!pvk->rlc_host.ready && !prepare_g16_rlc(pvk->rlc_host, pvk->host)) return set_err(BN254_E_VK, "degenerate key element (RLC tables)");
     }
     int rc;
-    if ((rc = upload(&r.btab, pvk->rlc_host.btab)) || (rc = upload(&r.tab, pvk->rlc_host.tab)) || (rc = upload(&r.one, pvk->rlc_host.one))) return rc;
+    if ((rc = upload(&r.btab, pvk->rlc_host.btab)) || (rc = upload(&r.one, pvk->rlc_host.one))) return rc;
+    if (!pvk->rlc_host.pts.empty() && pvk->rlc_host.tab.empty()) { if ((rc = build_tables_on_device(1, pvk->rlc_host.pts, &r.tab))) return rc; }
+    else if ((rc = upload(&r.tab, pvk->rlc_host.tab))) return rc;
     r.ready = true;
   }
   if (n > r.grp_cap) {
