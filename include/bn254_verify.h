@@ -341,7 +341,7 @@ int bn254_dbg_key_cache_slots(void);
 /* the fixed-base tables `device` built for a key (csrc/bn254_k_comb.hip: comb tables for more than 16 public inputs, byte windows otherwise) against the host construction: the tables of the first `inputs` inputs read back
  * and compared entry by entry as field values; *mismatches = entries that differ */
 int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches);
-int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches);   /* the same for the byte-window tables of a PlonK key's points (all of them) */
+int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches);   /* the window tables of a PlonK key's points (csrc/bn254_fw.h): every window's first, middle and last entries and a pseudo-random sample */
 
 /* Revision of this header's binary interface: bumped whenever a function changes its arguments, an array argument its length or a slot its meaning (5: this round --
  * BN254_PLONK_NUM_TIMINGS has been 9 since revision 4, bn254_dbg_plonk_msm_plan writes 9 ints per row).  A binding compares it with the value it was generated for. */

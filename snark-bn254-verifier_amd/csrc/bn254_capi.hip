@@ -159,9 +159,10 @@ template <typename T> static int upload(T** dst, const std::vector<T>& src) {
 static int build_tables_on_device(int form, const std::vector<int32_t>& pts, int32_t** dst) {
   if (*dst) return BN254_OK;
   const size_t np = pts.size() / (2 * BN_NL);
-  const size_t per_point = (form == 0 ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 255) * MSM_ENTRY_DWORDS;   // dwords of finished table per point
+  const size_t per_point = bn254_tab_build_out_entries(form) * MSM_ENTRY_DWORDS;   // dwords of finished table per point
   const size_t teeth = bn254_tab_build_teeth(form), entries = bn254_tab_build_entries(form);
-  const size_t slice = np < 256 ? np : 256;
+  const size_t slice_cap = ((size_t)256 << 13) / entries ? ((size_t)256 << 13) / entries : 1;   // points per pass: 2 M construction entries (226 MB of scratch) at most
+  const size_t slice = np < slice_cap ? np : slice_cap;
   int32_t *kp = nullptr, *tab = nullptr, *tplane = nullptr, *taff = nullptr, *plane = nullptr;
   auto drop = [&]() { if (kp) (void)hipFree(kp); if (tplane) (void)hipFree(tplane); if (taff) (void)hipFree(taff); if (plane) (void)hipFree(plane); };
   hipError_t e;
@@ -291,7 +292,7 @@ struct PlonkCtx {
 struct PlonkDev {
   bool ready = false;
   int32_t *tab0 = nullptr, *tab1 = nullptr, *one = nullptr;
-  int32_t* fixed_tabs = nullptr;       // byte-window tables of the key's G1 points (plonk_num_tables x 32 x 255 entries)
+  int32_t* fixed_tabs = nullptr;       // window tables of the key's G1 points (plonk_num_tables x MSM_FW_WINDOWS x MSM_FW_ENTRIES entries, bn254_fw.h)
   void* d_key = nullptr;               // the parsed key (PlonkKey) for the device-side stages
   PlonkCtx ctx[PLONK_WORKERS];
   // The contexts are handed out to calls: a call takes one per sub-batch (all at once, so two calls cannot wait for each other) and returns them when it
@@ -322,8 +323,8 @@ struct PlonkLease {   // the contexts of one call
 struct bn254_plonk_pvk {
   PlonkKey key;
   std::vector<int32_t> tab0, tab1, one;
-  std::vector<int32_t> fixed_tabs;     // bn254_host.hpp::build_window_table of every key point that enters an MSM (bn254_plonk.hpp::plonk_table_point) -- BN254_TABLES_HOST=1 only
-  std::vector<int32_t> fixed_pts;      // those points as affine digits (18 dwords each): the tables are built on the device that uses them (bn254_k_comb.hip)
+  std::vector<int32_t> fixed_pts;      // every key point that enters an MSM (bn254_plonk.hpp::plonk_table_point) as affine digits, 18 dwords each: their window tables
+                                       // (MSM_FW_BITS, bn254_fw.h) are built on the device that uses them (bn254_k_comb.hip form 2)
   MsmShape shape1, shape2, shape2_rlc; // term kinds of the two MSM launches (plonk_msm1_shape / plonk_msm2_shape; _rlc: the weighted form of BN254_FLAG_RLC)
   mutable std::mutex mu;               // protects the map below (lookup / insertion / first upload); batches take contexts from the device's pool
   mutable std::map<int, PlonkDev> dev;
@@ -352,8 +353,7 @@ static int plonk_ensure_dev(const bn254_plonk_pvk* pvk, int device, PlonkDev** o
   PlonkDev& d = pvk->dev[device];
   if (!d.ready) {
     if ((rc = upload(&d.tab0, pvk->tab0)) || (rc = upload(&d.tab1, pvk->tab1)) || (rc = upload(&d.one, pvk->one))) return rc;
-    if (!pvk->fixed_pts.empty() && pvk->fixed_tabs.empty()) { if ((rc = build_tables_on_device(1, pvk->fixed_pts, &d.fixed_tabs))) return rc; }
-    else if ((rc = upload(&d.fixed_tabs, pvk->fixed_tabs))) return rc;
+    if ((rc = build_tables_on_device(2, pvk->fixed_pts, &d.fixed_tabs))) return rc;
     // the key and the field constants for the device-side stages
     if (sizeof(PlonkKey) != bn254_plonk_key_bytes()) return set_err(BN254_E_HIP, "PlonK key layout differs between the translation units");
     HIPCK(bn254_plonk_dev_init(device));
@@ -1320,20 +1320,10 @@ int bn254_plonk_vk_prepare(const uint8_t* vk, size_t vk_len, bn254_plonk_pvk** o
   // byte-window tables of the key's G1 points that enter the MSMs with per-proof scalars (plonk/verify.rs:253-284: ql, qr, qm, qo, qk, s3; plonk/kzg.rs:74-85:
   // s1, s2, qcp[]; kzg.rs:169: the KZG generator): 32 mixed additions per term instead of a 128-step double-and-add chain
   {
+    // built on the device that uses them (bn254_k_comb.hip form 2: MSM_FW_WINDOWS windows of MSM_FW_BITS bits, bn254_fw.h): the host keeps the points
     const int nt = plonk_num_tables(p->key);
-    const size_t per = (size_t)32 * 255 * MSM_ENTRY_DWORDS;
-    if (!bn254_tables_on_host()) {
-      // built on the device that uses them (bn254_k_comb.hip): the host keeps the points
-      p->fixed_pts.resize((size_t)nt * 2 * BN_NL);
-      for (int i = 0; i < nt; i++) { const G1Aff& q = plonk_table_point(p->key, i); fp_to_limbs(p->fixed_pts.data() + (size_t)i * 2 * BN_NL, q.x); fp_to_limbs(p->fixed_pts.data() + (size_t)i * 2 * BN_NL + BN_NL, q.y); }
-    } else {
-    p->fixed_tabs.assign((size_t)nt * per, 0);
-    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1; if (hw > (unsigned)nt) hw = (unsigned)nt;
-    std::vector<std::thread> th;
-    for (unsigned t_ = 0; t_ < hw; t_++)
-      th.emplace_back([&, t_]() { for (int i = (int)t_; i < nt; i += (int)hw) build_window_table(p->fixed_tabs.data() + (size_t)i * per, plonk_table_point(p->key, i)); });
-    for (auto& x : th) x.join();
-    }
+    p->fixed_pts.resize((size_t)nt * 2 * BN_NL);
+    for (int i = 0; i < nt; i++) { const G1Aff& q = plonk_table_point(p->key, i); fp_to_limbs(p->fixed_pts.data() + (size_t)i * 2 * BN_NL, q.x); fp_to_limbs(p->fixed_pts.data() + (size_t)i * 2 * BN_NL + BN_NL, q.y); }
   }
   plonk_msm1_shape(p->key, p->shape1); plonk_msm2_shape(p->key, p->shape2); plonk_msm2_shape(p->key, p->shape2_rlc, true);
   *out = p;
@@ -2062,12 +2052,33 @@ int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int input
 }
 int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches) {
   if (!pvk || !mismatches) return set_err(BN254_E_BAD_ARG, "bad argument");
-  if (pvk->fixed_pts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables were not built on the device");
   PlonkDev* d;
   std::lock_guard<std::mutex> lk(pvk->mu);
   int rc = plonk_ensure_dev(pvk, device, &d);
   if (rc) return rc;
-  return compare_tables(1, pvk->fixed_pts, d->fixed_tabs, (int)(pvk->fixed_pts.size() / (2 * BN_NL)), mismatches);
+  // MSM_FW_WINDOWS x (2^MSM_FW_BITS - 1) entries per point: every window's first, middle and last entries and a pseudo-random sample, each against d 2^(bits w) P by double-and-add
+  const size_t np = pvk->fixed_pts.size() / (2 * BN_NL), per = (size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES;
+  size_t bad = 0;
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  std::vector<int32_t> e(MSM_ENTRY_DWORDS);
+  for (size_t i = 0; i < np; i++) {
+    G1Aff P; P.x = fp_from_limbs(pvk->fixed_pts.data() + i * 2 * BN_NL); P.y = fp_from_limbs(pvk->fixed_pts.data() + i * 2 * BN_NL + BN_NL);
+    G1Proj bw = g1_from_affine(P);
+    for (int w = 0; w < MSM_FW_WINDOWS; w++) {
+      std::vector<uint32_t> ds = {1, 2, 3, 255 % MSM_FW_ENTRIES + 1, 256 % MSM_FW_ENTRIES + 1, (MSM_FW_ENTRIES >> 1), (MSM_FW_ENTRIES >> 1) + 1, MSM_FW_ENTRIES - 1, MSM_FW_ENTRIES};
+      for (int k = 0; k < 14; k++) { x ^= x >> 12; x ^= x << 25; x ^= x >> 27; ds.push_back(1 + (uint32_t)((x * 0x2545F4914F6CDD1Dull) >> 40) % MSM_FW_ENTRIES); }
+      for (uint32_t dd : ds) {
+        HIPCK(hipMemcpy(e.data(), d->fixed_tabs + (i * per + (size_t)w * MSM_FW_ENTRIES + dd - 1) * MSM_ENTRY_DWORDS, MSM_ENTRY_DWORDS * sizeof(int32_t), hipMemcpyDeviceToHost));
+        G1Proj acc = g1_identity();
+        for (int bit = MSM_FW_BITS - 1; bit >= 0; bit--) { acc = g1_dbl(acc); if ((dd >> bit) & 1) acc = g1_add(acc, bw); }
+        const G1Aff want = g1_to_affine(acc);
+        if (!fp_eq(fp_from_limbs(e.data()), want.x) || !fp_eq(fp_from_limbs(e.data() + BN_NL), want.y) || e[18] != 0 || e[19] != 0) bad++;
+      }
+      for (int b = 0; b < MSM_FW_BITS; b++) bw = g1_dbl(bw);
+    }
+  }
+  *mismatches = bad;
+  return BN254_OK;
 }
 // host-only probe of the comb tables of keys with many public inputs: x * P from build_comb_table(P) and the column digits the kernels use
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]) {

@@ -110,15 +110,18 @@ __global__ void __launch_bounds__(256) k_tab_normalize(const int32_t* __restrict
 }  // namespace bn254
 
 using namespace bn254;
-// pts: `points` affine points (18 dwords each) in device memory.  form 0: comb tables, points * 8192 entries; form 1: byte-window tables, points * 32 * 255 entries (both of
-// MSM_ENTRY_DWORDS dwords).  Scratch: teeth_plane = 27 * points * T dwords, teeth_aff = 18 * points * T dwords (T = 13 | 256), plane = 27 * points * E dwords (E = 8192 | 32 * 256).
-size_t bn254_tab_build_teeth(int form) { return form == 0 ? (size_t)G16_COMB_TEETH : 256; }
-size_t bn254_tab_build_entries(int form) { return form == 0 ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 256; }
+// pts: `points` affine points (18 dwords each) in device memory.  form 0: comb tables, points * 8192 entries; form 1: byte-window tables, points * 32 * 255 entries; form 2:
+// MSM_FW_BITS-bit-window tables, points * MSM_FW_WINDOWS * (2^bits - 1) entries (all of MSM_ENTRY_DWORDS dwords).  Scratch: teeth_plane = 27 * points * T dwords, teeth_aff = 18 * points * T dwords (T = 13 | 256), plane = 27 * points * E dwords (E = 8192 | 32 * 256).
+// form 2: MSM_FW_BITS-bit windows (the key points of the PlonK MSMs, bn254_fw.h): MSM_FW_WINDOWS blocks of 2^bits construction entries per point, `bits` teeth per
+// block (tooth k = 2^k P, k < windows * bits), read by msm_entry(tab, (point * windows + w) * (2^bits - 1) + d - 1)
+size_t bn254_tab_build_teeth(int form) { return form == 0 ? (size_t)G16_COMB_TEETH : form == 1 ? 256 : (size_t)MSM_FW_WINDOWS * MSM_FW_BITS; }
+size_t bn254_tab_build_entries(int form) { return form == 0 ? ((size_t)1 << G16_COMB_TEETH) : form == 1 ? (size_t)32 * 256 : (size_t)MSM_FW_WINDOWS << MSM_FW_BITS; }
+size_t bn254_tab_build_out_entries(int form) { return form == 0 ? ((size_t)1 << G16_COMB_TEETH) : form == 1 ? (size_t)32 * 255 : (size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES; }
 hipError_t bn254_launch_tab_build(int form, const int32_t* pts, uint32_t points, int32_t* table, int32_t* teeth_plane, int32_t* teeth_aff, int32_t* plane, hipStream_t s) {
   if (points == 0) return hipSuccess;
   const int teeth = (int)bn254_tab_build_teeth(form), spacing = form == 0 ? G16_COMB_COLS : 1;
-  const int log2_entries = form == 0 ? G16_COMB_TEETH : 8, teeth_per_block = form == 0 ? G16_COMB_TEETH : 8;
-  const size_t blocks = form == 0 ? (size_t)points : (size_t)points * 32;
+  const int log2_entries = form == 0 ? G16_COMB_TEETH : form == 1 ? 8 : MSM_FW_BITS, teeth_per_block = log2_entries;
+  const size_t blocks = form == 0 ? (size_t)points : (size_t)points * (form == 1 ? 32 : MSM_FW_WINDOWS);
   hipLaunchKernelGGL(k_tab_teeth, dim3((points + 63) / 64), dim3(64), 0, s, pts, points, teeth, spacing, teeth_plane);
   const size_t n_teeth = (size_t)points * teeth;
   hipLaunchKernelGGL(k_tab_normalize, dim3((unsigned)(((n_teeth + TAB_GROUP - 1) / TAB_GROUP + 255) / 256)), dim3(256), 0, s, (const int32_t*)teeth_plane, n_teeth, teeth_aff, 2 * BN_NL, 0, 0);

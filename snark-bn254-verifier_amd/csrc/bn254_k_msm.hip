@@ -50,9 +50,15 @@ struct DevMsmIO {
     fl = flags_i[t];
   }
   __device__ __forceinline__ uint32_t kword(int t, int half, int w) const { return (uint32_t)terms_i[(size_t)t * MSM_TERM_DWORDS + 18 + 4 * half + w]; }
-  __device__ __forceinline__ uint32_t scalar_byte(int t, int w) const { return ((const uint8_t*)(terms_i + (size_t)t * MSM_TERM_DWORDS + 18))[w]; }
+  // digit w of the scalar (eight little-endian words): bits MSM_FW_BITS w .. MSM_FW_BITS (w + 1) - 1, zero beyond bit 255
+  __device__ __forceinline__ uint32_t scalar_digit(int t, int w) const {
+    const uint32_t* k = (const uint32_t*)(terms_i + (size_t)t * MSM_TERM_DWORDS + 18);
+    const int bit = MSM_FW_BITS * w, i = bit >> 5, sh = bit & 31;
+    const uint64_t two = (uint64_t)k[i] | ((uint64_t)(i + 1 < 8 ? k[i + 1 < 8 ? i + 1 : 7] : 0u) << 32);
+    return (uint32_t)(two >> sh) & MSM_FW_ENTRIES;
+  }
   __device__ __forceinline__ G1Aff entry(int tab, int w, uint32_t d) const {
-    return msm_entry(tabs + (size_t)tab * ((size_t)32 * 255 * MSM_ENTRY_DWORDS), (size_t)w * 255 + d);
+    return msm_entry(tabs + (size_t)tab * ((size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES * MSM_ENTRY_DWORDS), (size_t)w * MSM_FW_ENTRIES + d);
   }
 };
 

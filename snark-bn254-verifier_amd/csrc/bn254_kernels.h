@@ -18,6 +18,7 @@
 #define BN254_ST_LINF3 0x10    // internal (RLC group stage): the G1 point of the third fixed pair is the identity
 
 #define MSM_ENTRY_DWORDS 20    // affine G1 point, 2 x 9 limbs + 2 pad: 80-byte entries, 16-byte aligned
+#include "bn254_fw.h"   // MSM_FW_BITS / MSM_FW_WINDOWS / MSM_FW_ENTRIES: the window tables of the key points of the PlonK MSMs
 #define FIXED_LINE_DWORDS 54   // one precomputed Miller step of a fixed G2 argument: m, c, xi*c (3 Fp2)
 #define G16_WS_ELEMS 130       // Fp elements per proof in the workspace (bn254_vm.h: VE_COUNT)
 #define G16_WS_BYTES_PER_PROOF (G16_WS_ELEMS * 36)
@@ -102,6 +103,7 @@ void bn254_launch_miller_run_fixed2(const MillerKinds& kinds, int s_begin, int s
 // dwords, plane = 27 * points * entries dwords (bn254_tab_build_teeth / _entries: 13 / 8192 and 256 / 8192)
 size_t bn254_tab_build_teeth(int form);
 size_t bn254_tab_build_entries(int form);
+size_t bn254_tab_build_out_entries(int form);     // entries of the finished table per point: 8192 | 32 * 255 | 16 * 65535 (form 2: 16-bit windows, bn254_msm.h)
 hipError_t bn254_launch_tab_build(int form, const int32_t* pts, uint32_t points, int32_t* table, int32_t* teeth_plane, int32_t* teeth_aff, int32_t* plane, hipStream_t s);
 // RLC batch mode (bn254_rlc.h): one launch part = n <= G16_MAX_LAUNCH proofs forming plan.groups groups
 #include "bn254_rlc_plan.h"

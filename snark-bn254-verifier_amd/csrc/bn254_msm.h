@@ -7,9 +7,9 @@
 //              the high positions (the high row doubles its result a more times), which shortens the chain where a launch is latency-bound; or -- large
 //              launches, where the total work counts -- by a JOINT row that walks up to MSM_MAX_JOINT terms of a sum together (Straus): one pair of doublings
 //              per step for all of them instead of one pair per term;
-//   fixed      P_t belongs to the verifying key: a byte-window table of the point (32 x 255 multiples, bn254_host.hpp::build_window_table) turns the term
-//              into at most 32 complete mixed additions, and those additions are dealt out window by window -- to the LOW rows of the variable terms, which
-//              have time to spare while the high rows double, and to rows of their own;
+//   fixed      P_t belongs to the verifying key: a window table of the point (MSM_FW_WINDOWS = 20 windows of MSM_FW_BITS = 13 bits, 8191 multiples each, built on the
+//              device: bn254_k_comb.hip form 2; until round 5 byte windows, 32 x 255) turns the term into at most 20 complete mixed additions, and those additions are
+//              dealt out window by window -- to the LOW rows of the variable terms, which have time to spare while the high rows double, and to rows of their own;
 //   unit       k_t = +-1 (the -H of the KZG check): one mixed addition.
 // Every row produces one projective point; k_g1_sum_affine adds the rows of a sum.  All formulas are the complete ones of bn254_curve.h, so no scalar or
 // point a prover chooses reaches an exceptional case.  The plan is a pure function of (term kinds, items, lane budget): bn254_dbg_msm_plan exports it and
@@ -18,6 +18,7 @@
 #include <cstring>
 #include <utility>
 #include "bn254_rlc.h"
+#include "bn254_fw.h"
 
 namespace bn254 {
 
@@ -25,13 +26,14 @@ namespace bn254 {
 #define MSM_MAX_FIXED 16
 #define MSM_MAX_JOINT 8        // variable terms of one joint row
 #define MSM_TERM_DWORDS 26       // MsmTerm (bn254_plonk.hpp): 18 digits of the affine point, 8 scalar words
+// (window tables of the key's points: MSM_FW_BITS / MSM_FW_WINDOWS / MSM_FW_ENTRIES in bn254_fw.h)
 struct MsmRow {
   int8_t var_term;      // term whose GLV halves this row walks, or -1
   uint8_t pos_lo, pos_hi;   // joint bit positions [pos_lo, pos_hi) of the 128, both even; the row's result carries the factor 2^pos_lo
   int8_t unit_term;     // term added as +-P, or -1
   uint8_t sum;          // the sum the row belongs to
   uint8_t glv_slot;     // which of the launch's window-table scratch rows it uses (variable rows only)
-  uint16_t fw_lo, fw_hi;    // byte windows [fw_lo, fw_hi) of its sum's fixed terms, flattened: window q = byte q & 31 of fixed term q >> 5
+  uint16_t fw_lo, fw_hi;    // windows [fw_lo, fw_hi) of its sum's fixed terms, flattened: window q = digit q % MSM_FW_WINDOWS of fixed term q / MSM_FW_WINDOWS
   uint8_t n_joint;      // > 0: a JOINT row -- var_term is then the INDEX of its first term in var_list[sum], it walks n_joint consecutive ones over all 128
                         // positions with shared doublings; their window tables are the slots glv_slot .. glv_slot + n_joint - 1
   uint8_t reserved;
@@ -114,7 +116,7 @@ inline bool msm_plan_build(MsmPlan& p, const MsmShape& sh, size_t n_pad, size_t 
     p.first[s] = r;
     p.n_fixed[s] = sh.n_fixed[s];
     for (int f = 0; f < sh.n_fixed[s]; f++) { p.fixed_term[s][f] = sh.fixed_term[s][f]; p.fixed_tab[s][f] = sh.fixed_tab[s][f]; }
-    const int wf = 32 * sh.n_fixed[s], L = sh.n_var[s];
+    const int wf = MSM_FW_WINDOWS * sh.n_fixed[s], L = sh.n_var[s];
     for (int t = 0; t < L; t++) p.var_list[s][t] = sh.var_term[s][t];
     int low_each = 0, own_rows = 0, own_each = 0, a = 64;
     // joint rows: the L terms in ceil(L / joint_g) rows of sizes that differ by at most one
@@ -267,7 +269,7 @@ BN_HD G1Proj g1_mul_glv_w2(const G1Aff& P, const uint32_t* k1, bool neg1, const 
 
 // ---- one row ------------------------------------------------------------------------------------------------------------------------------------------------
 // IO supplies the item's data: term(t, P, k1, k2, flags) -- the affine point, the GLV halves and the flag byte (bit 0: the point is the identity, bits 1 / 2:
-// signs; for a unit term bit 1 is the sign) of term t; scalar_byte(t, w) -- byte w (weight 2^(8 w)) of the canonical scalar of fixed term t;
+// signs; for a unit term bit 1 is the sign) of term t; scalar_digit(t, w) -- digit w (MSM_FW_BITS bits, weight 2^(MSM_FW_BITS w)) of the canonical scalar of fixed term t;
 // entry(tab, w, d) -- multiple d + 1 of window w of key table `tab`.
 // ---- a joint row: sum_j (+-k1_j +- k2_j lambda) P_j for n_joint terms of a sum, Straus' way -- every term gets its 15-entry table (slot j of the row's scratch), then
 // 64 steps of  acc <- 4 acc + sum_j T_j[digit_j]: ONE pair of doublings per step whatever the number of terms.  The scalar words are re-read per step (io.kword:
@@ -333,14 +335,14 @@ BN_HD G1Proj msm_row_eval(const MsmPlan& plan, int r, IO& io, TAB& glv) {
   if (row.fw_lo < row.fw_hi) {
     // the next window's digit and table entry are fetched while the current addition runs
     int q = row.fw_lo;
-    uint32_t dig = io.scalar_byte(plan.fixed_term[s][q >> 5], q & 31);
-    G1Aff e = io.entry(plan.fixed_tab[s][q >> 5], q & 31, dig ? dig - 1 : 0);
+    uint32_t dig = io.scalar_digit(plan.fixed_term[s][q / MSM_FW_WINDOWS], q % MSM_FW_WINDOWS);
+    G1Aff e = io.entry(plan.fixed_tab[s][q / MSM_FW_WINDOWS], q % MSM_FW_WINDOWS, dig ? dig - 1 : 0);
     for (; q < row.fw_hi; q++) {
       uint32_t dn = 0; G1Aff en = e;
       if (q + 1 < row.fw_hi) {
         const int qn = q + 1;
-        dn = io.scalar_byte(plan.fixed_term[s][qn >> 5], qn & 31);
-        en = io.entry(plan.fixed_tab[s][qn >> 5], qn & 31, dn ? dn - 1 : 0);
+        dn = io.scalar_digit(plan.fixed_term[s][qn / MSM_FW_WINDOWS], qn % MSM_FW_WINDOWS);
+        en = io.entry(plan.fixed_tab[s][qn / MSM_FW_WINDOWS], qn % MSM_FW_WINDOWS, dn ? dn - 1 : 0);
       }
       const G1Proj c = g1_add_mixed(acc, e);
       const bool take = dig != 0;

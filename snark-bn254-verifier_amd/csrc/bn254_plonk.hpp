@@ -2,7 +2,7 @@
 // converter,proof}.rs, transcript.rs, hash_to_field.rs).
 //
 // Split of the work per proof:
-//   once per key (host)   the loader, the 80 KB byte-window tables of the key's points (plonk_table_point), the transcript prefix
+//   once per key (host)   the loader, the transcript prefix (the window tables of the key's points, plonk_table_point, are built on each device: bn254_k_comb.hip)
 //   per proof, DEVICE     everything: parsing, the Fiat-Shamir transcripts (SHA-256), BSB22 hash-to-field, the Fr arithmetic of the linearisation and the GLV
 //                         decomposition (PlonkStage1 / PlonkStage2 below, one proof per lane in csrc/bn254_k_plonk.hip), then every group operation: the two
 //                         multi-scalar multiplications as rows (bn254_msm.h, k_g1_msm_rows) and the two-pair pairing check (bn254_kernels.hip / bn254_coop12.hip)
@@ -740,7 +740,7 @@ PL_HD void put_term(MsmTerm& t, const G1Aff& p, const FrM& k, uint8_t* flag) {
   t.k[4] = (uint32_t)g.k2[0]; t.k[5] = (uint32_t)(g.k2[0] >> 32); t.k[6] = (uint32_t)g.k2[1]; t.k[7] = (uint32_t)(g.k2[1] >> 32);
   *flag = (uint8_t)((*flag & 1) | (g.neg1 ? 2 : 0) | (g.neg2 ? 4 : 0));
 }
-// a key-side (fixed-base) term: only its scalar travels, as 8 canonical words -- the byte windows of the key's table of that point (bn254_msm.h)
+// a key-side (fixed-base) term: only its scalar travels, as 8 canonical words -- its MSM_FW_BITS-bit digits index the key's window table of that point (bn254_msm.h, bn254_fw.h)
 PL_HD void put_fixed(MsmTerm& t, const FrM& k, uint8_t* flag) {
   for (int i = 0; i < 2 * BN_NL; i++) t.pt[i] = 0;
   fr_ctx().to_words(t.k, k);
@@ -764,7 +764,7 @@ struct PlonkWork {
 enum { PLONK_STAGE1_TERMS_BASE = 10 };  // + n_bsb
 PL_HD int plonk_stage1_terms(const PlonkKey& vk) { return PLONK_STAGE1_TERMS_BASE + (int)vk.n_qcp; }
 PL_HD int plonk_stage2_terms(const PlonkKey& vk) { return 10 + (int)vk.n_qcp; }   // lin_digest, lro x3, s1, s2, qcp.., z, kzg_g1, batch_h, zs_h
-// The key's points that enter the MSMs with per-proof scalars get byte-window tables at bn254_plonk_vk_prepare (bn254_host.hpp::build_window_table, 653 KB each):
+// The key's points that enter the MSMs with per-proof scalars get window tables (bn254_fw.h: 20 windows of 13 bits, 13 MB each), built on each device at the key's first use:
 // table numbers, and which terms of the two MSM launches are variable-base (proof points), fixed-base (key points) or a bare point (scalar -1).
 enum { PLONK_TAB_QL = 0, PLONK_TAB_QR, PLONK_TAB_QM, PLONK_TAB_QO, PLONK_TAB_QK, PLONK_TAB_S3, PLONK_TAB_S1, PLONK_TAB_S2, PLONK_TAB_KZG_G1, PLONK_TAB_QCP0 };
 inline int plonk_num_tables(const PlonkKey& vk) { return (int)PLONK_TAB_QCP0 + (int)vk.n_qcp; }

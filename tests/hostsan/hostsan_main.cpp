@@ -108,8 +108,9 @@ hipError_t bn254_launch_pairing2_fixed(int32_t*, uint8_t* status, size_t n, cons
   for (size_t i = 0; i < n; i++) if (status[i] & BN254_ST_PENDING) status[i] = BN254_ST_ACCEPT;
   return hipSuccess;
 }
-size_t bn254_tab_build_teeth(int form) { return form == 0 ? 13 : 256; }
-size_t bn254_tab_build_entries(int) { return 8192; }
+size_t bn254_tab_build_teeth(int form) { return form == 0 ? 13 : form == 1 ? 256 : (size_t)MSM_FW_WINDOWS * MSM_FW_BITS; }
+size_t bn254_tab_build_entries(int form) { return form == 2 ? ((size_t)MSM_FW_WINDOWS << MSM_FW_BITS) : 8192; }
+size_t bn254_tab_build_out_entries(int form) { return form == 0 ? 8192 : form == 1 ? 32 * 255 : (size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES; }
 hipError_t bn254_launch_tab_build(int, const int32_t*, uint32_t, int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t) { g_launches++; return hipSuccess; }
 double bn254_measure_valu_peak(int) { return 1.0; }
 double bn254_measure_valu_sustained(double) { return 1.0; }

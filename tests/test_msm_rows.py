@@ -82,7 +82,7 @@ def test_msm_rows_plonk_shapes_vs_oracle(hostsim, pkg, O):
     s1 = [([0, q + 6, q + 7, q + 8, q + 9], [], [(q + i, i) for i in range(6)])]
     s2 = [([0, 1, 2, 3, 6 + q, 8 + q, 9 + q], [], [(4, 6), (5, 7), (6, 9), (7 + q, 8)]), ([11 + q], [10 + q], [])]
     i1 = _run(hostsim, L, O, rng, s1, 10 + q, 4096, 65536)
-    assert i1[0] == 12 and i1[1] == 10        # five variable terms split (the planner's split point: 88), the six fixed terms on two rows of their own + a window on each low row
+    assert i1[0] == 11 and i1[1] == 10        # five variable terms split (the planner's split point), the six fixed terms (6 x 16 windows) on one row of their own + windows on the low rows
     i2 = _run(hostsim, L, O, rng, s2, 12 + q, 4096, 65536, zero_scalar_terms=(2,), identity_terms=(0,))
     assert i2[0] == 16 and i2[3] == 14 and i2[4] == 2
     i3 = _run(hostsim, L, O, rng, s2, 12 + q, 65536, 65536)
@@ -120,7 +120,7 @@ def test_msm_joint_rows_vs_oracle(hostsim, pkg, O):
     _run(hostsim, L, O, rng, [([0, 1, 2], [3], [])], 4, 65536, 65536, joint_g=3)
     _run(hostsim, L, O, rng, [([0], [], [(1, 0)]), ([2, 3], [], [])], 4, 65536, 65536, joint_g=2)
     # a split launch ignores the group size
-    assert _run(hostsim, L, O, rng, s1, 10 + q, 4096, 65536, joint_g=4)[0] == 12
+    assert _run(hostsim, L, O, rng, s1, 10 + q, 4096, 65536, joint_g=4)[0] == 11
 
 
 def _plan(L, n_qcp, stage, n, budget=0):
@@ -137,7 +137,7 @@ def _plan(L, n_qcp, stage, n, budget=0):
 
 def test_plonk_msm_plans_cover_every_term_once(pkg):
     """For every key shape (0..8 commitments), both launches and batch sizes on both sides of every form change: each variable term's 128 joint bit positions are
-    covered exactly once, each fixed term's 32 byte windows exactly once, each unit term once; rows of a sum are contiguous; the split form stays within the budget."""
+    covered exactly once, each fixed term's 20 windows (of 13 bits: bn254_fw.h MSM_FW_WINDOWS) exactly once, each unit term once; rows of a sum are contiguous; the split form stays within the budget."""
     L = pkg.lib()
     for q in range(0, 9):
         for stage in (1, 2):
@@ -179,7 +179,7 @@ def test_plonk_msm_plans_cover_every_term_once(pkg):
                     v = sorted(v)
                     assert v == [(0, 128)] or (len(v) == 2 and v[0][0] == 0 and v[0][1] == v[1][0] and v[1][1] == 128 and v[0][1] % 2 == 0 and 2 <= v[0][1] <= 126), v
                     assert (len(v) == 2) == split
-                assert [len(windows[0]), len(windows[1])] == [32 * n_fixed[0], 0]
+                assert [len(windows[0]), len(windows[1])] == [20 * n_fixed[0], 0]
                 assert units == ([] if stage == 1 else [10 + q])
                 assert slots == set(range(var))
                 first = [min(r for r, d in enumerate(desc) if d[4] == s) for s in range(2 if stage == 2 else 1)]
