@@ -94,7 +94,7 @@ typedef struct bn254_g16_pvk bn254_g16_pvk;
 /* Parse + decompress a gnark Groth16 verifying key ONCE (replaces the per-call load_groth16_verifying_key_from_bytes,
  * groth16/converter.rs:28-89, and the per-call pairing(alpha, beta), groth16/verify.rs:70): decompression, e(alpha,beta),
  * Miller-loop line tables for the two fixed G2 arguments.  Host work; no GPU needed: 3 ms for a 2-input key, 4 ms for 16 inputs, 14 ms for 1024.
- * The fixed-base tables for vk.K (byte windows, 650 KB per input; keys with more than 16 inputs: comb tables, 655 KB per input) are NOT built here: each device builds its
+ * The fixed-base tables for vk.K (13-bit windows, 13 MB per input; keys with more than 16 inputs: comb tables, 655 KB per input) are NOT built here: each device builds its
  * own copy from the key's K points on first use (bn254_groth16_reserve, or the first batch; csrc/bn254_k_comb.hip: 2 ms for 2 inputs, 17 ms for 1024), and the host keeps
  * 72 bytes per input (until round 5 the host built them: 9 ms for 2 inputs, 0.18 s for 16, 2.2 s for 1024 on 8 threads, and held the copy).  LIMIT a caller must still plan
  * for: 671 MB of DEVICE memory per 1024-input key and device (+ 226 MB of scratch during the construction); keep the handle, do not prepare per call.
@@ -338,8 +338,9 @@ int bn254_dbg_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n,
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]);
 /* prepared keys the single-proof entries keep (BN254_KEY_CACHE in the environment: unset 4, 0 off, N up to 64) */
 int bn254_dbg_key_cache_slots(void);
-/* the fixed-base tables `device` built for a key (csrc/bn254_k_comb.hip: comb tables for more than 16 public inputs, byte windows otherwise) against the host construction: the tables of the first `inputs` inputs read back
- * and compared entry by entry as field values; *mismatches = entries that differ */
+/* the fixed-base tables `device` built for a key (csrc/bn254_k_comb.hip) against host arithmetic, as field values; *mismatches = entries that differ.  Comb tables (more
+ * than 16 public inputs): every entry of the first `inputs` inputs against bn254_host.hpp::build_comb_table.  13-bit window tables (up to 16 inputs): every window's first,
+ * middle and last entries and a pseudo-random sample of every input, each against d 2^(13 w) K by double-and-add. */
 int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches);
 int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches);   /* the window tables of a PlonK key's points (csrc/bn254_fw.h): every window's first, middle and last entries and a pseudo-random sample */
 

@@ -156,6 +156,7 @@ template <typename T> static int upload(T** dst, const std::vector<T>& src) {
 // The fixed-base tables of a key, built on the current device from the key's points (bn254_k_comb.hip; form 0: comb tables, 1: byte windows; pts: 18 dwords per point):
 // 80 bytes x 8192 (8160) entries per point stay, the construction scratch (27 dwords per entry, passes of 256 points: 226 MB at most) is freed again.  *dst stays null unless
 // the table is complete (as upload() above).
+static inline int g16_table_form(const G16Prepared& h) { return h.msm_comb ? 0 : h.key_inputs() > (size_t)G16_WIDE_MSM_MIN_INPUTS ? 1 : 2; }
 static int build_tables_on_device(int form, const std::vector<int32_t>& pts, int32_t** dst) {
   if (*dst) return BN254_OK;
   const size_t np = pts.size() / (2 * BN_NL);
@@ -194,7 +195,8 @@ static int ensure_dev(const bn254_g16_pvk* pvk, DevState& d, int device, size_t 
   if (!d.ready) {
     if ((rc = upload(&d.k0, pvk->host.k0)) || (rc = upload(&d.gtab, pvk->host.gtab)) || (rc = upload(&d.dtab, pvk->host.dtab)) || (rc = upload(&d.target, pvk->host.target)))
       return rc;
-    if (!pvk->host.kpts.empty() && pvk->host.msm.empty()) { if ((rc = build_tables_on_device(pvk->host.msm_comb ? 0 : 1, pvk->host.kpts, &d.msm))) return rc; }
+    // comb tables above 16 inputs; 13-bit windows (bn254_fw.h) up to 16; byte windows only for the diagnostic BN254_WIDE_COMB=0 (k_g16_msm_partial)
+    if (!pvk->host.kpts.empty() && pvk->host.msm.empty()) { if ((rc = build_tables_on_device(g16_table_form(pvk->host), pvk->host.kpts, &d.msm))) return rc; }
     else if ((rc = upload(&d.msm, pvk->host.msm))) return rc;
     HIPCK(hipEventCreateWithFlags(&d.busy_ev, hipEventDisableTiming));
     d.ready = true;
@@ -767,8 +769,7 @@ static int rlc_ensure(const bn254_g16_pvk* pvk, DevState* d, size_t n, size_t n_
     }
     int rc;
     if ((rc = upload(&r.btab, pvk->rlc_host.btab)) || (rc = upload(&r.one, pvk->rlc_host.one))) return rc;
-    if (!pvk->rlc_host.pts.empty() && pvk->rlc_host.tab.empty()) { if ((rc = build_tables_on_device(1, pvk->rlc_host.pts, &r.tab))) return rc; }
-    else if ((rc = upload(&r.tab, pvk->rlc_host.tab))) return rc;
+    if ((rc = build_tables_on_device(2, pvk->rlc_host.pts, &r.tab))) return rc;      // -alpha and K[0]: 13-bit windows like the key's own (vm_rlc_group_points reads both)
     r.ready = true;
   }
   if (n > r.grp_cap) {
@@ -2041,34 +2042,21 @@ static int compare_tables(int form, const std::vector<int32_t>& pts, const int32
   *mismatches = bad;
   return BN254_OK;
 }
-int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches) {
-  if (!pvk || !mismatches || inputs < 1) return set_err(BN254_E_BAD_ARG, "bad argument");
-  if (pvk->host.kpts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables were not built on the device");
-  DevState* d = dev_state(pvk, device);
-  std::lock_guard<std::mutex> lk(d->mu);
-  int rc = ensure_dev(pvk, *d, device, 1);
-  if (rc) return rc;
-  return compare_tables(pvk->host.msm_comb ? 0 : 1, pvk->host.kpts, d->msm, inputs, mismatches);
-}
-int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches) {
-  if (!pvk || !mismatches) return set_err(BN254_E_BAD_ARG, "bad argument");
-  PlonkDev* d;
-  std::lock_guard<std::mutex> lk(pvk->mu);
-  int rc = plonk_ensure_dev(pvk, device, &d);
-  if (rc) return rc;
-  // MSM_FW_WINDOWS x (2^MSM_FW_BITS - 1) entries per point: every window's first, middle and last entries and a pseudo-random sample, each against d 2^(bits w) P by double-and-add
-  const size_t np = pvk->fixed_pts.size() / (2 * BN_NL), per = (size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES;
+// window tables of MSM_FW_BITS bits (form 2): MSM_FW_WINDOWS x (2^MSM_FW_BITS - 1) entries per point: every window's first, middle and last entries and a pseudo-random
+// sample, each against d 2^(bits w) P by double-and-add
+static int compare_window_tables(const std::vector<int32_t>& pts, const int32_t* d_tab, size_t* mismatches) {
+  const size_t np = pts.size() / (2 * BN_NL), per = (size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES;
   size_t bad = 0;
   uint64_t x = 0x9E3779B97F4A7C15ull;
   std::vector<int32_t> e(MSM_ENTRY_DWORDS);
   for (size_t i = 0; i < np; i++) {
-    G1Aff P; P.x = fp_from_limbs(pvk->fixed_pts.data() + i * 2 * BN_NL); P.y = fp_from_limbs(pvk->fixed_pts.data() + i * 2 * BN_NL + BN_NL);
+    G1Aff P; P.x = fp_from_limbs(pts.data() + i * 2 * BN_NL); P.y = fp_from_limbs(pts.data() + i * 2 * BN_NL + BN_NL);
     G1Proj bw = g1_from_affine(P);
     for (int w = 0; w < MSM_FW_WINDOWS; w++) {
       std::vector<uint32_t> ds = {1, 2, 3, 255 % MSM_FW_ENTRIES + 1, 256 % MSM_FW_ENTRIES + 1, (MSM_FW_ENTRIES >> 1), (MSM_FW_ENTRIES >> 1) + 1, MSM_FW_ENTRIES - 1, MSM_FW_ENTRIES};
       for (int k = 0; k < 14; k++) { x ^= x >> 12; x ^= x << 25; x ^= x >> 27; ds.push_back(1 + (uint32_t)((x * 0x2545F4914F6CDD1Dull) >> 40) % MSM_FW_ENTRIES); }
       for (uint32_t dd : ds) {
-        HIPCK(hipMemcpy(e.data(), d->fixed_tabs + (i * per + (size_t)w * MSM_FW_ENTRIES + dd - 1) * MSM_ENTRY_DWORDS, MSM_ENTRY_DWORDS * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(e.data(), d_tab + (i * per + (size_t)w * MSM_FW_ENTRIES + dd - 1) * MSM_ENTRY_DWORDS, MSM_ENTRY_DWORDS * sizeof(int32_t), hipMemcpyDeviceToHost));
         G1Proj acc = g1_identity();
         for (int bit = MSM_FW_BITS - 1; bit >= 0; bit--) { acc = g1_dbl(acc); if ((dd >> bit) & 1) acc = g1_add(acc, bw); }
         const G1Aff want = g1_to_affine(acc);
@@ -2079,6 +2067,25 @@ int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t
   }
   *mismatches = bad;
   return BN254_OK;
+}
+int bn254_dbg_comb_table_compare(const bn254_g16_pvk* pvk, int device, int inputs, size_t* mismatches) {
+  if (!pvk || !mismatches || inputs < 1) return set_err(BN254_E_BAD_ARG, "bad argument");
+  if (pvk->host.kpts.empty()) return set_err(BN254_E_BAD_ARG, "the key's tables were not built on the device");
+  DevState* d = dev_state(pvk, device);
+  std::lock_guard<std::mutex> lk(d->mu);
+  int rc = ensure_dev(pvk, *d, device, 1);
+  if (rc) return rc;
+  const int form = g16_table_form(pvk->host);
+  if (form == 2) return compare_window_tables(pvk->host.kpts, d->msm, mismatches);
+  return compare_tables(form, pvk->host.kpts, d->msm, inputs, mismatches);
+}
+int bn254_dbg_plonk_table_compare(const bn254_plonk_pvk* pvk, int device, size_t* mismatches) {
+  if (!pvk || !mismatches) return set_err(BN254_E_BAD_ARG, "bad argument");
+  PlonkDev* d;
+  std::lock_guard<std::mutex> lk(pvk->mu);
+  int rc = plonk_ensure_dev(pvk, device, &d);
+  if (rc) return rc;
+  return compare_window_tables(pvk->fixed_pts, d->fixed_tabs, mismatches);
 }
 // host-only probe of the comb tables of keys with many public inputs: x * P from build_comb_table(P) and the column digits the kernels use
 int bn254_dbg_comb_mul(const uint8_t p64[64], const uint8_t x32[32], uint8_t out64[64]) {

@@ -363,19 +363,23 @@ __device__ __forceinline__ G1Aff c12_msm_entry(const int32_t* __restrict__ msm_t
   q.y.v[7] = v4.x; q.y.v[8] = v4.y;
   return q;
 }
-// L = K0 + sum_i x_i K_i (groth16/verify.rs:53-63) by the twelve lanes of a proof: lane l adds the table entries of the byte-windows w = l, l + 12, ...
-// (32 windows per input); the twelve partial sums are then added through LDS (lanes 0..5: own + lane l + 6; lanes 0, 1: l, l + 2, l + 4; 0 + 1).
+// L = K0 + sum_i x_i K_i (groth16/verify.rs:53-63) by the twelve lanes of a proof: lane l adds the table entries of the windows w = l, l + 12, ...
+// (MSM_FW_WINDOWS = 20 windows of 13 bits per input, bn254_fw.h); the twelve partial sums are then added through LDS (lanes 0..5: own + lane l + 6; lanes 0, 1: l, l + 2, l + 4; 0 + 1).
 // L stays PROJECTIVE: the line of the pair (L, g') is scaled by Z_L, an Fp factor the final exponentiation removes.
 __device__ __noinline__ G1Proj c12_public_input_msm(const Coop12 co, const uint8_t* __restrict__ in /* this proof's inputs */, int n_public, bool use_inputs,
                                                     const int32_t* __restrict__ msm_tab, const int32_t* __restrict__ k0) {
   const uint32_t l12 = 2 * co.c + co.h;
   G1Proj acc = g1_identity();
   if (l12 == 0) { G1Aff K0; for (int l = 0; l < BN_NL; l++) { K0.x.v[l] = k0[l]; K0.y.v[l] = k0[BN_NL + l]; } acc = g1_from_affine(K0); }
-  const int windows = use_inputs ? 32 * n_public : 0;
+  const int windows = use_inputs ? MSM_FW_WINDOWS * n_public : 0;
   for (int w = (int)l12; w < windows; w += 12) {
-    const int sidx = w >> 5, wi = w & 31;
-    const uint32_t dig = in[(size_t)sidx * 32 + (31 - wi)];          // byte j of the big-endian scalar is window 31 - j
-    G1Proj nxt = g1_add_mixed(acc, c12_msm_entry(msm_tab, (size_t)(sidx * 32 + wi) * 255 + (dig ? dig - 1 : 0)));
+    const int sidx = w / MSM_FW_WINDOWS, wi = w - sidx * MSM_FW_WINDOWS;
+    // window wi = bits 13 wi .. 13 wi + 12 of the big-endian scalar (bn254_fw.h): at most three of its bytes, byte 31 - k holding bits 8 k .. 8 k + 7
+    const int bit = MSM_FW_BITS * wi, k0b = bit >> 3;
+    const uint8_t* sc = in + (size_t)sidx * 32;
+    const uint32_t three = (uint32_t)sc[31 - k0b] | (k0b + 1 < 32 ? (uint32_t)sc[30 - k0b] << 8 : 0u) | (k0b + 2 < 32 ? (uint32_t)sc[29 - k0b] << 16 : 0u);
+    const uint32_t dig = (three >> (bit & 7)) & MSM_FW_ENTRIES;
+    G1Proj nxt = g1_add_mixed(acc, c12_msm_entry(msm_tab, (size_t)(sidx * MSM_FW_WINDOWS + wi) * MSM_FW_ENTRIES + (dig ? dig - 1 : 0)));
     const bool take = dig != 0;
     acc.x = fp_select(take, nxt.x, acc.x); acc.y = fp_select(take, nxt.y, acc.y); acc.z = fp_select(take, nxt.z, acc.z);
   }

@@ -271,7 +271,7 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
   const size_t per_base = (out.msm_comb ? ((size_t)1 << G16_COMB_TEETH) : (size_t)32 * 255) * MSM_ENTRY_DWORDS;
   // the tables are built on the device that uses them (bn254_k_comb.hip: milliseconds instead of 2.2 s of host threads and a 671 MB upload for 1024 inputs, 0.18 s for 16);
   // BN254_TABLES_HOST=1 (or its round-5 name BN254_COMB_HOST=1) keeps the host construction
-  if (nb > 0 && !bn254_tables_on_host()) {
+  if (nb > 0 && (!bn254_tables_on_host() || nb <= (size_t)G16_WIDE_MSM_MIN_INPUTS)) {      // keys with up to 16 inputs: 13-bit windows (bn254_fw.h), a device construction only
     out.kpts.resize(nb * 2 * BN_NL);
     for (size_t i = 0; i < nb; i++) { fp_to_limbs(out.kpts.data() + i * 2 * BN_NL, vk.k[i + 1].x); fp_to_limbs(out.kpts.data() + i * 2 * BN_NL + BN_NL, vk.k[i + 1].y); }
     return true;
@@ -295,7 +295,7 @@ inline bool prepare_g16(G16Prepared& out, const G16Key& vk, int mode) {
 struct G16PreparedRlc {
   bool ready = false;
   std::vector<int32_t> btab, tab, one;
-  std::vector<int32_t> pts;              // -alpha and K[0] as affine digits: `tab` is built on the device (empty here) unless BN254_TABLES_HOST=1
+  std::vector<int32_t> pts;              // -alpha and K[0] as affine digits: their window tables are built on the device (`tab` stays empty)
 };
 inline bool prepare_g16_rlc(G16PreparedRlc& out, const G16Prepared& base) {
   std::vector<FixedLine> tb(BN_ATE_STEPS);
@@ -305,17 +305,12 @@ inline bool prepare_g16_rlc(G16PreparedRlc& out, const G16Prepared& base) {
     int32_t* b_ = out.btab.data() + (size_t)s * FIXED_LINE_DWORDS;
     put_fp2(b_, tb[s].m); put_fp2(b_ + 2 * BN_NL, tb[s].c); put_fp2(b_ + 4 * BN_NL, tb[s].xc);
   }
-  if (!bn254_tables_on_host()) {
-    // the two byte-window tables (-alpha, K[0]) are built on the device like the key's own (bn254_k_comb.hip)
+  {
+    // the two window tables (-alpha, K[0]; 13-bit windows, bn254_fw.h) are built on the device like the key's own (bn254_k_comb.hip)
     const G1Aff na = g1_neg(base.alpha);
     out.pts.resize(2 * 2 * BN_NL);
     fp_to_limbs(out.pts.data(), na.x); fp_to_limbs(out.pts.data() + BN_NL, na.y);
     fp_to_limbs(out.pts.data() + 2 * BN_NL, base.k0_pt.x); fp_to_limbs(out.pts.data() + 3 * BN_NL, base.k0_pt.y);
-  } else {
-    out.tab.assign((size_t)2 * 32 * 255 * MSM_ENTRY_DWORDS, 0);
-    std::thread t0([&]() { build_window_table(out.tab.data(), g1_neg(base.alpha)); });
-    build_window_table(out.tab.data() + (size_t)32 * 255 * MSM_ENTRY_DWORDS, base.k0_pt);
-    t0.join();
   }
   out.one.resize(12 * BN_NL);
   put_fp12(out.one.data(), fp12_one());

@@ -197,22 +197,25 @@ k_g16_prepare(const uint8_t* __restrict__ proofs, size_t stride, const uint8_t* 
 #pragma unroll
         for (int k = 0; k < 8; k++) sw[k] = (uint32_t)sp[4 * k] | (uint32_t)sp[4 * k + 1] << 8 | (uint32_t)sp[4 * k + 2] << 16 | (uint32_t)sp[4 * k + 3] << 24;
       }
-      // byte j of the big-endian scalar is sw[j / 4] >> (8 (j % 4)); window wi (weight 2^(8 wi)) is byte 31 - wi.  The bytes are
-      // consumed from the low end of sw[0] and the 256-bit array is shifted down by 8 each time: no dynamic register indexing.
-      // The 80-byte table entry of window j + 1 (18 digits + 2 pad, 16-byte aligned: five 16-byte loads per lane) is in flight while the addition of window j
-      // runs (round 4: load, wait, add per window left the read's latency exposed 64 times per proof with two wavefronts per SIMD to hide it).
-      auto next_digit = [&]() -> uint32_t {
-        const uint32_t dg = sw[0] & 0xff;
+      // sw[] holds the big-endian scalar as it lies in memory; kw[i] = bits 32 i .. 32 i + 31 of its value.  Window wi (MSM_FW_BITS = 13 bits, weight 2^(13 wi): bn254_fw.h --
+      // 20 table additions per input where the byte windows of rounds 1-4 made 32) is consumed from the low end of kw[0] and the 256-bit array is shifted down by 13 each
+      // time: no dynamic register indexing.  The 80-byte table entry of window wi + 1 (18 digits + 2 pad, 16-byte aligned: five 16-byte loads per lane) is in flight
+      // while the addition of window wi runs.
+      uint32_t kw[8];
 #pragma unroll
-        for (int k = 0; k < 7; k++) sw[k] = (sw[k] >> 8) | (sw[k + 1] << 24);
-        sw[7] >>= 8;
+      for (int k = 0; k < 8; k++) kw[k] = __builtin_bswap32(sw[7 - k]);
+      auto next_digit = [&]() -> uint32_t {
+        const uint32_t dg = kw[0] & MSM_FW_ENTRIES;
+#pragma unroll
+        for (int k = 0; k < 7; k++) kw[k] = (kw[k] >> MSM_FW_BITS) | (kw[k + 1] << (32 - MSM_FW_BITS));
+        kw[7] >>= MSM_FW_BITS;
         return dg;
       };
       uint32_t dig = next_digit();
-      G1Aff q = msm_entry(msm_tab, (size_t)(s * 32 + 31) * 255 + (dig ? dig - 1 : 0));
-      for (int j = 0; j < 32; j++) {
+      G1Aff q = msm_entry(msm_tab, (size_t)(s * MSM_FW_WINDOWS) * MSM_FW_ENTRIES + (dig ? dig - 1 : 0));
+      for (int j = 0; j < MSM_FW_WINDOWS; j++) {
         uint32_t dn = 0; G1Aff qn = q;
-        if (j + 1 < 32) { dn = next_digit(); qn = msm_entry(msm_tab, (size_t)(s * 32 + 30 - j) * 255 + (dn ? dn - 1 : 0)); }
+        if (j + 1 < MSM_FW_WINDOWS) { dn = next_digit(); qn = msm_entry(msm_tab, (size_t)(s * MSM_FW_WINDOWS + j + 1) * MSM_FW_ENTRIES + (dn ? dn - 1 : 0)); }
         if (dig != 0) L = g1_add_mixed(L, q);
         dig = dn; q = qn;
       }
@@ -567,7 +570,7 @@ k_rlc_group_points(int32_t* ws, uint32_t n, uint8_t* __restrict__ grp_status, ui
   if (__builtin_amdgcn_ballot_w64(g < groups) == 0) return;
   DevWs w(ws, n, g < groups ? g : DEAD_LANE);
   const int fl = vm_rlc_group_points(w, n_public, [&](int b, int wi, int d) {
-    return b < 2 ? msm_entry(rlc_tab, (size_t)(b * 32 + wi) * 255 + d) : msm_entry(msm_tab, (size_t)((b - 2) * 32 + wi) * 255 + d);
+    return b < 2 ? msm_entry(rlc_tab, (size_t)(b * MSM_FW_WINDOWS + wi) * MSM_FW_ENTRIES + d) : msm_entry(msm_tab, (size_t)((b - 2) * MSM_FW_WINDOWS + wi) * MSM_FW_ENTRIES + d);
   });
   if (g < groups) grp_status[g] = (uint8_t)(BN254_ST_PENDING | ((fl & 1) ? BN254_ST_LINF : 0) | ((fl & 2) ? BN254_ST_LINF2 : 0) | ((fl & 4) ? BN254_ST_LINF3 : 0));
 }

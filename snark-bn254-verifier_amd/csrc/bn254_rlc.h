@@ -15,6 +15,7 @@
 #pragma once
 #include "bn254_vm.h"
 #include "bn254_rlc_plan.h"
+#include "bn254_fw.h"
 
 namespace bn254 {
 
@@ -333,17 +334,17 @@ BN_HD void vm_rlc_fold(W& w, int n_public, bool with_f = true) {
   for (int j = 0; j <= n_public; j++)
     w.st(RLC_T + j, fr8_to_slot(fr8_add(fr8_from_slot(w.ld(RLC_T + j)), fr8_from_slot(w.ld(RLC_HI + RLC_T + j)))));
 }
-// sum over the 32 byte-windows of a 256-bit scalar: acc += sum_w T[w][byte_w(k) - 1].  TL(w, d) returns table entry d of window w.
+// sum over the MSM_FW_WINDOWS windows (MSM_FW_BITS bits each, bn254_fw.h) of a 256-bit scalar: acc += sum_w T[w][digit_w(k) - 1].  TL(w, d) returns table entry d of window w.
 template <class TL>
 BN_HD G1Proj g1_window_sum(G1Proj acc, const Fr8& k, const TL& entry) {
   uint32_t sw[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) sw[i] = k.w[i];
-  for (int wi = 0; wi < 32; wi++) {
-    const uint32_t dig = sw[0] & 0xff;
+  for (int wi = 0; wi < MSM_FW_WINDOWS; wi++) {
+    const uint32_t dig = sw[0] & MSM_FW_ENTRIES;
 #pragma unroll
-    for (int i = 0; i < 7; i++) sw[i] = (sw[i] >> 8) | (sw[i + 1] << 24);
-    sw[7] >>= 8;
+    for (int i = 0; i < 7; i++) sw[i] = (sw[i] >> MSM_FW_BITS) | (sw[i + 1] << (32 - MSM_FW_BITS));
+    sw[7] >>= MSM_FW_BITS;
     if (dig != 0) acc = g1_add_mixed(acc, entry(wi, (int)dig - 1));
   }
   return acc;

@@ -195,15 +195,15 @@ def model_kernel(name, ins):
     unmodelled = []
     prepare_windows = None
     if name == "k_g16_prepare":
-        # the public-input MSM of the 2-input path: n_public x 32 byte windows, a table addition unless the byte is zero.  The software-pipelined loop (the next
+        # the public-input MSM of the 2-input path: n_public x 20 windows of 13 bits (bn254_fw.h), a table addition unless the digit is zero.  The software-pipelined loop (the next
         # window's table entry in flight during the addition) is laid out with several back edges over ONE copy of the addition: the union of those regions
-        # executes n_public x 32 times, however the compiler nests them
+        # executes n_public x 20 times, however the compiler nests them
         w = [(h, l[-1]) for h, l, c in groups if _in(c, R_MIXED)]
         if w:
             prepare_windows = (min(a for a, _ in w), max(b for _, b in w))
             assert _in(count_in(mads, *prepare_windows), R_MIXED), ("k_g16_prepare: more than one addition in the window loops", w)
-            weight_ranges.append((prepare_windows[0], prepare_windows[1], N_PUBLIC * 32.0 * 255.0 / 256.0))
-            notes.append("byte-window loop: %d inputs x 32 windows, table addition (%d mads) unless the byte is zero" % (N_PUBLIC, count_in(mads, *prepare_windows)))
+            weight_ranges.append((prepare_windows[0], prepare_windows[1], N_PUBLIC * (19.0 * 8191.0 / 8192.0 + 511.0 / 512.0)))
+            notes.append("window loop: %d inputs x 20 windows of 13 bits (the top one 9 bits), table addition (%d mads) unless the digit is zero" % (N_PUBLIC, count_in(mads, *prepare_windows)))
     for h, latches, c in groups:
         if prepare_windows and prepare_windows[0] <= h and latches[-1] <= prepare_windows[1]:
             continue
@@ -376,12 +376,12 @@ def coop12_callees(funcs, notes):
     f6 = counts(callee_straight(funcs, "10fp6_mul_nlE"), [])
     out["c12_inv"] = add(counts(ins, e["weights"]), f6, calls)
     notes.append("c12_inv: %s + %d fp6_mul_nl calls" % (e["model"], calls))
-    # public-input MSM: ceil(32 n_public / 12) window additions per lane (the wavefront runs the longest lane), then the tree
+    # public-input MSM: ceil(20 n_public / 12) window additions per lane (the wavefront runs the longest lane), then the tree
     ins = callee_straight(funcs, "20c12_public_input_msmENS")
     lg, _ = loops_of(ins)
     lg = [g for g in lg if g[2] > 1000]
     assert len(lg) == 1, "c12_public_input_msm: one window loop expected"
-    trips = -(-32 * N_PUBLIC // 12)
+    trips = -(-20 * N_PUBLIC // 12)
     out["msm"] = counts(ins, [(lg[0][0], lg[0][1][-1], float(trips))])
     notes.append("c12_public_input_msm: window loop x%d (%d multiply-adds per table addition)" % (trips, lg[0][2]))
     return out, ops
