@@ -186,7 +186,8 @@ int bn254_plonk_verify_batch_flags(const bn254_plonk_pvk* pvk, const uint8_t* pr
  * reserve  allocates NOW what a batch of up to n proofs needs on `device` (contexts of the plan, their buffers; proof_stride > 0: also the pinned staging of the host-buffer
  *          entry for records of that stride), so that the batch itself neither allocates nor frees.  Footprint per context, measured for the SP1 key shape (about 10 KB per proof of capacity plus
  *          1.8 KB per proof and variable MSM term): 0.16 GB for passes of up to 5040 proofs, 1.7 GB for 65 536, 3.5 GB for 131 072, 6.9 GB for 262 144; a batch above
- *          65 536 proofs uses up to eight contexts of its pass size (two for 262 144 proofs).  bn254_plonk_footprint reports what a key holds on a device right now. */
+ *          65 536 proofs uses up to eight contexts of its pass size (two for 262 144 proofs); beside them the window tables of the key's points, 131 MB for the reference's key
+ *          (13 MB per point, built on the device at the key's first use).  bn254_plonk_footprint reports what a key holds on a device right now. */
 int bn254_plonk_verify_batch_device(const bn254_plonk_pvk* pvk, const void* d_proofs, size_t proof_stride, const void* d_public_inputs, size_t n_public, size_t n,
                                     void* d_status, int device, void* hip_stream, unsigned flags);
 int bn254_plonk_verify_batch_multi(const bn254_plonk_pvk* pvk, const uint8_t* proofs, size_t proof_stride, const uint8_t* public_inputs, size_t n_public, size_t n,

@@ -1696,7 +1696,7 @@ int bn254_plonk_reserve(const bn254_plonk_pvk* pvk, size_t n, size_t proof_strid
   for (int w = 0; w < workers; w++) if ((rc = plonk_ensure_ctx(pvk, lease.ctx(w), pass_cap, in_bytes))) return rc;
   return BN254_OK;
 }
-// device memory the contexts of this key hold on `device` right now (bytes; the window tables of the key itself not counted), and how many contexts hold any
+// device memory this key holds on `device` right now: its contexts' buffers and the window tables of its points (131 MB for the reference's key); and how many contexts hold any
 int bn254_plonk_footprint(const bn254_plonk_pvk* pvk, int device, size_t* bytes, int* contexts) {
   if (!pvk || !bytes) return set_err(BN254_E_BAD_ARG, "bad argument");
   *bytes = 0; if (contexts) *contexts = 0;
@@ -1708,6 +1708,7 @@ int bn254_plonk_footprint(const bn254_plonk_pvk* pvk, int device, size_t* bytes,
   }
   if (!d) return BN254_OK;
   std::lock_guard<std::mutex> lk(d->pool_mu);
+  if (d->fixed_tabs) *bytes += (pvk->fixed_pts.size() / (2 * BN_NL)) * (size_t)MSM_FW_WINDOWS * MSM_FW_ENTRIES * MSM_ENTRY_DWORDS * sizeof(int32_t);
   const int T1 = plonk_stage1_terms(pvk->key), TT = plonk_stage2_terms(pvk->key) + 2;
   const size_t tmax = (size_t)(TT > T1 ? TT : T1);
   for (const PlonkCtx& c : d->ctx) {
